@@ -1,0 +1,219 @@
+"""ctypes binding of include/coloc_hip.h.  Thin: every method is one C-ABI call.
+
+No fallback of any kind: if libcoloc_hip.so is missing or a call fails, CLCError is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+KP_DTYPE = np.dtype(
+    {"names": ["x", "y", "score", "angle", "scale"],
+     "formats": ["<i4", "<i4", "u1", "<f4", "u1"],
+     "offsets": [0, 4, 8, 12, 16], "itemsize": 20})   # clc_keypoint == reference Keypoint.h:155-163
+
+CLC_OK, CLC_ERR_BAD_ARG, CLC_ERR_CAPACITY, CLC_ERR_HIP, CLC_ERR_NO_DEVICE, CLC_ERR_STATE = range(6)
+
+
+class CLCError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("coloc_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+class DetectorOptions(C.Structure):   # coloc::DetectorOptions, colocData.hpp:29-36
+    _fields_ = [("scale_factor", C.c_float), ("scale_levels", C.c_uint8), ("width", C.c_uint32),
+                ("height", C.c_uint32), ("maxkp", C.c_uint32), ("thresh", C.c_uint8)]
+
+
+class MatcherOptions(C.Structure):    # coloc::MatcherOptions, colocData.hpp:38-42
+    _fields_ = [("distRatio", C.c_float), ("thresh", C.c_int), ("maxkp", C.c_uint32)]
+
+
+class MatchJob(C.Structure):          # clc_match_job
+    _fields_ = [("q_offset", C.c_uint32), ("nq", C.c_uint32), ("t_offset", C.c_uint32), ("nt", C.c_uint32),
+                ("out_offset", C.c_uint32), ("threshold", C.c_uint32)]
+
+
+EXPORTS = [
+    "clc_abi_version", "clc_status_string", "clc_ctx_create", "clc_ctx_destroy", "clc_last_error_string",
+    "clc_sync", "clc_stream", "clc_pyramid_build", "clc_pyramid_build_dev", "clc_pyramid_level",
+    "clc_pyramid_download", "clc_describe", "clc_describe_dev", "clc_keypoints_to_features",
+    "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
+    "clc_pnp_residuals", "clc_pnp_score",
+]
+
+_lib = None
+
+
+def lib_path():
+    return os.environ.get("COLOC_HIP_LIB", os.path.join(_PKG, "lib", "libcoloc_hip.so"))
+
+
+def load_library():
+    """dlopen libcoloc_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise CLCError(-1, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = C.CDLL(path)
+    lib.clc_status_string.restype = C.c_char_p
+    lib.clc_last_error_string.restype = C.c_char_p
+    lib.clc_last_error_string.argtypes = [C.c_void_p]
+    lib.clc_stream.restype = C.c_void_p
+    lib.clc_stream.argtypes = [C.c_void_p]
+    lib.clc_ctx_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.clc_ctx_destroy.argtypes = [C.c_void_p]
+    lib.clc_sync.argtypes = [C.c_void_p]
+    vp, ci, u32, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_size_t
+    lib.clc_pyramid_build.argtypes = [vp, vp, u32, u32]
+    lib.clc_pyramid_build_dev.argtypes = [vp, vp, u32, u32, sz, vp]
+    lib.clc_pyramid_level.argtypes = [vp, ci, C.POINTER(u32), C.POINTER(u32), C.POINTER(sz), C.POINTER(vp)]
+    lib.clc_pyramid_download.argtypes = [vp, ci, vp]
+    lib.clc_describe.argtypes = [vp, vp, ci, vp]
+    lib.clc_describe_dev.argtypes = [vp, vp, ci, vp, vp]
+    lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
+    lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
+    lib.clc_match_2nn_dev.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
+    lib.clc_match_jobs_dev.argtypes = [vp, vp, vp, ci, vp, vp]
+    lib.clc_set_map.argtypes = [vp, vp, ci]
+    lib.clc_match_map.argtypes = [vp, vp, ci, ci, vp]
+    lib.clc_pnp_residuals.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
+    lib.clc_pnp_score.argtypes = [vp, vp, ci, vp, vp, ci, vp, C.c_double, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def keypoints_to_features(kps):
+    lib = load_library()
+    kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+    out = np.zeros((len(kps), 4), dtype=np.float32)
+    rc = lib.clc_keypoints_to_features(_p(kps), len(kps), _p(out))
+    if rc != CLC_OK:
+        raise CLCError(rc, lib.clc_status_string(rc).decode())
+    return out
+
+
+class Context:
+    """One clc_ctx: device buffers + stream on one GPU (one per host thread / per rank)."""
+
+    def __init__(self, device=0, width=640, height=480, maxkp=10000, scale_factor=1.2, scale_levels=8,
+                 fast_thresh=40, match_thresh=60, detector=True, matcher=True):
+        self.lib = load_library()
+        self.dopts = DetectorOptions(scale_factor, scale_levels, width, height, maxkp, fast_thresh)
+        self.mopts = MatcherOptions(0.8, match_thresh, maxkp)
+        h = C.c_void_p()
+        rc = self.lib.clc_ctx_create(device, C.byref(self.dopts) if detector else None,
+                                     C.byref(self.mopts) if matcher else None, C.byref(h))
+        if rc != CLC_OK:
+            raise CLCError(rc, "clc_ctx_create: " + self.lib.clc_status_string(rc).decode())
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc):
+        if rc != CLC_OK:
+            raise CLCError(rc, "%s: %s" % (self.lib.clc_status_string(rc).decode(),
+                                           self.lib.clc_last_error_string(self.h).decode()))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.clc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self.lib.clc_sync(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.clc_stream(self.h)
+
+    # -- pyramid
+    def pyramid_build(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        self._chk(self.lib.clc_pyramid_build(self.h, _p(img), img.shape[1], img.shape[0]))
+
+    def pyramid_build_dev(self, d_ptr, width, height, pitch, stream=None):
+        self._chk(self.lib.clc_pyramid_build_dev(self.h, d_ptr, width, height, pitch, stream))
+
+    def pyramid_level(self, level):
+        w, h, p, d = C.c_uint32(), C.c_uint32(), C.c_size_t(), C.c_void_p()
+        self._chk(self.lib.clc_pyramid_level(self.h, level, C.byref(w), C.byref(h), C.byref(p), C.byref(d)))
+        return w.value, h.value, p.value, d.value
+
+    def pyramid_download(self, level):
+        w, h, _, _ = self.pyramid_level(level)
+        out = np.zeros((h, w), dtype=np.uint8)
+        self._chk(self.lib.clc_pyramid_download(self.h, level, _p(out)))
+        return out
+
+    # -- describe
+    def describe(self, kps):
+        kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
+        desc = np.zeros((len(kps), 64), dtype=np.uint8)
+        self._chk(self.lib.clc_describe(self.h, _p(kps), len(kps), _p(desc)))
+        return desc
+
+    def describe_dev(self, d_kps, n, d_desc, stream=None):
+        self._chk(self.lib.clc_describe_dev(self.h, d_kps, n, d_desc, stream))
+
+    # -- match
+    def match_2nn(self, Q, T, threshold=40, want_dist=False):
+        Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
+        T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 64)
+        m = np.full(Q.shape[0], -2, dtype=np.int32)
+        b = np.zeros(Q.shape[0], dtype=np.uint16) if want_dist else None
+        s = np.zeros(Q.shape[0], dtype=np.uint16) if want_dist else None
+        self._chk(self.lib.clc_match_2nn(self.h, _p(Q), Q.shape[0], _p(T), T.shape[0], int(threshold), _p(m), _p(b), _p(s)))
+        return (m, b, s) if want_dist else m
+
+    def match_2nn_dev(self, d_q, nq, d_t, nt, threshold, d_match, stream=None):
+        self._chk(self.lib.clc_match_2nn_dev(self.h, d_q, nq, d_t, nt, int(threshold), d_match, stream))
+
+    def match_jobs_dev(self, d_desc_base, jobs, d_match, stream=None):
+        arr = (MatchJob * len(jobs))(*[MatchJob(*j) for j in jobs])
+        self._chk(self.lib.clc_match_jobs_dev(self.h, d_desc_base, arr, len(jobs), d_match, stream))
+
+    def set_map(self, desc):
+        desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 64)
+        self._chk(self.lib.clc_set_map(self.h, _p(desc), desc.shape[0]))
+
+    def match_map(self, Q, threshold=60):
+        Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
+        m = np.full(Q.shape[0], -2, dtype=np.int32)
+        self._chk(self.lib.clc_match_map(self.h, _p(Q), Q.shape[0], int(threshold), _p(m)))
+        return m
+
+    # -- pnp
+    def pnp_residuals(self, Rt, X, x, K):
+        Rt = np.ascontiguousarray(Rt, dtype=np.float64).reshape(-1, 12)
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        err = np.zeros((Rt.shape[0], X.shape[0]), dtype=np.float64)
+        self._chk(self.lib.clc_pnp_residuals(self.h, _p(Rt), Rt.shape[0], _p(X), _p(x), X.shape[0], _p(K), _p(err)))
+        return err
+
+    def pnp_score(self, Rt, X, x, K, thr2):
+        Rt = np.ascontiguousarray(Rt, dtype=np.float64).reshape(-1, 12)
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        cnt = np.zeros(Rt.shape[0], dtype=np.int32)
+        cost = np.zeros(Rt.shape[0], dtype=np.float64)
+        self._chk(self.lib.clc_pnp_score(self.h, _p(Rt), Rt.shape[0], _p(X), _p(x), X.shape[0], _p(K), float(thr2), _p(cnt), _p(cost)))
+        return cnt, cost

@@ -1,0 +1,508 @@
+// capi.hip -- the C ABI of libcoloc_hip.so (include/coloc_hip.h): context, buffers, status codes.
+//
+// Host-side replacement for the CUDA-runtime plumbing of the reference's
+// include/coloc/GPUDetector.hpp (ctor :70-138, detectAndDescribe :216-291) and
+// include/coloc/GPUMatcher.hpp (ctor :70-95, setMapData :110-117, computeMatches :180-226,
+// matchFeaturesWithMap :252-271).  No textures, no per-call object creation (the reference leaks a
+// texture object per frame / per match call, GPUDetector.hpp:240,244, GPUMatcher.hpp:198-201), one
+// stream per context, every HIP status checked and mapped to an int code.
+#include "clc_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace clc;
+
+struct clc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool has_det = false, has_mat = false;
+    clc_detector_opts dopts{};
+    clc_matcher_opts mopts{};
+    // pyramid
+    PyramidDesc pd{};
+    uint8_t* d_arena = nullptr;
+    size_t arena_bytes = 0;
+    bool pyramid_valid = false;
+    // describe
+    clc_keypoint* d_kps = nullptr;
+    uint64_t* d_desc = nullptr;
+    // match
+    uint8_t* d_q = nullptr;
+    uint8_t* d_t = nullptr;
+    uint8_t* d_m = nullptr;
+    int map_n = -1;
+    int32_t* d_match = nullptr;
+    uint16_t* d_best = nullptr;
+    uint16_t* d_second = nullptr;
+    uint2* d_partial = nullptr;
+    size_t partial_cap = 0;
+    int target_blocks = 2048;
+    // pnp
+    double* d_pnp = nullptr;
+    size_t pnp_cap = 0;   // doubles
+};
+
+namespace {
+
+int fail(clc_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (ctx) {
+        char buf[512];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+        else snprintf(buf, sizeof buf, "%s", what);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define CLC_HIP(ctx, call)                                                      \
+    do {                                                                        \
+        hipError_t e__ = (call);                                                \
+        if (e__ != hipSuccess) return fail((ctx), CLC_ERR_HIP, #call, e__);     \
+    } while (0)
+
+hipStream_t pick(clc_ctx* ctx, void* stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) / a * a; }
+
+// GPUDetector.hpp:109-114: f_i = f_{i-1} * scale_factor, dims (uint32)((float)W / f + 0.5f)
+void plan_pyramid(const clc_detector_opts& o, PyramidDesc& pd, size_t& bytes)
+{
+    pd.levels = o.scale_levels;
+    float f = 1.0f;
+    uint32_t off = 0, blk = 0;
+    for (int i = 0; i < pd.levels; ++i) {
+        if (i) f *= o.scale_factor;
+        const uint32_t w = i ? (uint32_t)((float)o.width / f + 0.5f) : o.width;
+        const uint32_t h = i ? (uint32_t)((float)o.height / f + 0.5f) : o.height;
+        pd.f[i] = f;
+        pd.lv[i].w = w;
+        pd.lv[i].h = h;
+        pd.lv[i].pitch = align_up(w ? w : 1, 64);
+        pd.lv[i].offset = off;
+        off += align_up(pd.lv[i].pitch * (h ? h : 1), 256);
+        pd.blk_begin[i] = blk;
+        if (i) blk += (pd.lv[i].pitch / 4 * h + 255) / 256;
+    }
+    for (int i = pd.levels; i <= CLC_MAX_LEVELS; ++i) pd.blk_begin[i] = blk;
+    bytes = off + 256;
+}
+
+int ensure_partial(clc_ctx* ctx, size_t elems)
+{
+    if (elems <= ctx->partial_cap) return CLC_OK;
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_partial) CLC_HIP(ctx, hipFree(ctx->d_partial));
+    ctx->d_partial = nullptr;
+    ctx->partial_cap = 0;
+    size_t cap = elems + elems / 4;
+    CLC_HIP(ctx, hipMalloc((void**)&ctx->d_partial, cap * sizeof(uint2)));
+    ctx->partial_cap = cap;
+    return CLC_OK;
+}
+
+int ensure_pnp(clc_ctx* ctx, size_t doubles)
+{
+    if (doubles <= ctx->pnp_cap) return CLC_OK;
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_pnp) CLC_HIP(ctx, hipFree(ctx->d_pnp));
+    ctx->d_pnp = nullptr;
+    ctx->pnp_cap = 0;
+    CLC_HIP(ctx, hipMalloc((void**)&ctx->d_pnp, doubles * sizeof(double)));
+    ctx->pnp_cap = doubles;
+    return CLC_OK;
+}
+
+int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
+{
+    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), ctx->target_blocks);
+    const int rc = ensure_partial(ctx, plan.partial_elems);
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(ctx, launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st));
+    return CLC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int clc_abi_version(void) { return CLC_ABI_VERSION; }
+
+const char* clc_status_string(int status)
+{
+    switch (status) {
+        case CLC_OK: return "ok";
+        case CLC_ERR_BAD_ARG: return "bad argument";
+        case CLC_ERR_CAPACITY: return "capacity exceeded";
+        case CLC_ERR_HIP: return "HIP runtime error";
+        case CLC_ERR_NO_DEVICE: return "no usable device";
+        case CLC_ERR_STATE: return "invalid call order";
+        default: return "unknown status";
+    }
+}
+
+const char* clc_last_error_string(const clc_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matcher_opts* mopts, clc_ctx** out_ctx)
+{
+    if (!out_ctx) return CLC_ERR_BAD_ARG;
+    *out_ctx = nullptr;
+    if (dopts) {
+        if (dopts->scale_levels < 1 || dopts->scale_levels > CLC_MAX_LEVELS || dopts->width < 8 || dopts->height < 8 ||
+            !(dopts->scale_factor > 1.0f) || dopts->maxkp == 0)
+            return CLC_ERR_BAD_ARG;
+    }
+    if (mopts && mopts->maxkp == 0) return CLC_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return CLC_ERR_NO_DEVICE;
+    clc_ctx* ctx = new (std::nothrow) clc_ctx;
+    if (!ctx) return CLC_ERR_HIP;
+    ctx->device = device_id;
+#define CREATE_HIP(call)                                     \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) {                             \
+            fprintf(stderr, "coloc_hip: %s failed: %s\n", #call, hipGetErrorString(e__)); \
+            clc_ctx_destroy(ctx);                            \
+            return CLC_ERR_HIP;                              \
+        }                                                    \
+    } while (0)
+    CREATE_HIP(hipSetDevice(device_id));
+    CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (const char* e = getenv("CLC_K2NN_TARGET_BLOCKS")) {
+        const int v = atoi(e);
+        if (v > 0) ctx->target_blocks = v;
+    }
+    if (dopts) {
+        ctx->has_det = true;
+        ctx->dopts = *dopts;
+        plan_pyramid(*dopts, ctx->pd, ctx->arena_bytes);
+        CREATE_HIP(hipMalloc((void**)&ctx->d_arena, ctx->arena_bytes));
+        CREATE_HIP(hipMemsetAsync(ctx->d_arena, 0, ctx->arena_bytes, ctx->stream));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_kps, (size_t)dopts->maxkp * sizeof(clc_keypoint)));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_desc, (size_t)dopts->maxkp * CLC_DESC_BYTES));
+    }
+    if (mopts) {
+        ctx->has_mat = true;
+        ctx->mopts = *mopts;
+        const size_t cap = (size_t)mopts->maxkp;
+        CREATE_HIP(hipMalloc((void**)&ctx->d_q, cap * CLC_DESC_BYTES));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_t, cap * CLC_DESC_BYTES));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_m, cap * CLC_DESC_BYTES));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_match, cap * sizeof(int32_t)));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_best, cap * sizeof(uint16_t)));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_second, cap * sizeof(uint16_t)));
+    }
+    // partial workspace: enough for one maxkp x maxkp pair at the target split count
+    {
+        const size_t cap = dopts || mopts ? (size_t)(mopts ? mopts->maxkp : dopts->maxkp) : 16384;
+        const size_t elems = ((cap + 63) & ~(size_t)63) * 128 + 4096;
+        CREATE_HIP(hipMalloc((void**)&ctx->d_partial, elems * sizeof(uint2)));
+        ctx->partial_cap = elems;
+    }
+    CREATE_HIP(hipStreamSynchronize(ctx->stream));
+#undef CREATE_HIP
+    *out_ctx = ctx;
+    return CLC_OK;
+}
+
+int clc_ctx_destroy(clc_ctx* ctx)
+{
+    if (!ctx) return CLC_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void* bufs[] = { ctx->d_arena, ctx->d_kps, ctx->d_desc, ctx->d_q, ctx->d_t, ctx->d_m, ctx->d_match,
+                     ctx->d_best, ctx->d_second, ctx->d_partial, ctx->d_pnp };
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CLC_OK;
+}
+
+int clc_sync(clc_ctx* ctx)
+{
+    if (!ctx) return CLC_ERR_BAD_ARG;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
+void* clc_stream(clc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+/* ---- pyramid ------------------------------------------------------------------------------- */
+
+int clc_pyramid_build_dev(clc_ctx* ctx, const void* d_img, uint32_t width, uint32_t height, size_t pitch, void* stream)
+{
+    if (!ctx || !d_img) return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_build: null argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "pyramid_build: context created without detector options");
+    if (width != ctx->dopts.width || height != ctx->dopts.height || pitch < width)
+        return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_build: image size differs from DetectorOptions width/height");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    const LevelDesc& L0 = ctx->pd.lv[0];
+    CLC_HIP(ctx, hipMemcpy2DAsync(ctx->d_arena + L0.offset, L0.pitch, d_img, pitch, width, height,
+                                  hipMemcpyDeviceToDevice, st));
+    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, st));
+    ctx->pyramid_valid = true;
+    return CLC_OK;
+}
+
+int clc_pyramid_build(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32_t height)
+{
+    if (!ctx || !h_img) return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_build: null argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "pyramid_build: context created without detector options");
+    if (width != ctx->dopts.width || height != ctx->dopts.height)
+        return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_build: image size differs from DetectorOptions width/height");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    const LevelDesc& L0 = ctx->pd.lv[0];
+    CLC_HIP(ctx, hipMemcpy2DAsync(ctx->d_arena + L0.offset, L0.pitch, h_img, width, width, height,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pyramid_valid = true;
+    return CLC_OK;
+}
+
+int clc_pyramid_level(const clc_ctx* ctx, int level, uint32_t* w, uint32_t* h, size_t* pitch, const void** d_ptr)
+{
+    if (!ctx || !ctx->has_det || level < 0 || level >= ctx->pd.levels) return CLC_ERR_BAD_ARG;
+    const LevelDesc& L = ctx->pd.lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (pitch) *pitch = L.pitch;
+    if (d_ptr) *d_ptr = ctx->d_arena + L.offset;
+    return CLC_OK;
+}
+
+int clc_pyramid_download(clc_ctx* ctx, int level, uint8_t* h_out)
+{
+    if (!ctx || !h_out) return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_download: null argument");
+    if (!ctx->has_det || level < 0 || level >= ctx->pd.levels) return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_download: bad level");
+    if (!ctx->pyramid_valid) return fail(ctx, CLC_ERR_STATE, "pyramid_download before pyramid_build");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    const LevelDesc& L = ctx->pd.lv[level];
+    CLC_HIP(ctx, hipMemcpy2DAsync(h_out, L.w, ctx->d_arena + L.offset, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
+/* ---- describe ------------------------------------------------------------------------------ */
+
+int clc_describe_dev(clc_ctx* ctx, const clc_keypoint* d_kps, int n, void* d_desc, void* stream)
+{
+    if (!ctx || n < 0 || (n > 0 && (!d_kps || !d_desc))) return fail(ctx, CLC_ERR_BAD_ARG, "describe: bad argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "describe: context created without detector options");
+    if (!ctx->pyramid_valid) return fail(ctx, CLC_ERR_STATE, "describe before pyramid_build");
+    if (((uintptr_t)d_desc & 7u) || ((uintptr_t)d_kps & 3u)) return fail(ctx, CLC_ERR_BAD_ARG, "describe: misaligned device pointer");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    CLC_HIP(ctx, launch_clatch(ctx->pd, ctx->d_arena, d_kps, n, (uint64_t*)d_desc, pick(ctx, stream)));
+    return CLC_OK;
+}
+
+int clc_describe(clc_ctx* ctx, const clc_keypoint* h_kps, int n, uint8_t* h_desc)
+{
+    if (!ctx || n < 0 || (n > 0 && (!h_kps || !h_desc))) return fail(ctx, CLC_ERR_BAD_ARG, "describe: bad argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "describe: context created without detector options");
+    if ((uint32_t)n > ctx->dopts.maxkp) return fail(ctx, CLC_ERR_CAPACITY, "describe: more keypoints than DetectorOptions.maxkp");
+    if (!ctx->pyramid_valid) return fail(ctx, CLC_ERR_STATE, "describe before pyramid_build");
+    if (n == 0) return CLC_OK;
+    for (int i = 0; i < n; ++i)
+        if (h_kps[i].scale >= ctx->pd.levels) return fail(ctx, CLC_ERR_BAD_ARG, "describe: keypoint scale >= scale_levels");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    CLC_HIP(ctx, hipMemcpyAsync(ctx->d_kps, h_kps, (size_t)n * sizeof(clc_keypoint), hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_clatch(ctx->pd, ctx->d_arena, ctx->d_kps, n, ctx->d_desc, ctx->stream));
+    CLC_HIP(ctx, hipMemcpyAsync(h_desc, ctx->d_desc, (size_t)n * CLC_DESC_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
+int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4)
+{
+    if (n < 0 || (n > 0 && (!h_kps || !h_feat4))) return CLC_ERR_BAD_ARG;
+    for (int i = 0; i < n; ++i) {
+        // GPUDetector.hpp:173: static_cast<float>(std::pow(1.2f, kps[i].scale)) -- pow(float, integer) is evaluated in double
+        const float scale = (float)std::pow((double)1.2f, (double)h_kps[i].scale);
+        h_feat4[4 * i + 0] = scale * (float)h_kps[i].x;
+        h_feat4[4 * i + 1] = scale * (float)h_kps[i].y;
+        h_feat4[4 * i + 2] = 7.0f * scale;
+        h_feat4[4 * i + 3] = h_kps[i].angle;
+    }
+    return CLC_OK;
+}
+
+/* ---- match ---------------------------------------------------------------------------------- */
+
+int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int threshold,
+                      int32_t* d_match, void* stream)
+{
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_match)) || (nt > 0 && !d_t))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_2nn: bad argument");
+    if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 15u) || ((uintptr_t)d_match & 3u))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_2nn: device pointers must be 16-byte aligned");
+    if (nq == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<K2nnJobDev> jobs(1);
+    jobs[0] = K2nnJobDev{};
+    jobs[0].q = (const uint4*)d_q;
+    jobs[0].t = (const uint4*)d_t;
+    jobs[0].out = d_match;
+    jobs[0].nq = (uint32_t)nq;
+    jobs[0].nt = (uint32_t)nt;
+    jobs[0].thr = (uint32_t)(uint8_t)threshold;   // CUDAK2NN.cu:46: the kernel parameter is uint8_t
+    return run_jobs(ctx, jobs, pick(ctx, stream));
+}
+
+int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs, int njobs,
+                       int32_t* d_match, void* stream)
+{
+    if (!ctx || njobs < 0 || (njobs > 0 && (!d_desc_base || !h_jobs || !d_match)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs: bad argument");
+    if (((uintptr_t)d_desc_base & 15u) || ((uintptr_t)d_match & 3u))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs: device pointers must be 16-byte aligned");
+    if (njobs == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<K2nnJobDev> jobs;
+    jobs.reserve(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        if (h_jobs[j].nq == 0) continue;
+        K2nnJobDev jb{};
+        jb.q = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].q_offset * CLC_DESC_BYTES);
+        jb.t = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].t_offset * CLC_DESC_BYTES);
+        jb.out = d_match + h_jobs[j].out_offset;
+        jb.nq = h_jobs[j].nq;
+        jb.nt = h_jobs[j].nt;
+        jb.thr = (uint32_t)(uint8_t)h_jobs[j].threshold;
+        jobs.push_back(jb);
+    }
+    if (jobs.empty()) return CLC_OK;
+    return run_jobs(ctx, jobs, pick(ctx, stream));
+}
+
+static int match_host(clc_ctx* ctx, const void* h_q, int nq, const uint8_t* d_train, int nt, int threshold,
+                      int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
+{
+    CLC_HIP(ctx, hipMemcpyAsync(ctx->d_q, h_q, (size_t)nq * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<K2nnJobDev> jobs(1);
+    jobs[0] = K2nnJobDev{};
+    jobs[0].q = (const uint4*)ctx->d_q;
+    jobs[0].t = (const uint4*)d_train;
+    jobs[0].out = ctx->d_match;
+    jobs[0].best_out = h_best ? ctx->d_best : nullptr;
+    jobs[0].second_out = h_second ? ctx->d_second : nullptr;
+    jobs[0].nq = (uint32_t)nq;
+    jobs[0].nt = (uint32_t)nt;
+    jobs[0].thr = (uint32_t)(uint8_t)threshold;
+    const int rc = run_jobs(ctx, jobs, ctx->stream);
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(ctx, hipMemcpyAsync(h_match, ctx->d_match, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (h_best) CLC_HIP(ctx, hipMemcpyAsync(h_best, ctx->d_best, (size_t)nq * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (h_second) CLC_HIP(ctx, hipMemcpyAsync(h_second, ctx->d_second, (size_t)nq * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
+int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt, int threshold,
+                  int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
+{
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!h_q || !h_match)) || (nt > 0 && !h_t))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_2nn: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "match_2nn: context created without matcher options");
+    if ((uint32_t)nq > ctx->mopts.maxkp || (uint32_t)nt > ctx->mopts.maxkp)
+        return fail(ctx, CLC_ERR_CAPACITY, "match_2nn: more descriptors than MatcherOptions.maxkp");
+    if (nq == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    if (nt > 0) CLC_HIP(ctx, hipMemcpyAsync(ctx->d_t, h_t, (size_t)nt * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    return match_host(ctx, h_q, nq, ctx->d_t, nt, threshold, h_match, h_best, h_second);
+}
+
+int clc_set_map(clc_ctx* ctx, const void* h_desc, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && !h_desc)) return fail(ctx, CLC_ERR_BAD_ARG, "set_map: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "set_map: context created without matcher options");
+    if ((uint32_t)n > ctx->mopts.maxkp) return fail(ctx, CLC_ERR_CAPACITY, "set_map: more descriptors than MatcherOptions.maxkp");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    if (n > 0) CLC_HIP(ctx, hipMemcpyAsync(ctx->d_m, h_desc, (size_t)n * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->map_n = n;
+    return CLC_OK;
+}
+
+int clc_match_map(clc_ctx* ctx, const void* h_q, int nq, int threshold, int32_t* h_match)
+{
+    if (!ctx || nq < 0 || (nq > 0 && (!h_q || !h_match))) return fail(ctx, CLC_ERR_BAD_ARG, "match_map: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "match_map: context created without matcher options");
+    if (ctx->map_n < 0) return fail(ctx, CLC_ERR_STATE, "match_map before set_map");
+    if ((uint32_t)nq > ctx->mopts.maxkp) return fail(ctx, CLC_ERR_CAPACITY, "match_map: more descriptors than MatcherOptions.maxkp");
+    if (nq == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    return match_host(ctx, h_q, nq, ctx->d_m, ctx->map_n, threshold, h_match, nullptr, nullptr);
+}
+
+/* ---- PnP ------------------------------------------------------------------------------------ */
+
+static int pnp_upload(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, const double* h_x, int N,
+                      const double* h_K, size_t extra, double** dRt, double** dX, double** dx, double** dK, double** dExtra)
+{
+    const size_t need = (size_t)12 * H + (size_t)5 * N + 16 + extra;
+    const int rc = ensure_pnp(ctx, need);
+    if (rc != CLC_OK) return rc;
+    double* p = ctx->d_pnp;
+    *dRt = p; p += (size_t)12 * H;
+    *dX = p; p += (size_t)3 * N;
+    *dx = p; p += (size_t)2 * N;
+    *dK = p; p += 16;
+    *dExtra = p;
+    CLC_HIP(ctx, hipMemcpyAsync(*dRt, h_Rt, sizeof(double) * 12 * H, hipMemcpyHostToDevice, ctx->stream));
+    if (N > 0) {
+        CLC_HIP(ctx, hipMemcpyAsync(*dX, h_X, sizeof(double) * 3 * N, hipMemcpyHostToDevice, ctx->stream));
+        CLC_HIP(ctx, hipMemcpyAsync(*dx, h_x, sizeof(double) * 2 * N, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CLC_HIP(ctx, hipMemcpyAsync(*dK, h_K, sizeof(double) * 9, hipMemcpyHostToDevice, ctx->stream));
+    return CLC_OK;
+}
+
+int clc_pnp_residuals(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, const double* h_x, int N,
+                      const double* h_K, double* h_err)
+{
+    if (!ctx || H < 0 || N < 0 || !h_K || (H > 0 && !h_Rt) || (N > 0 && (!h_X || !h_x)) || (H > 0 && N > 0 && !h_err))
+        return fail(ctx, CLC_ERR_BAD_ARG, "pnp_residuals: bad argument");
+    if (H == 0 || N == 0) return CLC_OK;
+    if (H > 65535) return fail(ctx, CLC_ERR_CAPACITY, "pnp_residuals: more than 65535 hypotheses per call");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    double *dRt, *dX, *dx, *dK, *dE;
+    const int rc = pnp_upload(ctx, h_Rt, H, h_X, h_x, N, h_K, (size_t)H * N, &dRt, &dX, &dx, &dK, &dE);
+    if (rc != CLC_OK) return rc;
+    CLC_HIP(ctx, launch_pnp_residuals(dRt, H, dX, dx, N, dK, dE, ctx->stream));
+    CLC_HIP(ctx, hipMemcpyAsync(h_err, dE, sizeof(double) * (size_t)H * N, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
+int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, const double* h_x, int N,
+                  const double* h_K, double thr2, int32_t* h_count, double* h_cost)
+{
+    if (!ctx || H < 0 || N < 0 || !h_K || (H > 0 && !h_Rt) || (N > 0 && (!h_X || !h_x)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "pnp_score: bad argument");
+    if (H == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    double *dRt, *dX, *dx, *dK, *dE;
+    const int rc = pnp_upload(ctx, h_Rt, H, h_X, h_x, N, h_K, (size_t)2 * H, &dRt, &dX, &dx, &dK, &dE);
+    if (rc != CLC_OK) return rc;
+    double* d_cost = dE;
+    int32_t* d_count = (int32_t*)(dE + H);
+    CLC_HIP(ctx, launch_pnp_score(dRt, H, dX, dx, N, dK, thr2, d_count, d_cost, ctx->stream));
+    if (h_cost) CLC_HIP(ctx, hipMemcpyAsync(h_cost, d_cost, sizeof(double) * H, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_count) CLC_HIP(ctx, hipMemcpyAsync(h_count, d_count, sizeof(int32_t) * H, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,70 @@
+// clc_internal.h -- shared declarations of libcoloc_hip.so's translation units (not installed).
+#ifndef CLC_INTERNAL_H
+#define CLC_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/coloc_hip.h"
+
+namespace clc {
+
+// ---- pyramid -------------------------------------------------------------------------------
+struct LevelDesc {
+    uint32_t w, h;        // level size
+    uint32_t pitch;       // bytes per row (multiple of 64)
+    uint32_t offset;      // byte offset of the level inside the pyramid arena
+};
+struct PyramidDesc {
+    LevelDesc lv[CLC_MAX_LEVELS];
+    float     f[CLC_MAX_LEVELS];      // resampling factor of level i (f_0 = 1)
+    uint32_t  blk_begin[CLC_MAX_LEVELS + 1]; // first workgroup of level i in the fused resample launch
+    int       levels;
+};
+
+// Resample levels 1..L-1 from level 0 (all inside `arena`) in one launch.
+hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream);
+
+// ---- CLATCH ----------------------------------------------------------------------------------
+hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
+                         int n, uint64_t* d_desc, hipStream_t stream);
+
+// ---- K2NN ------------------------------------------------------------------------------------
+struct K2nnJobDev {
+    const uint4* q;        // first query row of this job
+    const uint4* t;        // first train row
+    int32_t*     out;      // match indices, nq entries
+    uint16_t*    best_out; // nullable
+    uint16_t*    second_out; // nullable
+    uint32_t     nq, nt;
+    uint32_t     thr;      // already truncated to 8 bits
+    uint32_t     qblocks;  // ceil(nq / queries-per-workgroup)
+    uint32_t     splits;   // train-dimension splits
+    uint32_t     t_per_split;
+    uint32_t     partial_off; // first uint2 of this job's partial slab
+    uint32_t     nq_pad;      // row length of the slab
+};
+static constexpr int kK2nnJobsPerLaunch = 16;
+// Passed BY VALUE as the kernel argument (1.2 KB of kernarg): no job upload, no staging hazard.
+struct K2nnJobList {
+    K2nnJobDev j[kK2nnJobsPerLaunch];
+};
+struct K2nnPlan {
+    size_t   partial_elems;// uint2 entries needed
+};
+// Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks);
+// Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
+hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream);
+int k2nn_queries_per_block();
+
+// ---- PnP -------------------------------------------------------------------------------------
+hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x,
+                                int N, const double* d_K, double* d_err, hipStream_t stream);
+hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,
+                            const double* d_K, double thr2, int32_t* d_count, double* d_cost,
+                            hipStream_t stream);
+
+} // namespace clc
+#endif

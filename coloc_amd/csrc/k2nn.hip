@@ -1,0 +1,216 @@
+// k2nn.hip -- brute-force 2-NN matcher for 512-bit descriptors on gfx950 (MI355X).
+//
+// Semantics: reference src/CUDAK2NN.cu:46-75 (per query: running best / second-best Hamming
+// distance over all train vectors in index order, accept iff second - best > threshold, ties for
+// the minimum keep the lowest train index).  The ARCHITECTURE is not the reference's: that kernel
+// is a 1-D grid of 256 queries per block (40 blocks at 10k queries, CUDAK2NN.cu:79) built around
+// a 32-lane shuffle butterfly.  Here:
+//
+//   * lane = query.  Each lane keeps R complete 512-bit queries in VGPRs (16 dwords each), so a
+//     distance needs NO cross-lane traffic at all.
+//   * the train vector is wave-uniform: it is fetched with ONE scalar load (s_load_dwordx16, 64 B)
+//     into SGPRs and used directly as the scalar operand of v_xor_b32 -- no LDS, no VGPRs, no
+//     vector-memory instructions in the inner loop.  Per (query, train) pair the VALU executes
+//     16 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate) = 32 lane-ops.
+//   * top-2 without branches or an index register: key = (distance << 22) | train_index_in_split.
+//     Unsigned order on keys is (distance, index) lexicographic, so best' = min(best, key) keeps
+//     the lowest index among equal distances, and second' = med3(best, second, key) is the second
+//     smallest key = the second smallest distance of the multiset.  3 more lane-ops per pair.
+//   * 2-D decomposition: (query block) x (train split) so that 10k x 10k fills 256 CUs x 8
+//     waves/SIMD; every (split, query) writes an 8-byte partial {best_key, second_key} and a tiny
+//     second kernel folds the splits left-to-right with the exact merge rule of SURVEY.md 8(a)
+//     note N1 (A = lower train indices), applies the threshold and writes the int32 result.
+//
+// Bound: integer VALU (32 of the 35 lane-ops per pair are the algorithmic xor+popcount); HBM
+// traffic is the compulsory 64*(nq+nt) B plus 16*splits*nq B of partials.
+#include "clc_internal.h"
+
+namespace clc {
+
+static constexpr int kR = 2;                 // queries per lane
+static constexpr int kWaves = 4;             // waves per workgroup
+static constexpr int kQPerBlock = 64 * kR * kWaves;
+static constexpr uint32_t kKeyShift = 22;    // distance <= 512 needs 10 bits; 22 bits of index
+static constexpr uint32_t kIdxMask = (1u << kKeyShift) - 1u;
+static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+// Pointers arrive inside a job record read from memory, so the compiler only knows them as
+// generic.  Re-type them: train rows as CONSTANT address space (wave-uniform address -> s_load),
+// query rows / partials as GLOBAL (global_load / global_store instead of flat_*).
+// (builtin vector types: HIP's uint4 class has no constructors from qualified address spaces)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const u32x4 __attribute__((address_space(4)))* const_u4_ptr;
+typedef const u32x4 __attribute__((address_space(1)))* global_cu4_ptr;
+typedef u32x2 __attribute__((address_space(1)))* global_u2_ptr;
+
+int k2nn_queries_per_block() { return kQPerBlock; }
+
+__device__ __forceinline__ uint32_t bcnt_first(uint32_t x)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// One train vector (16 wave-uniform dwords) against the R queries of this lane.
+template <int R>
+__device__ __forceinline__ void sweep_one(const uint32_t (&q)[R][16], const u32x4 a, const u32x4 b,
+                                          const u32x4 c, const u32x4 d, const uint32_t t_rel,
+                                          uint32_t (&best)[R], uint32_t (&second)[R])
+{
+    const uint32_t tw[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w,
+                              c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t acc = bcnt_first(q[r][0] ^ tw[0]);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) acc = bcnt_acc(q[r][k] ^ tw[k], acc);
+        const uint32_t key = (acc << kKeyShift) + t_rel;
+        second[r] = umed3(best[r], second[r], key);
+        best[r] = min(best[r], key);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobList jobs,
+                                                                  uint2* __restrict__ partial)
+{
+    const K2nnJobDev& job = jobs.j[blockIdx.y];
+    const uint32_t nblk = job.qblocks * job.splits;
+    if (blockIdx.x >= nblk) return;
+    // consecutive workgroups walk the splits of one query block: they read disjoint train slices
+    const uint32_t qblock = blockIdx.x / job.splits;
+    const uint32_t split = blockIdx.x - qblock * job.splits;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t qbase = qblock * (64u * R * kWaves) + wave * (64u * R) + lane;
+
+    uint32_t q[R][16];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t qi = qbase + 64u * r;
+        if (qi >= job.nq) qi = job.nq - 1u;   // clamp: duplicate work, never stored
+        const global_cu4_ptr qp = (global_cu4_ptr)(uintptr_t)job.q + (size_t)qi * 4u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x4 v = qp[k];
+            q[r][4 * k + 0] = v.x; q[r][4 * k + 1] = v.y; q[r][4 * k + 2] = v.z; q[r][4 * k + 3] = v.w;
+        }
+    }
+    uint32_t best[R], second[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best[r] = kEmpty; second[r] = kEmpty; }
+
+    const uint32_t t0 = split * job.t_per_split;
+    uint32_t t1 = t0 + job.t_per_split;
+    if (t1 > job.nt) t1 = job.nt;
+    const_u4_ptr tp = (const_u4_ptr)(uintptr_t)job.t + (size_t)t0 * 4u;   // wave-uniform -> s_load_dwordx16
+    for (uint32_t t = t0; t < t1; ++t, tp += 4) {
+        const u32x4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        sweep_one<R>(q, a, b, c, d, t - t0, best, second);
+    }
+
+    const global_u2_ptr prow = (global_u2_ptr)(uintptr_t)partial + job.partial_off + (size_t)split * job.nq_pad;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t qi = qbase + 64u * r;
+        if (qi < job.nq) prow[qi] = u32x2{ best[r], second[r] };
+    }
+}
+
+// Fold the per-split partials of one query left to right and threshold.
+__global__ __launch_bounds__(256) void k2nn_merge_kernel(const K2nnJobList jobs,
+                                                          const uint2* __restrict__ partial)
+{
+    const K2nnJobDev& job = jobs.j[blockIdx.y];
+    const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
+    if (qi >= job.nq) return;
+    int best_v = 100000, second_v = 200000, best_i = -1;   // CUDAK2NN.cu:54 sentinels
+    const uint2* p = partial + job.partial_off + qi;
+    const uint32_t nsplit = job.nt ? job.splits : 0u;   // nt == 0: nothing was swept -> -1
+    for (uint32_t s = 0; s < nsplit; ++s, p += job.nq_pad) {
+        const uint2 e = *p;
+        if (e.x == kEmpty) continue;
+        const int b_best = (int)(e.x >> kKeyShift);
+        const int b_idx = (int)(s * job.t_per_split + (e.x & kIdxMask));
+        const int b_second = e.y == kEmpty ? 100000 : (int)(e.y >> kKeyShift);
+        if (b_best < best_v) {
+            second_v = min(best_v, b_second);
+            best_v = b_best;
+            best_i = b_idx;
+        } else {
+            second_v = min(second_v, b_best);
+        }
+    }
+    job.out[qi] = (best_i >= 0 && second_v - best_v > (int)job.thr) ? best_i : -1;
+    if (job.best_out) job.best_out[qi] = (uint16_t)min(best_v, 65535);
+    if (job.second_out) job.second_out[qi] = (uint16_t)min(second_v, 65535);
+}
+
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
+{
+    K2nnPlan plan{0};
+    uint32_t total_qblocks = 0;
+    for (int j = 0; j < njobs; ++j) {
+        jobs[j].qblocks = (jobs[j].nq + kQPerBlock - 1) / kQPerBlock;
+        total_qblocks += jobs[j].qblocks;
+    }
+    if (total_qblocks == 0) total_qblocks = 1;
+    uint32_t want = ((uint32_t)target_blocks + total_qblocks - 1) / total_qblocks;
+    if (want < 1) want = 1;
+    size_t off = 0;
+    for (int j = 0; j < njobs; ++j) {
+        K2nnJobDev& jb = jobs[j];
+        uint32_t splits = want;
+        const uint32_t max_splits = jb.nt / 32u > 0 ? jb.nt / 32u : 1u;   // >= 32 train vectors per split
+        if (splits > max_splits) splits = max_splits;
+        uint32_t per = jb.nt ? (jb.nt + splits - 1) / splits : 1u;
+        if (per > kIdxMask + 1u) per = kIdxMask + 1u;                     // index field is 22 bits
+        splits = jb.nt ? (jb.nt + per - 1) / per : 1u;
+        jb.splits = splits;
+        jb.t_per_split = per;
+        jb.nq_pad = (jb.nq + 63u) & ~63u;
+        jb.partial_off = (uint32_t)off;
+        off += (size_t)splits * jb.nq_pad;
+    }
+    plan.partial_elems = off;
+    return plan;
+}
+
+hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream)
+{
+    for (int base = 0; base < njobs; base += kK2nnJobsPerLaunch) {
+        const int cnt = njobs - base < kK2nnJobsPerLaunch ? njobs - base : kK2nnJobsPerLaunch;
+        K2nnJobList list;
+        uint32_t grid_x = 0, max_nq = 0;
+        for (int j = 0; j < cnt; ++j) {
+            list.j[j] = jobs[base + j];
+            const uint32_t gx = list.j[j].nt ? list.j[j].qblocks * list.j[j].splits : 0u;
+            if (gx > grid_x) grid_x = gx;
+            if (list.j[j].nq > max_nq) max_nq = list.j[j].nq;
+        }
+        for (int j = cnt; j < kK2nnJobsPerLaunch; ++j) list.j[j] = K2nnJobDev{};
+        if (max_nq == 0) continue;
+        if (grid_x > 0)
+            hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
+        hipLaunchKernelGGL(k2nn_merge_kernel, dim3((max_nq + 255) / 256, cnt), dim3(256), 0, stream, list,
+                           (const uint2*)d_partial);
+    }
+    return hipGetLastError();
+}
+
+} // namespace clc

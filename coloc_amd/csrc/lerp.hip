@@ -1,0 +1,86 @@
+// lerp.hip -- scale-space pyramid: bilinear resample of level 0 into levels 1..L-1 (u8 -> u8).
+//
+// Semantics: reference src/CUDALERP.cu:157-178 for one output pixel and
+// include/coloc/GPUDetector.hpp:109-114,249-254 for level sizes / factors (every level is
+// resampled FROM LEVEL 0 with gxs = gys = f_i, f_i = f_{i-1} * scale_factor in fp32).
+// Texture-unit behaviour restated in plain arithmetic: tex2Dgather footprint = the four texels
+// (i,j),(i+1,j),(i,j+1),(i+1,j+1) with i = floor(fx), j = floor(fy), clamp-to-edge addressing
+// (GPUDetector.hpp:96-97) and normalized-float reads u8/255.0f (:239).  fp32, evaluation order as
+// written in the source, no FMA contraction (the file is built with -ffp-contract=off).
+//
+// MI355X shape: the reference issues 7 launches on 7 streams (GPUDetector.hpp:250-255); here ALL
+// levels are one launch.  Each lane produces 4 horizontally adjacent output pixels and stores one
+// dword, so a wave writes 256 contiguous bytes; the source taps are plain byte loads from the
+// L2-resident level-0 image (640x480 = 300 KB).  HBM-trivial: writes 2.09 x W x H bytes.
+#include "clc_internal.h"
+
+namespace clc {
+
+struct LerpArgs {
+    PyramidDesc pd;
+};
+
+__device__ __forceinline__ float tap(const uint8_t* __restrict__ img, uint32_t pitch, int W, int H, int x, int y)
+{
+    x = min(max(x, 0), W - 1);
+    y = min(max(y, 0), H - 1);
+    return (float)img[(size_t)y * pitch + (size_t)x] / 255.0f;
+}
+
+__global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t* __restrict__ arena)
+{
+    // which level does this workgroup belong to?  (wave-uniform scan over <= 7 entries)
+    int lv = 1;
+#pragma unroll
+    for (int i = 2; i < CLC_MAX_LEVELS; ++i)
+        if (i < a.pd.levels && blockIdx.x >= a.pd.blk_begin[i]) lv = i;
+    const LevelDesc L = a.pd.lv[lv];
+    const LevelDesc L0 = a.pd.lv[0];
+    const float gs = a.pd.f[lv];
+    const uint32_t dpr = L.pitch >> 2;                       // dwords per output row
+    const uint32_t idx = (blockIdx.x - a.pd.blk_begin[lv]) * 256u + threadIdx.x;
+    if (idx >= dpr * L.h) return;
+    const uint32_t y = idx / dpr;
+    const uint32_t x0 = (idx - y * dpr) << 2;
+    const uint8_t* __restrict__ src = arena + L0.offset;
+    const int W = (int)L0.w, H = (int)L0.h;
+
+    const float fy = ((float)y + 0.5f) * gs - 0.5f;          // CUDALERP.cu:160
+    const float fl_y = floorf(fy);
+    const float wt_y = fy - fl_y;
+    const float invwt_y = 1.0f - wt_y;
+    const int j = (int)fl_y;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t x = x0 + k;
+        const float fx = ((float)x + 0.5f) * gs - 0.5f;      // :165
+        const float fl_x = floorf(fx);
+        const int i = (int)fl_x;
+        const float f_w = tap(src, L0.pitch, W, H, i, j);
+        const float f_z = tap(src, L0.pitch, W, H, i + 1, j);
+        const float f_x = tap(src, L0.pitch, W, H, i, j + 1);
+        const float f_y = tap(src, L0.pitch, W, H, i + 1, j + 1);
+        const float wt_x = fx - fl_x;
+        const float invwt_x = 1.0f - wt_x;
+        const float xa = invwt_x * f_w + wt_x * f_z;         // :172
+        const float xb = invwt_x * f_x + wt_x * f_y;         // :173
+        const float res = 255.0f * (invwt_y * xa + wt_y * xb) + 0.5f;   // :174
+        const uint32_t v = x < L.w ? (uint32_t)(uint8_t)res : 0u;       // truncating store :177
+        packed |= v << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(arena + L.offset + (size_t)y * L.pitch + x0) = packed;
+}
+
+hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream)
+{
+    if (pd.levels <= 1) return hipSuccess;
+    LerpArgs a;
+    a.pd = pd;
+    const uint32_t nblk = pd.blk_begin[pd.levels] - pd.blk_begin[1];
+    if (nblk == 0) return hipSuccess;
+    hipLaunchKernelGGL(pyramid_kernel, dim3(pd.blk_begin[pd.levels]), dim3(256), 0, stream, a, arena);
+    return hipGetLastError();
+}
+
+} // namespace clc

@@ -1,0 +1,165 @@
+/*
+ * coloc_hip.h -- C ABI of libcoloc_hip.so: the MI355X (gfx950) implementation of CoLoC's
+ * describe -> 512-bit Hamming 2-NN match -> batched PnP scoring hot path.
+ *
+ * This is the drop-in boundary.  It replaces the reference's static library `koral`
+ * (CMakeLists.txt:37 = src/CUDALERP.cu + src/CLATCH.cu + src/CUDAK2NN.cu) and the CUDA-runtime
+ * plumbing inside include/coloc/GPUDetector.hpp / GPUMatcher.hpp.  Plain C types only: no C++
+ * types, no exceptions, no exit() -- every entry point returns an int status (the reference
+ * aborts via exit(code) on four calls and ignores all other CUDA errors,
+ * GPUMatcher.hpp:33-41,188-195).
+ *
+ * Conventions
+ *   - descriptors: rows of 64 bytes = 16 little-endian uint32 = 8 little-endian uint64
+ *     (CLATCH.cu:185-188, CUDAK2NN.cu:47-52).
+ *   - `h_` pointers are host memory (caller-owned), `d_` pointers are device memory on the
+ *     context's GPU (caller-owned unless stated); `stream` is a hipStream_t passed as void*
+ *     (NULL = the context's own stream).  Host-pointer entry points are synchronous on return,
+ *     like the reference (CUDAK2NN.cu:80, GPUDetector.hpp:290); `_dev` entry points only enqueue.
+ *   - device buffers owned by the context are sized from the options' maxkp with an explicit
+ *     capacity check (CLC_ERR_CAPACITY); the reference has none (GPUDetector.hpp:135,281).
+ *   - inputs need no padding (the reference needs +8 readable train vectors,
+ *     GPUMatcher.hpp:183-186).
+ *   - a context is thread-compatible: one host thread at a time; several contexts per
+ *     process / device are fine; no hidden process-global state.
+ */
+#ifndef COLOC_HIP_H
+#define COLOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLC_ABI_VERSION 1
+#define CLC_DESC_BYTES 64
+#define CLC_MAX_LEVELS 8
+
+/* status codes */
+enum {
+    CLC_OK = 0,
+    CLC_ERR_BAD_ARG = 1,    /* null pointer, negative count, misaligned device pointer ...      */
+    CLC_ERR_CAPACITY = 2,   /* more keypoints / descriptors / hypotheses than the ctx was sized for */
+    CLC_ERR_HIP = 3,        /* a HIP runtime call failed; see clc_last_error_string            */
+    CLC_ERR_NO_DEVICE = 4,  /* no usable gfx950 device                                          */
+    CLC_ERR_STATE = 5       /* call order violated (e.g. describe before pyramid_build)        */
+};
+
+/* mirrors coloc::DetectorOptions, include/coloc/colocData.hpp:29-36 */
+typedef struct clc_detector_opts {
+    float    scale_factor;  /* 1.2f in coloc_node.cpp:77 */
+    uint8_t  scale_levels;  /* 8; at most CLC_MAX_LEVELS (CLATCH indexes d_all_tex[8], CLATCH.cu:160) */
+    uint32_t width;
+    uint32_t height;
+    uint32_t maxkp;
+    uint8_t  thresh;        /* FAST threshold (host feeder), coloc_node.cpp:81 */
+} clc_detector_opts;
+
+/* mirrors coloc::MatcherOptions, include/coloc/colocData.hpp:38-42 */
+typedef struct clc_matcher_opts {
+    float    distRatio;     /* unused by the 2-NN difference rule; kept for the CPU comparator */
+    int      thresh;        /* map-tracking threshold (Mopts.thresh = 60, coloc_node.cpp:85)    */
+    uint32_t maxkp;
+} clc_matcher_opts;
+
+/* wire format shared with the host feeder: include/coloc/Keypoint.h:155-163, sizeof == 20 */
+typedef struct clc_keypoint {
+    int32_t x;      /* level-local pixel column */
+    int32_t y;      /* level-local pixel row    */
+    uint8_t score;
+    float   angle;  /* radians                  */
+    uint8_t scale;  /* pyramid level 0..7       */
+} clc_keypoint;
+
+typedef struct clc_ctx clc_ctx;
+
+/* one unit of matcher work for clc_match_jobs_dev: queries [q_begin, q_begin+nq) of a query set
+ * against a whole train set.  Offsets are in descriptors (rows of 64 B) from the base pointers. */
+typedef struct clc_match_job {
+    uint32_t q_offset;   /* first query row, relative to d_desc_base        */
+    uint32_t nq;
+    uint32_t t_offset;   /* first train row, relative to d_desc_base        */
+    uint32_t nt;
+    uint32_t out_offset; /* first int32 of the result, relative to d_match  */
+    uint32_t threshold;  /* truncated to 8 bits, see clc_match_2nn          */
+} clc_match_job;
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+
+int clc_abi_version(void);
+const char* clc_status_string(int status);
+
+/* Replaces the constructors GPUDetector(DetectorOptions) (GPUDetector.hpp:70-138) and
+ * GPUMatcher(MatcherOptions) (GPUMatcher.hpp:70-95): allocates pyramid levels, keypoint /
+ * descriptor / match buffers and the learned triplet table on device `device_id`.
+ * Either opts pointer may be NULL if that half is not used. */
+int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matcher_opts* mopts,
+                   clc_ctx** out_ctx);
+/* Replaces freeGPUMemory() (GPUDetector.hpp:144-155, GPUMatcher.hpp:102-108). */
+int clc_ctx_destroy(clc_ctx* ctx);
+const char* clc_last_error_string(const clc_ctx* ctx);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int clc_sync(clc_ctx* ctx);
+/* The context's hipStream_t (as void*), for callers that enqueue their own work in order. */
+void* clc_stream(clc_ctx* ctx);
+
+/* ---- pyramid: replaces CUDALERP() (CUDALERP.h:166) + the level loop GPUDetector.hpp:232-255 -- */
+
+/* Upload a WxH u8 image (tight rows) as level 0 and resample levels 1..L-1 from it. */
+int clc_pyramid_build(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32_t height);
+/* Same from a device image with `pitch` bytes per row. */
+int clc_pyramid_build_dev(clc_ctx* ctx, const void* d_img, uint32_t width, uint32_t height,
+                          size_t pitch, void* stream);
+/* Geometry and device address of one level (GPUDetector.hpp:109-114 dims). */
+int clc_pyramid_level(const clc_ctx* ctx, int level, uint32_t* w, uint32_t* h, size_t* pitch,
+                      const void** d_ptr);
+/* Download one level into tight host rows (the reference's per-level D2H, GPUDetector.hpp:265). */
+int clc_pyramid_download(clc_ctx* ctx, int level, uint8_t* h_out);
+
+/* ---- describe: replaces CLATCH() (CLATCH.h:168) + GPUDetector.hpp:280-290 ------------------ */
+
+/* n keypoints on the current pyramid -> n x 64 B descriptors. */
+int clc_describe(clc_ctx* ctx, const clc_keypoint* h_kps, int n, uint8_t* h_desc);
+int clc_describe_dev(clc_ctx* ctx, const clc_keypoint* d_kps, int n, void* d_desc, void* stream);
+/* {scale*x, scale*y, 7*scale, angle}, scale = pow(1.2f, level): GPUDetector.hpp:172-179. */
+int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4);
+
+/* ---- match: replaces CUDAK2NN() (CUDAK2NN.h:54) + GPUMatcher.hpp:180-226 -------------------- */
+
+/* For each query the best train index if (second_best - best > (uint8_t)threshold), else -1
+ * (CUDAK2NN.cu:75; the kernel's threshold parameter is uint8_t, :46, so the int is truncated).
+ * Ties for the minimum keep the lowest train index.  nt == 0 gives -1 everywhere (undefined in
+ * the reference).  h_best / h_second (nullable) receive the two distances saturated to 65535
+ * (the reference's 100000 / 200000 "none" sentinels read as 65535). */
+int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt, int threshold,
+                  int32_t* h_match, uint16_t* h_best, uint16_t* h_second);
+/* Device-resident form; d_q / d_t must be 16-byte aligned. */
+int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt,
+                      int threshold, int32_t* d_match, void* stream);
+/* Many (query-slice, train-set) jobs over one descriptor arena in ONE sweep launch: the
+ * all-pairs loop of GPUMatcher::computeMatches (GPUMatcher.hpp:143-155) and the per-rank share
+ * of it after the multi-GPU all-gather.  h_jobs is host memory. */
+int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs,
+                       int njobs, int32_t* d_match, void* stream);
+
+/* Map database: GPUMatcher::setMapData (GPUMatcher.hpp:110-117) / matchFeaturesWithMap (:252-271). */
+int clc_set_map(clc_ctx* ctx, const void* h_desc, int n);
+int clc_match_map(clc_ctx* ctx, const void* h_q, int nq, int threshold, int32_t* h_match);
+
+/* ---- pose scoring: the data-parallel core of SfM_Localizer::Localize (Localizer.hpp:82-93) --- */
+
+/* err[h*N+i] = || x_i - hnormalized(K (R_h X_i + t_h)) ||^2, fp64.
+ * h_Rt: H x 12 row-major [R|t]; h_X: N x 3; h_x: N x 2; h_K: 9 row-major. */
+int clc_pnp_residuals(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X,
+                      const double* h_x, int N, const double* h_K, double* h_err);
+/* Fused scoring without materialising the H x N matrix: per hypothesis the inlier count
+ * (err < thr2) and the truncated cost sum_i min(err, thr2).  Outputs nullable. */
+int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, const double* h_x,
+                  int N, const double* h_K, double thr2, int32_t* h_count, double* h_cost);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COLOC_HIP_H */

@@ -1,0 +1,447 @@
+/*
+ * clc_oracle.c -- CPU ORACLE (test infrastructure, see clc_oracle.h for the rules).
+ *
+ * Scalar restatement of the reference semantics; every function cites what it follows.
+ * Build: gcc -O2 -std=c11 -ffp-contract=off (NO -march=native / -mfma), see oracle/Makefile.
+ */
+#include "clc_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* K2NN                                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline uint64_t ld64(const uint8_t* p)
+{
+    uint64_t v;
+    memcpy(&v, p, 8);
+    return v;
+}
+
+static inline int hamming512(const uint8_t* a, const uint8_t* b)
+{
+    int d = 0;
+    for (int k = 0; k < 8; ++k) d += __builtin_popcountll(ld64(a + 8 * k) ^ ld64(b + 8 * k));
+    return d;
+}
+
+/* src/CUDAK2NN.cu:54 (initial state), :56-73 (loop), :75 (acceptance; threshold is uint8_t :46) */
+void orc_k2nn(const uint8_t* q, int nq, const uint8_t* t, int nt, int threshold,
+              int32_t* match_out, uint16_t* best_out, uint16_t* second_out)
+{
+    const int thr = (int)(uint8_t)threshold;
+    for (int i = 0; i < nq; ++i) {
+        int best_i = -1, best_v = 100000, second_v = 200000;
+        for (int j = 0; j < nt; ++j) {
+            const int d = hamming512(q + (size_t)64 * i, t + (size_t)64 * j);
+            second_v = d < second_v ? d : second_v;
+            if (d < best_v) {
+                second_v = best_v;
+                best_i = j;
+                best_v = d;
+            }
+        }
+        match_out[i] = (nt > 0 && second_v - best_v > thr) ? best_i : -1;
+        if (best_out) best_out[i] = (uint16_t)(best_v > 65535 ? 65535 : best_v);
+        if (second_out) second_out[i] = (uint16_t)(second_v > 65535 ? 65535 : second_v);
+    }
+}
+
+/* SURVEY.md 8(a) note N1: order-free definition + exact merge, A = lower train indices. */
+void orc_k2nn_split(const uint8_t* q, int nq, const uint8_t* t, int nt, int threshold,
+                    int nsplit, int32_t* match_out)
+{
+    const int thr = (int)(uint8_t)threshold;
+    if (nsplit < 1) nsplit = 1;
+    const int per = (nt + nsplit - 1) / nsplit;
+    for (int i = 0; i < nq; ++i) {
+        int A_best = 100000, A_second = 200000, A_idx = -1;
+        for (int s = 0; s < nsplit; ++s) {
+            const int t0 = s * per, t1 = (t0 + per < nt) ? t0 + per : nt;
+            /* partition-local result from the multiset definition */
+            int B_best = 100000, B_second = 200000, B_idx = -1;
+            for (int j = t0; j < t1; ++j) {
+                const int d = hamming512(q + (size_t)64 * i, t + (size_t)64 * j);
+                if (d < B_best) { B_second = B_best; B_best = d; B_idx = j; }
+                else if (d < B_second) B_second = d;
+            }
+            if (B_idx < 0) continue;
+            if (B_best < A_best) {
+                const int sec = A_best < B_second ? A_best : B_second;
+                A_best = B_best; A_idx = B_idx; A_second = sec;
+            } else {
+                A_second = A_second < B_best ? A_second : B_best;
+            }
+        }
+        match_out[i] = (A_idx >= 0 && A_second - A_best > thr) ? A_idx : -1;
+    }
+}
+
+/* include/coloc/CPUMatcher.hpp:67-76 -> DistanceRatioMatch(0.8f, BRUTE_FORCE_HAMMING, A, B):
+ * exhaustive Hamming, top-2 per query, OpenMP over queries. */
+int orc_k2nn_omp(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule, int threshold,
+                 float ratio, int32_t* match_out)
+{
+    const int thr = (int)(uint8_t)threshold;
+    const float r2 = ratio * ratio;
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(static)
+#endif
+    for (int i = 0; i < nq; ++i) {
+        uint64_t qq[8];
+        for (int k = 0; k < 8; ++k) qq[k] = ld64(q + (size_t)64 * i + 8 * k);
+        int best_i = -1, best_v = 100000, second_v = 200000;
+        for (int j = 0; j < nt; ++j) {
+            const uint8_t* tp = t + (size_t)64 * j;
+            int d = 0;
+            for (int k = 0; k < 8; ++k) d += __builtin_popcountll(qq[k] ^ ld64(tp + 8 * k));
+            second_v = d < second_v ? d : second_v;
+            if (d < best_v) { second_v = best_v; best_i = j; best_v = d; }
+        }
+        int ok;
+        if (rule == 0) ok = (nt > 0) && (second_v - best_v > thr);
+        else ok = (nt > 1) && ((float)best_v < r2 * (float)second_v);
+        match_out[i] = ok ? best_i : -1;
+    }
+    return nthreads;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* pyramid                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* include/coloc/GPUDetector.hpp:109-114 */
+void orc_pyramid_dims(uint32_t W, uint32_t H, float scale_factor, int levels,
+                      uint32_t* w_out, uint32_t* h_out, float* f_out)
+{
+    float f = 1.0f;
+    w_out[0] = W; h_out[0] = H;
+    if (f_out) f_out[0] = 1.0f;
+    for (int i = 1; i < levels; ++i) {
+        f *= scale_factor;
+        w_out[i] = (uint32_t)((float)W / f + 0.5f);
+        h_out[i] = (uint32_t)((float)H / f + 0.5f);
+        if (f_out) f_out[i] = f;
+    }
+}
+
+static inline float tap(const uint8_t* img, uint32_t W, uint32_t H, size_t pitch, int x, int y)
+{
+    /* clamp addressing (GPUDetector.hpp:96-97), normalized-float read (:239): u8 / 255 */
+    if (x < 0) x = 0;
+    if (y < 0) y = 0;
+    if (x > (int)W - 1) x = (int)W - 1;
+    if (y > (int)H - 1) y = (int)H - 1;
+    return (float)img[(size_t)y * pitch + (size_t)x] / 255.0f;
+}
+
+/* src/CUDALERP.cu:157-178.  tex2Dgather(fx+0.5, fy+0.5) returns the bilinear footprint of
+ * (fx, fy): w=(i,j) z=(i+1,j) x=(i,j+1) y=(i+1,j+1), i=floor(fx), j=floor(fy). */
+void orc_lerp(const uint8_t* img, uint32_t W, uint32_t H, size_t in_pitch, float gxs, float gys,
+              uint8_t* out, uint32_t neww, uint32_t newh, size_t out_pitch)
+{
+    for (uint32_t y = 0; y < newh; ++y) {
+        const float fy = ((float)y + 0.5f) * gys - 0.5f;
+        const float wt_y = fy - floorf(fy);
+        const float invwt_y = 1.0f - wt_y;
+        const int j = (int)floorf(fy);
+        for (uint32_t x = 0; x < neww; ++x) {
+            const float fx = ((float)x + 0.5f) * gxs - 0.5f;
+            const int i = (int)floorf(fx);
+            const float f_w = tap(img, W, H, in_pitch, i, j);
+            const float f_z = tap(img, W, H, in_pitch, i + 1, j);
+            const float f_x = tap(img, W, H, in_pitch, i, j + 1);
+            const float f_y = tap(img, W, H, in_pitch, i + 1, j + 1);
+            const float wt_x = fx - floorf(fx);
+            const float invwt_x = 1.0f - wt_x;
+            const float xa = invwt_x * f_w + wt_x * f_z;
+            const float xb = invwt_x * f_x + wt_x * f_y;
+            const float res = 255.0f * (invwt_y * xa + wt_y * xb) + 0.5f;
+            out[(size_t)y * out_pitch + x] = (uint8_t)res; /* truncating store, :177 */
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* CLATCH                                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+
+static const uint8_t k_latch_pattern[512][6] = {
+#include "../coloc_amd/csrc/latch_pattern.inc"
+};
+
+const uint8_t* orc_latch_pattern(void) { return &k_latch_pattern[0][0]; }
+
+/* src/CLATCH.cu:161-168: rotated 64x64 window, point sampled with clamp, C truncation of the
+ * fp32 coordinate + 0.5f.  Evaluation order exactly as written: (pt.x + (xo*c - yo*s)) + 0.5f. */
+void orc_clatch_roi(const uint8_t* level, uint32_t w, uint32_t h, size_t pitch,
+                    const orc_keypoint* kp, uint8_t* roi_out)
+{
+    const float s = (float)sin((double)kp->angle);
+    const float c = (float)cos((double)kp->angle);
+    for (int r = 0; r < 64; ++r) {
+        for (int cc = 0; cc < 64; ++cc) {
+            const float xo = (float)(cc - 32);
+            const float yo = (float)(r - 32);
+            const float fx = ((float)kp->x + (xo * c - yo * s)) + 0.5f;
+            const float fy = ((float)kp->y + (xo * s + yo * c)) + 0.5f;
+            int sx = (int)fx, sy = (int)fy;
+            if (sx < 0) sx = 0;
+            if (sy < 0) sy = 0;
+            if (sx > (int)w - 1) sx = (int)w - 1;
+            if (sy > (int)h - 1) sy = (int)h - 1;
+            roi_out[r * 64 + cc] = level[(size_t)sy * pitch + (size_t)sx];
+        }
+    }
+}
+
+/* src/CLATCH.cu:169-188: S_n = sum over the 8x8 patch of (A-B)^2 - (C-B)^2, bit = S_n < 0,
+ * bit n&31 of little-endian uint32 word n>>5. */
+void orc_clatch(const uint8_t* const* levels, const uint32_t* w, const uint32_t* h,
+                const size_t* pitch, const orc_keypoint* kps, int n, uint8_t* desc_out)
+{
+    uint8_t roi[64 * 64];
+    for (int k = 0; k < n; ++k) {
+        const int lv = kps[k].scale;
+        orc_clatch_roi(levels[lv], w[lv], h[lv], pitch[lv], &kps[k], roi);
+        uint32_t words[16];
+        memset(words, 0, sizeof words);
+        for (int t = 0; t < 512; ++t) {
+            const uint8_t* p = k_latch_pattern[t];
+            int32_t S = 0;
+            for (int dy = 0; dy < 8; ++dy) {
+                for (int dx = 0; dx < 8; ++dx) {
+                    const int32_t A = roi[(p[0] + dy) * 64 + p[1] + dx];
+                    const int32_t B = roi[(p[2] + dy) * 64 + p[3] + dx];
+                    const int32_t C = roi[(p[4] + dy) * 64 + p[5] + dx];
+                    S += (A - B) * (A - B) - (C - B) * (C - B);
+                }
+            }
+            if (S < 0) words[t >> 5] |= 1u << (t & 31);
+        }
+        for (int wd = 0; wd < 16; ++wd) {
+            uint8_t* o = desc_out + (size_t)64 * k + 4 * wd;
+            o[0] = (uint8_t)(words[wd]);
+            o[1] = (uint8_t)(words[wd] >> 8);
+            o[2] = (uint8_t)(words[wd] >> 16);
+            o[3] = (uint8_t)(words[wd] >> 24);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* host feeders                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+/* include/coloc/FeatureAngle.h:160-177 */
+static float orc_fast_atan2(float y, float x)
+{
+    const float PI = 3.1415927f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a;
+    if (ax >= ay) {
+        const float c = ay / (ax + FLT_MIN);
+        const float cc = c * c;
+        a = (((-0.0443265555479f * cc + 0.1555786518f) * cc - 0.325808397f) * cc + 0.9997878412f) * c;
+    } else {
+        const float c = ax / (ay + FLT_MIN);
+        const float cc = c * c;
+        a = PI * 0.5f - (((-0.0443265555479f * cc + 0.1555786518f) * cc - 0.325808397f) * cc + 0.9997878412f) * c;
+    }
+    if (x < 0.0f) a = PI - a;
+    if (y < 0.0f) a = -a;
+    return a;
+}
+
+/* include/coloc/FeatureAngle.h:179-246: 37-pixel disc (rows of 3,5,7,7,7,5,3), x weight = column
+ * offset, y weight = row offset; int16 sums (|sum| <= 26*255, no wrap). */
+float orc_feature_angle(const uint8_t* img, int px, int py, int step)
+{
+    static const int half[7] = { 1, 2, 3, 3, 3, 2, 1 };
+    int xs = 0, ys = 0;
+    for (int r = -3; r <= 3; ++r) {
+        const int hw = half[r + 3];
+        for (int c = -hw; c <= hw; ++c) {
+            const int v = img[(size_t)(py + r) * step + (px + c)];
+            xs += c * v;
+            ys += r * v;
+        }
+    }
+    return orc_fast_atan2((float)(int16_t)ys, (float)(int16_t)xs);
+}
+
+/* include/coloc/KFAST.h:164-500.  The reference walks each row in 32-column blocks with a
+ * 16-column "retreat" when the low half of the cardinal pre-test mask is empty (:259-265) and
+ * masks the final partial block with (1 << (cols-j-3)) - 1 (:245).  When the walk lands exactly
+ * on j == cols-35 that shift count is 32, which x86 evaluates as a shift by 0 -> mask 0 -> the
+ * last 32 columns of that row are dropped.  The walk is reproduced here (scalar per pixel inside
+ * a block) so that the restatement matches what the compiled reference produces. */
+static const int k_ring_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+static const int k_ring_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+
+static int fast_pretest(const uint8_t* p, int stride, int t)
+{
+    const int c = *p;
+    const int hi = c + t > 255 ? 255 : c + t;
+    const int lo = c - t < 0 ? 0 : c - t;
+    const int p9 = p[3 * stride], p5 = p[3], p1 = p[-3 * stride], p13 = p[-3];
+    const int b = ((p9 > hi) & (p5 > hi)) | ((p5 > hi) & (p1 > hi)) | ((p1 > hi) & (p13 > hi)) | ((p13 > hi) & (p9 > hi));
+    const int d = ((p9 < lo) & (p5 < lo)) | ((p5 < lo) & (p1 < lo)) | ((p1 < lo) & (p13 < lo)) | ((p13 < lo) & (p9 < lo));
+    return b | d;
+}
+
+static int fast_is_corner(const uint8_t* p, int stride, int t, uint8_t* score)
+{
+    const int c = *p;
+    const int hi = c + t > 255 ? 255 : c + t;
+    const int lo = c - t < 0 ? 0 : c - t;
+    int ring[24];
+    for (int k = 0; k < 24; ++k) ring[k] = p[k_ring_dy[k & 15] * stride + k_ring_dx[k & 15]];
+    int bc = 0, dc = 0, bmax = 0, dmax = 0;
+    for (int k = 0; k < 24; ++k) {
+        bc = ring[k] > hi ? bc + 1 : 0;
+        dc = ring[k] < lo ? dc + 1 : 0;
+        if (bc > bmax) bmax = bc;
+        if (dc > dmax) dmax = dc;
+    }
+    if ((bmax > dmax ? bmax : dmax) <= 8) return 0;
+    /* corner score :300-374: max over the 16 arcs of 9 of max(min(p-ring), -max(p-ring)) */
+    int best = -32768;
+    for (int s = 0; s < 16; ++s) {
+        int mn = 32767, mx = -32768;
+        for (int k = s; k < s + 9; ++k) {
+            const int v = c - ring[k];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
+        const int val = mn > -mx ? mn : -mx;
+        if (val > best) best = val;
+    }
+    *score = (uint8_t)best;
+    return 1;
+}
+
+int orc_fast9(const uint8_t* img, int cols, int rows, int stride, uint8_t threshold,
+              orc_keypoint* out, int cap)
+{
+    int count = 0;
+    if (cols < 7 || rows < 7) return 0;
+    uint8_t* buf = (uint8_t*)calloc((size_t)3 * cols, 1);
+    uint8_t* rowbuf[3] = { buf, buf + cols, buf + 2 * cols };
+    for (int i = 3; i < rows - 2; ++i) {
+        uint8_t* cur = rowbuf[i % 3];
+        memset(cur, 0, (size_t)cols);
+        if (i < rows - 3) {
+            const uint8_t* row = img + (size_t)i * stride;
+            int j = 3;
+            for (;;) {
+                const int full = j < cols - 35;
+                int width = 32;
+                if (!full) {
+                    const int sh = (cols - j - 3) & 31; /* x86 shift-count masking of :245 */
+                    width = (cols - j - 3 == 32) ? 0 : sh;
+                    (void)sh;
+                }
+                uint32_t m = 0;
+                for (int x = 0; x < (full ? 32 : width); ++x)
+                    if (fast_pretest(row + j + x, stride, threshold)) m |= 1u << x;
+                if (m != 0) {
+                    if (full && (m & 0xFFFFu) == 0) {
+                        j -= 16; /* :259-265 retreat; net +16 after the loop increment */
+                    } else {
+                        for (int x = 0; x < (full ? 32 : width); ++x) {
+                            uint8_t sc;
+                            if (fast_is_corner(row + j + x, stride, threshold, &sc)) cur[j + x] = sc;
+                        }
+                    }
+                }
+                if (!full) break;
+                j += 32;
+            }
+        }
+        if (i == 3) continue;
+        const uint8_t* last = rowbuf[(i - 1) % 3];
+        const uint8_t* last2 = rowbuf[(i - 2) % 3];
+        for (int j = 3; j < cols - 3; ++j) {
+            const uint8_t sc = last[j];
+            if (!sc) continue;
+            if ((sc > last[j - 1]) & (sc > last[j + 1]) & (sc > cur[j - 1]) & (sc > cur[j]) & (sc > cur[j + 1]) &
+                (sc > last2[j - 1]) & (sc > last2[j]) & (sc > last2[j + 1])) {
+                if (count < cap) {
+                    out[count].x = j;
+                    out[count].y = i - 1;
+                    out[count].score = sc;
+                    out[count].angle = 0.0f;
+                    out[count].scale = 0;
+                }
+                ++count;
+            }
+        }
+    }
+    free(buf);
+    return count < cap ? count : cap;
+}
+
+/* include/coloc/GPUDetector.hpp:172-179 */
+void orc_features_from_kps(const orc_keypoint* kps, int n, float* feat_out)
+{
+    for (int i = 0; i < n; ++i) {
+        const float scale = (float)pow((double)1.2f, (double)kps[i].scale); /* std::pow(float,uint8) -> double */
+        feat_out[4 * i + 0] = scale * (float)kps[i].x;
+        feat_out[4 * i + 1] = scale * (float)kps[i].y;
+        feat_out[4 * i + 2] = 7.0f * scale;
+        feat_out[4 * i + 3] = kps[i].angle;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PnP residuals                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* include/coloc/Localizer.hpp:61-72 builds pt3D (3xN) / pt2D (2xN); the residual OpenMVG's
+ * resection kernel evaluates is the squared pixel reprojection error of P = K[R|t]. */
+void orc_pnp_residuals(const double* Rt, int H, const double* X, const double* x, int N,
+                       const double* K, double* err_out)
+{
+    for (int h = 0; h < H; ++h) {
+        const double* P = Rt + (size_t)12 * h;
+        for (int i = 0; i < N; ++i) {
+            const double Xw = X[3 * i + 0], Yw = X[3 * i + 1], Zw = X[3 * i + 2];
+            const double xc = ((P[0] * Xw + P[1] * Yw) + P[2] * Zw) + P[3];
+            const double yc = ((P[4] * Xw + P[5] * Yw) + P[6] * Zw) + P[7];
+            const double zc = ((P[8] * Xw + P[9] * Yw) + P[10] * Zw) + P[11];
+            const double u = (K[0] * xc + K[1] * yc) + K[2] * zc;
+            const double v = (K[3] * xc + K[4] * yc) + K[5] * zc;
+            const double w = (K[6] * xc + K[7] * yc) + K[8] * zc;
+            const double du = x[2 * i + 0] - u / w;
+            const double dv = x[2 * i + 1] - v / w;
+            err_out[(size_t)h * N + i] = du * du + dv * dv;
+        }
+    }
+}
+
+void orc_pnp_score(const double* err, int H, int N, double thr2, int32_t* count_out,
+                   double* cost_out)
+{
+    for (int h = 0; h < H; ++h) {
+        int32_t cnt = 0;
+        double cost = 0.0;
+        for (int i = 0; i < N; ++i) {
+            const double e = err[(size_t)h * N + i];
+            if (e < thr2) { ++cnt; cost += e; }
+            else cost += thr2;
+        }
+        if (count_out) count_out[h] = cnt;
+        if (cost_out) cost_out[h] = cost;
+    }
+}

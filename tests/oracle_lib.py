@@ -1,0 +1,180 @@
+"""ctypes access to the CPU oracle (oracle/liboracle.so) and the compiled reference feeders
+(oracle/_ref/libref_feeder.so).  Test infrastructure only -- imported from tests/, bench.py's
+cpu_baseline leg and __graft_entry__.smoke(); never from the product package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+try:
+    from . import synth
+except ImportError:  # imported as a top-level module (bench.py / smoke)
+    import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "all"], stdout=subprocess.DEVNULL)
+
+
+def _ptr(a, ty=C.c_void_p):
+    return a.ctypes.data_as(ty)
+
+
+class Oracle:
+    def __init__(self):
+        path = os.path.join(ORACLE_DIR, "liboracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        self.lib = C.CDLL(path)
+        self.lib.orc_k2nn_omp.restype = C.c_int
+        self.lib.orc_fast9.restype = C.c_int
+        self.lib.orc_feature_angle.restype = C.c_float
+        self.lib.orc_latch_pattern.restype = C.POINTER(C.c_uint8)
+
+    # -- K2NN
+    def k2nn(self, Q, T, threshold, want_dist=False):
+        Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
+        T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 64)
+        nq, nt = Q.shape[0], T.shape[0]
+        m = np.empty(nq, dtype=np.int32)
+        b = np.empty(nq, dtype=np.uint16); s = np.empty(nq, dtype=np.uint16)
+        self.lib.orc_k2nn(_ptr(Q), C.c_int(nq), _ptr(T), C.c_int(nt), C.c_int(int(threshold)),
+                          _ptr(m), _ptr(b), _ptr(s))
+        return (m, b, s) if want_dist else m
+
+    def k2nn_split(self, Q, T, threshold, nsplit):
+        Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
+        T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 64)
+        m = np.empty(Q.shape[0], dtype=np.int32)
+        self.lib.orc_k2nn_split(_ptr(Q), C.c_int(Q.shape[0]), _ptr(T), C.c_int(T.shape[0]),
+                                C.c_int(int(threshold)), C.c_int(int(nsplit)), _ptr(m))
+        return m
+
+    def k2nn_omp(self, Q, T, rule=0, threshold=40, ratio=0.8):
+        Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
+        T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 64)
+        m = np.empty(Q.shape[0], dtype=np.int32)
+        nthr = self.lib.orc_k2nn_omp(_ptr(Q), C.c_int(Q.shape[0]), _ptr(T), C.c_int(T.shape[0]),
+                                     C.c_int(rule), C.c_int(int(threshold)), C.c_float(ratio), _ptr(m))
+        return m, nthr
+
+    # -- pyramid
+    def pyramid_dims(self, W, H, scale_factor=1.2, levels=8):
+        w = (C.c_uint32 * levels)(); h = (C.c_uint32 * levels)(); f = (C.c_float * levels)()
+        self.lib.orc_pyramid_dims(C.c_uint32(W), C.c_uint32(H), C.c_float(scale_factor), C.c_int(levels), w, h, f)
+        return list(w), list(h), [np.float32(v) for v in f]
+
+    def lerp(self, img, f, neww, newh):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        H, W = img.shape
+        out = np.zeros((newh, neww), dtype=np.uint8)
+        self.lib.orc_lerp(_ptr(img), C.c_uint32(W), C.c_uint32(H), C.c_size_t(W), C.c_float(f), C.c_float(f),
+                          _ptr(out), C.c_uint32(neww), C.c_uint32(newh), C.c_size_t(neww))
+        return out
+
+    def pyramid(self, img, scale_factor=1.2, levels=8):
+        H, W = img.shape
+        ws, hs, fs = self.pyramid_dims(W, H, scale_factor, levels)
+        out = [np.ascontiguousarray(img, dtype=np.uint8)]
+        for i in range(1, levels):
+            out.append(self.lerp(img, float(fs[i]), ws[i], hs[i]))
+        return out
+
+    # -- CLATCH
+    def clatch(self, levels, kps):
+        n = len(kps)
+        L = len(levels)
+        levels = [np.ascontiguousarray(l, dtype=np.uint8) for l in levels]
+        ptrs = (C.c_void_p * L)(*[l.ctypes.data for l in levels])
+        w = (C.c_uint32 * L)(*[l.shape[1] for l in levels])
+        h = (C.c_uint32 * L)(*[l.shape[0] for l in levels])
+        p = (C.c_size_t * L)(*[l.shape[1] for l in levels])
+        kps = np.ascontiguousarray(kps, dtype=synth.KP_DTYPE)
+        desc = np.zeros((n, 64), dtype=np.uint8)
+        self.lib.orc_clatch(ptrs, w, h, p, _ptr(kps), C.c_int(n), _ptr(desc))
+        return desc
+
+    def clatch_roi(self, level, kp):
+        level = np.ascontiguousarray(level, dtype=np.uint8)
+        kp = np.ascontiguousarray(kp, dtype=synth.KP_DTYPE).reshape(1)
+        roi = np.zeros((64, 64), dtype=np.uint8)
+        self.lib.orc_clatch_roi(_ptr(level), C.c_uint32(level.shape[1]), C.c_uint32(level.shape[0]),
+                                C.c_size_t(level.shape[1]), _ptr(kp), _ptr(roi))
+        return roi
+
+    def latch_pattern(self):
+        p = self.lib.orc_latch_pattern()
+        return np.ctypeslib.as_array(p, shape=(512, 6)).copy()
+
+    # -- feeders
+    def fast9(self, img, threshold, cap=200000):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rows, cols = img.shape
+        out = np.zeros(cap, dtype=synth.KP_DTYPE)
+        n = self.lib.orc_fast9(_ptr(img), C.c_int(cols), C.c_int(rows), C.c_int(cols), C.c_uint8(threshold),
+                               _ptr(out), C.c_int(cap))
+        return out[:n]
+
+    def feature_angle(self, img, px, py):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        return np.float32(self.lib.orc_feature_angle(_ptr(img), C.c_int(px), C.c_int(py), C.c_int(img.shape[1])))
+
+    def features_from_kps(self, kps):
+        kps = np.ascontiguousarray(kps, dtype=synth.KP_DTYPE)
+        out = np.zeros((len(kps), 4), dtype=np.float32)
+        self.lib.orc_features_from_kps(_ptr(kps), C.c_int(len(kps)), _ptr(out))
+        return out
+
+    # -- PnP
+    def pnp_residuals(self, Rt, X, x, K):
+        Rt = np.ascontiguousarray(Rt, dtype=np.float64).reshape(-1, 12)
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        H, N = Rt.shape[0], X.shape[0]
+        err = np.zeros((H, N), dtype=np.float64)
+        self.lib.orc_pnp_residuals(_ptr(Rt), C.c_int(H), _ptr(X), _ptr(x), C.c_int(N), _ptr(K), _ptr(err))
+        return err
+
+    def pnp_score(self, err, thr2):
+        err = np.ascontiguousarray(err, dtype=np.float64)
+        H, N = err.shape
+        cnt = np.zeros(H, dtype=np.int32); cost = np.zeros(H, dtype=np.float64)
+        self.lib.orc_pnp_score(_ptr(err), C.c_int(H), C.c_int(N), C.c_double(thr2), _ptr(cnt), _ptr(cost))
+        return cnt, cost
+
+
+class RefFeeder:
+    """The reference's own KFAST.h / FeatureAngle.h, compiled into oracle/_ref/ (build container)."""
+
+    def __init__(self):
+        path = os.path.join(ORACLE_DIR, "_ref", "libref_feeder.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = C.CDLL(path)
+        self.lib.ref_kfast.restype = C.c_int
+        self.lib.ref_feature_angle.restype = C.c_float
+        assert self.lib.ref_sizeof_keypoint() == 20
+
+    def kfast(self, img, threshold, multithreading=True, cap=200000):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rows, cols = img.shape
+        # KFAST reads 32-byte vectors past row ends and 8 B per row in featureAngle: pad the buffer
+        buf = np.zeros(rows * cols + 64, dtype=np.uint8)
+        buf[:rows * cols] = img.reshape(-1)
+        out = np.zeros(cap, dtype=synth.KP_DTYPE)
+        n = self.lib.ref_kfast(_ptr(buf), C.c_int(cols), C.c_int(rows), C.c_int(cols), C.c_uint8(threshold),
+                               C.c_int(1 if multithreading else 0), _ptr(out), C.c_int(cap))
+        return out[:min(n, cap)]
+
+    def feature_angle(self, img, px, py):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        rows, cols = img.shape
+        buf = np.zeros(rows * cols + 64, dtype=np.uint8)
+        buf[:rows * cols] = img.reshape(-1)
+        return np.float32(self.lib.ref_feature_angle(_ptr(buf), C.c_int(px), C.c_int(py), C.c_int(cols)))
