@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- CoLoC hot path on MI355X: describe (pyramid + CLATCH) -> 512-bit Hamming 2-NN match.
+
+Metric (BASELINE.json): Mmatches/s = 512-bit Hamming comparisons per second / 1e6 for the all-pairs
+sweep at 10k keypoints per image (value), with Mdesc/s and the pose-scoring latency reported
+beside it.  One step = one pass of the hot path over one batch of synthetic input that is already
+resident in HBM:
+  N = 1 : BASELINE config[1] -- 2 images (640x480) x 10k keypoints: 2 x (pyramid + CLATCH) and the
+          one pair's 10k x 10k K2NN sweep (Q = image 0, T = image 1, threshold 40).
+  N > 1 : BASELINE config[3] -- one camera per GPU: pyramid + CLATCH of the rank's own image, RCCL
+          all-gather of the 10k x 64 B descriptor block, then the rank's share of the N(N-1)/2 pair
+          sweeps (coloc_amd/multicam.py).  Per-GPU describe work is fixed ("weak").
+Launch for N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H, NKP, THR = 640, 480, 10000, 40
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(desc_q, desc_t):
+    """The oracle's OpenMP brute-force matcher (restated OpenMVG BRUTE_FORCE_HAMMING top-2) on the same
+    10k x 10k pair, all host cores; the CHECKER timed as a baseline, never the product path."""
+    import numpy as np
+    import oracle_lib
+    orc = oracle_lib.Oracle()
+    best = None
+    nthr = 1
+    reps = 3
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        _, nthr = orc.k2nn_omp(desc_q, desc_t, rule=0, threshold=THR)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    cmp_per_s = desc_q.shape[0] * desc_t.shape[0] / best
+    return {"value": cmp_per_s / 1e6, "unit": "Mmatches/s", "cores": int(nthr), "kind": "port",
+            "sample": "full %d x %d pair, K2NN acceptance rule, best of %d (%.3f s each)"
+                      % (desc_q.shape[0], desc_t.shape[0], reps, best),
+            "cpu_count": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import synth
+    from coloc_amd import Context, multicam
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    ctx = Context(device=local_rank, width=W, height=H, maxkp=NKP)
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+
+    # ---- synthetic inputs, resident in HBM before the timed region --------------------------
+    cams = [0, 1] if world == 1 else [rank]
+    imgs = [torch.from_numpy(synth.rect_image(W, H, seed=1000 + c, noise_sigma=2.0)).to(dev) for c in cams]
+    kps_np = [synth.random_keypoints(NKP, W, H, seed=2000 + c) for c in cams]
+    kps = [torch.from_numpy(k.view(np.uint8).reshape(-1, 20).copy()).to(dev) for k in kps_np]
+    n_cams = 2 if world == 1 else world
+    counts = [NKP] * n_cams
+    arena = torch.zeros((n_cams, NKP, 64), dtype=torch.uint8, device=dev)
+    jobs = multicam.shard_pairs(counts, world, rank)
+    abi_jobs = multicam.jobs_to_abi(jobs, counts, NKP, THR)
+    n_out = sum(j.nq for j in jobs)
+    d_match = torch.empty((max(n_out, 1),), dtype=torch.int32, device=dev)
+    my_cmp = sum(j.nq * counts[j.pair[1]] for j in jobs)
+    total_cmp = sum(counts[i] * counts[j] for i, j in multicam.exhaustive_pairs(n_cams))
+
+    def step():
+        for k, c in enumerate(cams):
+            ctx.pyramid_build_dev(imgs[k].data_ptr(), W, H, W, sptr)
+            ctx.describe_dev(kps[k].data_ptr(), NKP, arena[c].data_ptr(), sptr)
+        if world > 1:
+            dist.all_gather_into_tensor(arena.view(-1), arena[rank].reshape(-1))
+        if abi_jobs:
+            ctx.match_jobs_dev(arena.data_ptr(), abi_jobs, d_match.data_ptr(), sptr)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile_reset()
+    ctx.profile_enable(True)          # HIP events around every kernel, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    prof = ctx.profile_read()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        def avg_us(name):
+            ms, cnt = prof[name]
+            return (ms / cnt * 1e3) if cnt else None
+
+        sweep_us = avg_us("k2nn_sweep_kernel")
+        clatch_us = avg_us("clatch_kernel")
+        # dominant kernel = K2NN sweep.  Algorithmic work per launch: 32 VALU lane-ops
+        # and 64 swept train bytes per comparison; compulsory HBM bytes 64*(nq+nt)+4*nq per pair.
+        launches = prof["k2nn_sweep_kernel"][1]
+        cmp_per_launch = my_cmp * args.steps / max(launches, 1)
+        compulsory_bytes = sum(64 * (j.nq + counts[j.pair[1]]) + 4 * j.nq for j in jobs)
+        roof = None
+        if sweep_us:
+            t = sweep_us * 1e-6
+            laneops = cmp_per_launch * 32 / t / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "k2nn_hbm_traffic.json")
+            if os.path.exists(tpath) and world == 1:
+                try:
+                    traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "k2nn_sweep_kernel", "achieved": compulsory_bytes / t / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": compulsory_bytes / t / 1e9 / HBM_PEAK_GBS,
+                    "traffic": traffic, "avg_launch_us": sweep_us,
+                    "algorithmic_bytes_per_launch": compulsory_bytes,
+                    "swept_GBps": cmp_per_launch * 64 / t / 1e9,
+                    "binding": "valu",
+                    "valu": {"achieved": laneops, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlaneop/s",
+                             "frac": laneops / VALU_PEAK_TLANEOPS,
+                             "lane_ops_per_comparison": 32,
+                             "Gcmp_per_s_kernel": cmp_per_launch / t / 1e9}}
+        out = {
+            "metric": "Mmatches/s (512-bit Hamming comparisons) at 10k kp/img, describe+match step",
+            "value": total_cmp / (dt / args.steps) / 1e6,
+            "unit": "Mmatches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32 (xor+popcount); fp32 sample coords", "data": "synthetic",
+            "config": {"workload": ("config[1]: 2 images 640x480 x 10k kp, CLATCH + K2NN 1 pair, thr 40" if world == 1 else
+                                    "config[3]: %d cameras one-per-GPU, 640x480 x 10k kp, all-gather + %d pairs" % (world, len(multicam.exhaustive_pairs(world)))),
+                       "keypoints_per_image": NKP, "pairs": len(multicam.exhaustive_pairs(n_cams)),
+                       "comparisons_per_step": total_cmp},
+            "stages": {"clatch_us_per_launch": clatch_us, "pyramid_us_per_launch": avg_us("pyramid_kernel"),
+                       "k2nn_sweep_us": sweep_us, "k2nn_merge_us": avg_us("k2nn_merge_kernel"),
+                       "Mdesc_per_s_kernel": (NKP / clatch_us) if clatch_us else None,
+                       "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            dq = arena[0].cpu().numpy()
+            dt_ = arena[1].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(dq, dt_)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

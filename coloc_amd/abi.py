@@ -42,8 +42,11 @@ EXPORTS = [
     "clc_sync", "clc_stream", "clc_pyramid_build", "clc_pyramid_build_dev", "clc_pyramid_level",
     "clc_pyramid_download", "clc_describe", "clc_describe_dev", "clc_keypoints_to_features",
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
-    "clc_pnp_residuals", "clc_pnp_score",
+    "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
+    "clc_kernel_name",
 ]
+KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
+           "pnp_score_kernel"]
 
 _lib = None
 
@@ -85,6 +88,10 @@ def load_library():
     lib.clc_match_map.argtypes = [vp, vp, ci, ci, vp]
     lib.clc_pnp_residuals.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
     lib.clc_pnp_score.argtypes = [vp, vp, ci, vp, vp, ci, vp, C.c_double, vp, vp]
+    lib.clc_profile_enable.argtypes = [vp, ci]
+    lib.clc_profile_reset.argtypes = [vp]
+    lib.clc_profile_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(ci)]
+    lib.clc_kernel_name.restype = C.c_char_p
     _lib = lib
     return lib
 
@@ -141,6 +148,22 @@ class Context:
     @property
     def stream(self):
         return self.lib.clc_stream(self.h)
+
+    # -- per-kernel event timing
+    def profile_enable(self, on=True):
+        self._chk(self.lib.clc_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self.lib.clc_profile_reset(self.h))
+
+    def profile_read(self):
+        """{kernel name: (total device ms, launches)} since the last reset (synchronises)."""
+        out = {}
+        for k, name in enumerate(KERNELS):
+            ms, cnt = C.c_double(), C.c_int()
+            self._chk(self.lib.clc_profile_read(self.h, k, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
 
     # -- pyramid
     def pyramid_build(self, img):

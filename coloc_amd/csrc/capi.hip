@@ -18,6 +18,61 @@
 
 using namespace clc;
 
+namespace clc {
+// Event pairs recorded around kernel launches; drained (with a stream sync) by clc_profile_read.
+struct Profiler {
+    bool on = false;
+    struct Pair { hipEvent_t a = nullptr, b = nullptr; int kernel = 0; hipStream_t stream = nullptr; bool open = false; };
+    std::vector<Pair> pending;
+    std::vector<hipEvent_t> pool;
+    double total_ms[CLC_KERNEL_COUNT] = {};
+    int launches[CLC_KERNEL_COUNT] = {};
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void drain()
+    {
+        for (Pair& p : pending) {
+            if (!p.a || !p.b || p.open) continue;
+            (void)hipEventSynchronize(p.b);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { total_ms[p.kernel] += ms; launches[p.kernel] += 1; }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    ~Profiler()
+    {
+        for (Pair& p : pending) { if (p.a) (void)hipEventDestroy(p.a); if (p.b) (void)hipEventDestroy(p.b); }
+        for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    }
+};
+void prof_mark(Profiler* prof, int kernel, bool begin, hipStream_t stream)
+{
+    if (!prof || !prof->on) return;
+    if (begin) {
+        Profiler::Pair p;
+        p.a = prof->get(); p.b = prof->get(); p.kernel = kernel; p.stream = stream; p.open = true;
+        if (p.a) (void)hipEventRecord(p.a, stream);
+        prof->pending.push_back(p);
+    } else {
+        for (size_t i = prof->pending.size(); i-- > 0;) {
+            Profiler::Pair& p = prof->pending[i];
+            if (p.open && p.kernel == kernel && p.stream == stream) {
+                if (p.b) (void)hipEventRecord(p.b, stream);
+                p.open = false;
+                break;
+            }
+        }
+    }
+}
+} // namespace clc
+
 struct clc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -47,6 +102,7 @@ struct clc_ctx {
     // pnp
     double* d_pnp = nullptr;
     size_t pnp_cap = 0;   // doubles
+    Profiler prof;
 };
 
 namespace {
@@ -125,7 +181,7 @@ int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
     const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), ctx->target_blocks);
     const int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;
-    CLC_HIP(ctx, launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st));
+    CLC_HIP(ctx, launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, &ctx->prof));
     return CLC_OK;
 }
 
@@ -237,6 +293,41 @@ int clc_sync(clc_ctx* ctx)
 
 void* clc_stream(clc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int clc_profile_enable(clc_ctx* ctx, int on)
+{
+    if (!ctx) return CLC_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (!on) ctx->prof.drain();
+    ctx->prof.on = on != 0;
+    return CLC_OK;
+}
+
+int clc_profile_reset(clc_ctx* ctx)
+{
+    if (!ctx) return CLC_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    ctx->prof.drain();
+    for (int k = 0; k < CLC_KERNEL_COUNT; ++k) { ctx->prof.total_ms[k] = 0.0; ctx->prof.launches[k] = 0; }
+    return CLC_OK;
+}
+
+int clc_profile_read(clc_ctx* ctx, int kernel, double* total_ms, int* launches)
+{
+    if (!ctx || kernel < 0 || kernel >= CLC_KERNEL_COUNT) return CLC_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    ctx->prof.drain();
+    if (total_ms) *total_ms = ctx->prof.total_ms[kernel];
+    if (launches) *launches = ctx->prof.launches[kernel];
+    return CLC_OK;
+}
+
+const char* clc_kernel_name(int kernel)
+{
+    static const char* names[CLC_KERNEL_COUNT] = { "pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel",
+                                                    "k2nn_merge_kernel", "pnp_residual_kernel", "pnp_score_kernel" };
+    return (kernel >= 0 && kernel < CLC_KERNEL_COUNT) ? names[kernel] : "?";
+}
+
 /* ---- pyramid ------------------------------------------------------------------------------- */
 
 int clc_pyramid_build_dev(clc_ctx* ctx, const void* d_img, uint32_t width, uint32_t height, size_t pitch, void* stream)
@@ -250,7 +341,7 @@ int clc_pyramid_build_dev(clc_ctx* ctx, const void* d_img, uint32_t width, uint3
     const LevelDesc& L0 = ctx->pd.lv[0];
     CLC_HIP(ctx, hipMemcpy2DAsync(ctx->d_arena + L0.offset, L0.pitch, d_img, pitch, width, height,
                                   hipMemcpyDeviceToDevice, st));
-    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, st));
+    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, st, &ctx->prof));
     ctx->pyramid_valid = true;
     return CLC_OK;
 }
@@ -265,7 +356,7 @@ int clc_pyramid_build(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32
     const LevelDesc& L0 = ctx->pd.lv[0];
     CLC_HIP(ctx, hipMemcpy2DAsync(ctx->d_arena + L0.offset, L0.pitch, h_img, width, width, height,
                                   hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, ctx->stream));
+    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, ctx->stream, &ctx->prof));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pyramid_valid = true;
     return CLC_OK;
@@ -303,7 +394,7 @@ int clc_describe_dev(clc_ctx* ctx, const clc_keypoint* d_kps, int n, void* d_des
     if (!ctx->pyramid_valid) return fail(ctx, CLC_ERR_STATE, "describe before pyramid_build");
     if (((uintptr_t)d_desc & 7u) || ((uintptr_t)d_kps & 3u)) return fail(ctx, CLC_ERR_BAD_ARG, "describe: misaligned device pointer");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
-    CLC_HIP(ctx, launch_clatch(ctx->pd, ctx->d_arena, d_kps, n, (uint64_t*)d_desc, pick(ctx, stream)));
+    CLC_HIP(ctx, launch_clatch(ctx->pd, ctx->d_arena, d_kps, n, (uint64_t*)d_desc, pick(ctx, stream), &ctx->prof));
     return CLC_OK;
 }
 
@@ -318,7 +409,7 @@ int clc_describe(clc_ctx* ctx, const clc_keypoint* h_kps, int n, uint8_t* h_desc
         if (h_kps[i].scale >= ctx->pd.levels) return fail(ctx, CLC_ERR_BAD_ARG, "describe: keypoint scale >= scale_levels");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     CLC_HIP(ctx, hipMemcpyAsync(ctx->d_kps, h_kps, (size_t)n * sizeof(clc_keypoint), hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, launch_clatch(ctx->pd, ctx->d_arena, ctx->d_kps, n, ctx->d_desc, ctx->stream));
+    CLC_HIP(ctx, launch_clatch(ctx->pd, ctx->d_arena, ctx->d_kps, n, ctx->d_desc, ctx->stream, &ctx->prof));
     CLC_HIP(ctx, hipMemcpyAsync(h_desc, ctx->d_desc, (size_t)n * CLC_DESC_BYTES, hipMemcpyDeviceToHost, ctx->stream));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CLC_OK;
@@ -480,7 +571,7 @@ int clc_pnp_residuals(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X
     double *dRt, *dX, *dx, *dK, *dE;
     const int rc = pnp_upload(ctx, h_Rt, H, h_X, h_x, N, h_K, (size_t)H * N, &dRt, &dX, &dx, &dK, &dE);
     if (rc != CLC_OK) return rc;
-    CLC_HIP(ctx, launch_pnp_residuals(dRt, H, dX, dx, N, dK, dE, ctx->stream));
+    CLC_HIP(ctx, launch_pnp_residuals(dRt, H, dX, dx, N, dK, dE, ctx->stream, &ctx->prof));
     CLC_HIP(ctx, hipMemcpyAsync(h_err, dE, sizeof(double) * (size_t)H * N, hipMemcpyDeviceToHost, ctx->stream));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CLC_OK;
@@ -498,7 +589,7 @@ int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, co
     if (rc != CLC_OK) return rc;
     double* d_cost = dE;
     int32_t* d_count = (int32_t*)(dE + H);
-    CLC_HIP(ctx, launch_pnp_score(dRt, H, dX, dx, N, dK, thr2, d_count, d_cost, ctx->stream));
+    CLC_HIP(ctx, launch_pnp_score(dRt, H, dX, dx, N, dK, thr2, d_count, d_cost, ctx->stream, &ctx->prof));
     if (h_cost) CLC_HIP(ctx, hipMemcpyAsync(h_cost, d_cost, sizeof(double) * H, hipMemcpyDeviceToHost, ctx->stream));
     if (h_count) CLC_HIP(ctx, hipMemcpyAsync(h_count, d_count, sizeof(int32_t) * H, hipMemcpyDeviceToHost, ctx->stream));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -167,14 +167,16 @@ __global__ __launch_bounds__(64 * kClatchWaves) void clatch_kernel(const ClatchA
 }
 
 hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps, int n,
-                         uint64_t* d_desc, hipStream_t stream)
+                         uint64_t* d_desc, hipStream_t stream, Profiler* prof)
 {
     if (n <= 0) return hipSuccess;
     ClatchArgs a;
     a.pd = pd;
     int blocks = (n + kClatchWaves - 1) / kClatchWaves;
     if (blocks > 512) blocks = 512;   // 2 workgroups (74 KB LDS each) per CU x 256 CUs, persistent
+    prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
     hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64 * kClatchWaves), 0, stream, a, arena, d_kps, n, d_desc);
+    prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
     return hipGetLastError();
 }
 

@@ -10,6 +10,11 @@
 
 namespace clc {
 
+// ---- optional per-kernel event timing (clc_profile_* in the C ABI) ---------------------------
+struct Profiler;
+// Records an event on `stream` tagged (kernel, begin/end); no-op when prof is null or disabled.
+void prof_mark(Profiler* prof, int kernel, bool begin, hipStream_t stream);
+
 // ---- pyramid -------------------------------------------------------------------------------
 struct LevelDesc {
     uint32_t w, h;        // level size
@@ -24,11 +29,11 @@ struct PyramidDesc {
 };
 
 // Resample levels 1..L-1 from level 0 (all inside `arena`) in one launch.
-hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream);
+hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream, Profiler* prof = nullptr);
 
 // ---- CLATCH ----------------------------------------------------------------------------------
 hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
-                         int n, uint64_t* d_desc, hipStream_t stream);
+                         int n, uint64_t* d_desc, hipStream_t stream, Profiler* prof = nullptr);
 
 // ---- K2NN ------------------------------------------------------------------------------------
 struct K2nnJobDev {
@@ -56,15 +61,17 @@ struct K2nnPlan {
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
 K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks);
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
-hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream);
+hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream,
+                       Profiler* prof = nullptr);
 int k2nn_queries_per_block();
 
 // ---- PnP -------------------------------------------------------------------------------------
 hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x,
-                                int N, const double* d_K, double* d_err, hipStream_t stream);
+                                int N, const double* d_K, double* d_err, hipStream_t stream,
+                                Profiler* prof = nullptr);
 hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,
                             const double* d_K, double thr2, int32_t* d_count, double* d_cost,
-                            hipStream_t stream);
+                            hipStream_t stream, Profiler* prof = nullptr);
 
 } // namespace clc
 #endif

@@ -132,33 +132,76 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
     }
 }
 
-// Fold the per-split partials of one query left to right and threshold.
-__global__ __launch_bounds__(256) void k2nn_merge_kernel(const K2nnJobList jobs,
-                                                          const uint2* __restrict__ partial)
+// Fold the per-split partials of one query and threshold.
+// The merge of two partial results is associative as long as the left operand holds the lower
+// train indices, so the splits of a query are folded by kMergeGroups threads in parallel (each a
+// contiguous run of splits, loads issued 4 deep) and the group results are folded in order through
+// LDS.  Reads stay coalesced: consecutive lanes own consecutive queries of one split row.
+static constexpr int kMergeQ = 32;        // queries per workgroup
+static constexpr int kMergeGroups = 8;    // split groups per query
+
+struct Top2 { int best_v, second_v, best_i; };
+
+__device__ __forceinline__ void fold(Top2& a, const uint32_t bk, const uint32_t sk, const uint32_t t0)
 {
+    if (bk == kEmpty) return;
+    const int b_best = (int)(bk >> kKeyShift);
+    const int b_idx = (int)(t0 + (bk & kIdxMask));
+    const int b_second = sk == kEmpty ? 100000 : (int)(sk >> kKeyShift);
+    if (b_best < a.best_v) {
+        a.second_v = min(a.best_v, b_second);
+        a.best_v = b_best;
+        a.best_i = b_idx;
+    } else {
+        a.second_v = min(a.second_v, b_best);
+    }
+}
+
+__global__ __launch_bounds__(kMergeQ * kMergeGroups) void k2nn_merge_kernel(const K2nnJobList jobs,
+                                                                             const uint2* __restrict__ partial)
+{
+    __shared__ Top2 sh[kMergeGroups][kMergeQ];
     const K2nnJobDev& job = jobs.j[blockIdx.y];
-    const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
-    if (qi >= job.nq) return;
-    int best_v = 100000, second_v = 200000, best_i = -1;   // CUDAK2NN.cu:54 sentinels
-    const uint2* p = partial + job.partial_off + qi;
-    const uint32_t nsplit = job.nt ? job.splits : 0u;   // nt == 0: nothing was swept -> -1
-    for (uint32_t s = 0; s < nsplit; ++s, p += job.nq_pad) {
-        const uint2 e = *p;
-        if (e.x == kEmpty) continue;
-        const int b_best = (int)(e.x >> kKeyShift);
-        const int b_idx = (int)(s * job.t_per_split + (e.x & kIdxMask));
-        const int b_second = e.y == kEmpty ? 100000 : (int)(e.y >> kKeyShift);
-        if (b_best < best_v) {
-            second_v = min(best_v, b_second);
-            best_v = b_best;
-            best_i = b_idx;
-        } else {
-            second_v = min(second_v, b_best);
+    const uint32_t qx = threadIdx.x & (kMergeQ - 1);
+    const uint32_t g = threadIdx.x / kMergeQ;
+    const uint32_t qi = blockIdx.x * kMergeQ + qx;
+    if (blockIdx.x * kMergeQ >= job.nq) return;                       // whole workgroup past the end
+    const uint32_t nsplit = job.nt ? job.splits : 0u;                  // nt == 0: nothing was swept -> -1
+    const uint32_t per_g = (nsplit + kMergeGroups - 1) / kMergeGroups;
+    const uint32_t s0 = min(g * per_g, nsplit), s1 = min(s0 + per_g, nsplit);
+    Top2 a{ 100000, 200000, -1 };                                      // CUDAK2NN.cu:54 sentinels
+    if (qi < job.nq) {
+        const uint2* p = partial + job.partial_off + (size_t)s0 * job.nq_pad + qi;
+        uint32_t s = s0;
+        for (; s + 4 <= s1; s += 4, p += 4 * (size_t)job.nq_pad) {
+            const uint2 e0 = p[0], e1 = p[job.nq_pad], e2 = p[2 * (size_t)job.nq_pad], e3 = p[3 * (size_t)job.nq_pad];
+            fold(a, e0.x, e0.y, s * job.t_per_split);
+            fold(a, e1.x, e1.y, (s + 1) * job.t_per_split);
+            fold(a, e2.x, e2.y, (s + 2) * job.t_per_split);
+            fold(a, e3.x, e3.y, (s + 3) * job.t_per_split);
+        }
+        for (; s < s1; ++s, p += job.nq_pad) {
+            const uint2 e = *p;
+            fold(a, e.x, e.y, s * job.t_per_split);
         }
     }
-    job.out[qi] = (best_i >= 0 && second_v - best_v > (int)job.thr) ? best_i : -1;
-    if (job.best_out) job.best_out[qi] = (uint16_t)min(best_v, 65535);
-    if (job.second_out) job.second_out[qi] = (uint16_t)min(second_v, 65535);
+    sh[g][qx] = a;
+    __syncthreads();
+    if (g != 0 || qi >= job.nq) return;
+    for (int k = 1; k < kMergeGroups; ++k) {                           // in order: group k holds higher indices
+        const Top2 b = sh[k][qx];
+        if (b.best_i < 0) continue;
+        if (b.best_v < a.best_v) {
+            a.second_v = min(a.best_v, b.second_v);
+            a.best_v = b.best_v;
+            a.best_i = b.best_i;
+        } else {
+            a.second_v = min(a.second_v, b.best_v);
+        }
+    }
+    job.out[qi] = (a.best_i >= 0 && a.second_v - a.best_v > (int)job.thr) ? a.best_i : -1;
+    if (job.best_out) job.best_out[qi] = (uint16_t)min(a.best_v, 65535);
+    if (job.second_out) job.second_out[qi] = (uint16_t)min(a.second_v, 65535);
 }
 
 K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
@@ -191,7 +234,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
     return plan;
 }
 
-hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream)
+hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream, Profiler* prof)
 {
     for (int base = 0; base < njobs; base += kK2nnJobsPerLaunch) {
         const int cnt = njobs - base < kK2nnJobsPerLaunch ? njobs - base : kK2nnJobsPerLaunch;
@@ -205,10 +248,15 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
         }
         for (int j = cnt; j < kK2nnJobsPerLaunch; ++j) list.j[j] = K2nnJobDev{};
         if (max_nq == 0) continue;
-        if (grid_x > 0)
+        if (grid_x > 0) {
+            prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, true, stream);
             hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
-        hipLaunchKernelGGL(k2nn_merge_kernel, dim3((max_nq + 255) / 256, cnt), dim3(256), 0, stream, list,
-                           (const uint2*)d_partial);
+            prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, false, stream);
+        }
+        prof_mark(prof, CLC_KERNEL_K2NN_MERGE, true, stream);
+        hipLaunchKernelGGL(k2nn_merge_kernel, dim3((max_nq + kMergeQ - 1) / kMergeQ, cnt), dim3(kMergeQ * kMergeGroups),
+                           0, stream, list, (const uint2*)d_partial);
+        prof_mark(prof, CLC_KERNEL_K2NN_MERGE, false, stream);
     }
     return hipGetLastError();
 }

@@ -72,14 +72,16 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t*
     *reinterpret_cast<uint32_t*>(arena + L.offset + (size_t)y * L.pitch + x0) = packed;
 }
 
-hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream)
+hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream, Profiler* prof)
 {
     if (pd.levels <= 1) return hipSuccess;
     LerpArgs a;
     a.pd = pd;
     const uint32_t nblk = pd.blk_begin[pd.levels] - pd.blk_begin[1];
     if (nblk == 0) return hipSuccess;
+    prof_mark(prof, CLC_KERNEL_PYRAMID, true, stream);
     hipLaunchKernelGGL(pyramid_kernel, dim3(pd.blk_begin[pd.levels]), dim3(256), 0, stream, a, arena);
+    prof_mark(prof, CLC_KERNEL_PYRAMID, false, stream);
     return hipGetLastError();
 }
 

@@ -78,18 +78,23 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const double* __restrict
 }
 
 hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,
-                                const double* d_K, double* d_err, hipStream_t stream)
+                                const double* d_K, double* d_err, hipStream_t stream, Profiler* prof)
 {
     if (H <= 0 || N <= 0) return hipSuccess;
+    prof_mark(prof, CLC_KERNEL_PNP_RESIDUALS, true, stream);
     hipLaunchKernelGGL(pnp_residual_kernel, dim3((N + 255) / 256, H), dim3(256), 0, stream, d_Rt, d_X, d_x, N, d_K, d_err);
+    prof_mark(prof, CLC_KERNEL_PNP_RESIDUALS, false, stream);
     return hipGetLastError();
 }
 
 hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,
-                            const double* d_K, double thr2, int32_t* d_count, double* d_cost, hipStream_t stream)
+                            const double* d_K, double thr2, int32_t* d_count, double* d_cost, hipStream_t stream,
+                            Profiler* prof)
 {
     if (H <= 0) return hipSuccess;
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
     hipLaunchKernelGGL(pnp_score_kernel, dim3(H), dim3(256), 0, stream, d_Rt, d_X, d_x, N, d_K, thr2, d_count, d_cost);
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
     return hipGetLastError();
 }
 

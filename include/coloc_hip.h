@@ -105,6 +105,25 @@ int clc_sync(clc_ctx* ctx);
 /* The context's hipStream_t (as void*), for callers that enqueue their own work in order. */
 void* clc_stream(clc_ctx* ctx);
 
+/* ---- kernel timing (replaces the std::chrono prints around CUDAK2NN, GPUMatcher.hpp:204-206) ---
+ * When enabled, every kernel launch made through this context is bracketed by a pair of HIP
+ * events on the stream it is launched on.  clc_profile_read drains the finished pairs (it
+ * synchronises those streams) and returns the accumulated device time and launch count of one
+ * kernel since the last clc_profile_reset. */
+enum {
+    CLC_KERNEL_PYRAMID = 0,
+    CLC_KERNEL_CLATCH = 1,
+    CLC_KERNEL_K2NN_SWEEP = 2,
+    CLC_KERNEL_K2NN_MERGE = 3,
+    CLC_KERNEL_PNP_RESIDUALS = 4,
+    CLC_KERNEL_PNP_SCORE = 5,
+    CLC_KERNEL_COUNT = 6
+};
+int clc_profile_enable(clc_ctx* ctx, int on);
+int clc_profile_reset(clc_ctx* ctx);
+int clc_profile_read(clc_ctx* ctx, int kernel, double* total_ms, int* launches);
+const char* clc_kernel_name(int kernel);
+
 /* ---- pyramid: replaces CUDALERP() (CUDALERP.h:166) + the level loop GPUDetector.hpp:232-255 -- */
 
 /* Upload a WxH u8 image (tight rows) as level 0 and resample levels 1..L-1 from it. */

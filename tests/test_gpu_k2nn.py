@@ -1,0 +1,97 @@
+"""GPU parity of the K2NN matcher (through the C ABI) against the CPU oracle: bit-identical match
+indices and distances.  Reference semantics: src/CUDAK2NN.cu:46-75; index conventions
+include/coloc/GPUMatcher.hpp:180-226,252-271."""
+import numpy as np
+import pytest
+
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nq,nt,thr", [
+    (1, 1, 40), (1, 2, 40), (5, 2, 0), (63, 64, 40), (64, 65, 40), (255, 257, 60), (256, 256, 40),
+    (257, 1000, 40), (511, 513, 40), (512, 31, 40), (513, 33, 40), (1000, 1, 40), (3000, 2500, 60),
+    (10000, 10000, 40), (20000, 777, 40), (777, 20000, 40),
+])
+def test_match_indices_bit_identical(gpu_ctx, oracle, nq, nt, thr):
+    Q, T = synth.planted_descriptors(nq, nt, seed=3000 + nq * 7 + nt)
+    m, b, s = gpu_ctx.match_2nn(Q, T, thr, want_dist=True)
+    mo, bo, so = oracle.k2nn(Q, T, thr, want_dist=True)
+    assert np.array_equal(m, mo)
+    assert np.array_equal(b, bo) and np.array_equal(s, so)
+
+
+def test_nt_zero_gives_no_match(gpu_ctx):
+    Q = synth.random_descriptors(100, seed=1)
+    assert (gpu_ctx.match_2nn(Q, np.zeros((0, 64), np.uint8), 40) == -1).all()
+
+
+def test_empty_query_set(gpu_ctx):
+    T = synth.random_descriptors(10, seed=1)
+    assert gpu_ctx.match_2nn(np.zeros((0, 64), np.uint8), T, 40).shape == (0,)
+
+
+def test_duplicates_ties_and_lowest_index(gpu_ctx, oracle):
+    T = synth.random_descriptors(5000, seed=2)
+    T[4000] = T[3]; T[17] = T[4999]; T[2500] = T[2499]
+    Q = T[[3, 4999, 2499, 100]].copy()
+    Q[3, 5] ^= 0x10
+    for thr in (0, 40):
+        m, b, s = gpu_ctx.match_2nn(Q, T, thr, want_dist=True)
+        mo, bo, so = oracle.k2nn(Q, T, thr, want_dist=True)
+        assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so)
+    assert m[0] == -1 and m[1] == -1 and m[2] == -1 and m[3] == 100     # ties rejected; unique near-duplicate accepted
+
+
+def test_threshold_edges_and_uint8_truncation(gpu_ctx, oracle):
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 256, 64, dtype=np.uint8)
+
+    def flipped(k):
+        bits = np.unpackbits(base); bits[:k] ^= 1
+        return np.packbits(bits)
+
+    T = np.stack([flipped(10), flipped(51)])
+    q = base[None]
+    for thr, want in ((40, 0), (41, -1), (296, 0), (297, -1)):
+        assert gpu_ctx.match_2nn(q, T, thr)[0] == want == oracle.k2nn(q, T, thr)[0]
+
+
+def test_all_zero_and_all_one_descriptors(gpu_ctx, oracle):
+    Q = np.zeros((130, 64), np.uint8); Q[::2] = 0xFF
+    T = np.zeros((70, 64), np.uint8); T[1::3] = 0xFF; T[5, 0] = 1
+    m, b, s = gpu_ctx.match_2nn(Q, T, 0, want_dist=True)
+    mo, bo, so = oracle.k2nn(Q, T, 0, want_dist=True)
+    assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so)
+
+
+def test_map_tracking_path(gpu_ctx, oracle):
+    """setMapData + matchFeaturesWithMap (GPUMatcher.hpp:110-117,252-271): train = map, thr = Mopts.thresh."""
+    Q, M = synth.planted_descriptors(1500, 4000, seed=99)
+    gpu_ctx.set_map(M)
+    assert np.array_equal(gpu_ctx.match_map(Q, 60), oracle.k2nn(Q, M, 60))
+    assert np.array_equal(gpu_ctx.match_map(Q[:10], 60), oracle.k2nn(Q[:10], M, 60))
+
+
+def test_capacity_is_checked(gpu_ctx):
+    from coloc_amd import CLCError
+    Q = synth.random_descriptors(20001, seed=3)
+    with pytest.raises(CLCError) as e:
+        gpu_ctx.match_2nn(Q, Q[:10], 40)
+    assert e.value.status == 2
+
+
+def test_full_size_properties(gpu_ctx, oracle):
+    """BASELINE config[1] size (10k x 10k): self-match is the identity with distance 0, and the result
+    is invariant under a permutation of the train set (indices map through the permutation)."""
+    D = synth.random_descriptors(10000, seed=3000)
+    m, b, s = gpu_ctx.match_2nn(D, D, 40, want_dist=True)
+    assert np.array_equal(m, np.arange(10000)) and (b == 0).all()
+    Q, T = synth.planted_descriptors(10000, 10000, seed=4242)
+    perm = np.random.default_rng(1).permutation(10000)
+    m1 = gpu_ctx.match_2nn(Q, T, 40)
+    m2 = gpu_ctx.match_2nn(Q, T[perm], 40)
+    acc = m1 >= 0
+    assert np.array_equal(acc, m2 >= 0)
+    assert np.array_equal(perm[m2[acc]], m1[acc])
