@@ -1,0 +1,62 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/coloc_hip.h
+declares; struct layouts match the reference's wire formats.  No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "coloc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(clc_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from coloc_amd import abi
+    lib = abi.load_library()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "missing export " + n
+    assert sorted(abi.EXPORTS) == names
+    assert lib.clc_abi_version() == 1
+    assert lib.clc_status_string(2) == b"capacity exceeded"
+
+
+def test_struct_layouts():
+    from coloc_amd import abi
+    assert abi.KP_DTYPE.itemsize == 20                       # Keypoint.h:155-163
+    assert [abi.KP_DTYPE.fields[k][1] for k in ("x", "y", "score", "angle", "scale")] == [0, 4, 8, 12, 16]
+    assert C.sizeof(abi.DetectorOptions) == 24 and C.sizeof(abi.MatcherOptions) == 12
+    assert C.sizeof(abi.MatchJob) == 24
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from coloc_amd import abi
+    monkeypatch.setattr(abi, "_lib", None)
+    monkeypatch.setenv("COLOC_HIP_LIB", "/nonexistent/libcoloc_hip.so")
+    with pytest.raises(abi.CLCError):
+        abi.load_library()
+
+
+def test_no_device_is_an_error_code_not_a_crash():
+    """In the CPU container there is no GPU: ctx_create must return CLC_ERR_NO_DEVICE (4)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from coloc_amd import Context, CLCError
+    with pytest.raises(CLCError) as e:
+        Context(device=0)
+    assert e.value.status == 4
+
+
+def test_keypoints_to_features_is_host_only(oracle):
+    import synth
+    from coloc_amd import keypoints_to_features
+    kps = synth.random_keypoints(64, 640, 480, seed=1)
+    assert np.array_equal(keypoints_to_features(kps), oracle.features_from_kps(kps))
