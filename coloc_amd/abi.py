@@ -55,6 +55,28 @@ def lib_path():
     return os.environ.get("COLOC_HIP_LIB", os.path.join(_PKG, "lib", "libcoloc_hip.so"))
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so / libhsa-runtime64.so.  Two HIP runtimes in one
+    process cannot both own the GPU ("No HIP GPUs are available" in whichever initialises second), so
+    when torch is installed its runtime is mapped first and libcoloc_hip.so's DT_NEEDED
+    libamdhip64.so.7 resolves to it.  A pure C/C++ host simply uses the system ROCm runtime."""
+    if os.environ.get("COLOC_HIP_SYSTEM_RUNTIME"):
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libcoloc_hip.so; raises (never falls back) when it is absent."""
     global _lib
@@ -64,6 +86,7 @@ def load_library():
     if not os.path.exists(path):
         raise CLCError(-1, "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     lib.clc_status_string.restype = C.c_char_p
     lib.clc_last_error_string.restype = C.c_char_p
@@ -150,8 +173,14 @@ class Context:
         return self.lib.clc_stream(self.h)
 
     # -- per-kernel event timing
-    def profile_enable(self, on=True):
-        self._chk(self.lib.clc_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, on=True, only=None):
+        """on=True brackets every kernel with HIP events; only=[kernel names] restricts it."""
+        v = 1 if on else 0
+        if on and only:
+            v = 0
+            for name in only:
+                v |= 1 << (KERNELS.index(name) + 1)
+        self._chk(self.lib.clc_profile_enable(self.h, v))
 
     def profile_reset(self):
         self._chk(self.lib.clc_profile_reset(self.h))

@@ -22,6 +22,7 @@ namespace clc {
 // Event pairs recorded around kernel launches; drained (with a stream sync) by clc_profile_read.
 struct Profiler {
     bool on = false;
+    unsigned mask = 0xFFFFFFFFu;   // which kernels are bracketed
     struct Pair { hipEvent_t a = nullptr, b = nullptr; int kernel = 0; hipStream_t stream = nullptr; bool open = false; };
     std::vector<Pair> pending;
     std::vector<hipEvent_t> pool;
@@ -54,7 +55,7 @@ struct Profiler {
 };
 void prof_mark(Profiler* prof, int kernel, bool begin, hipStream_t stream)
 {
-    if (!prof || !prof->on) return;
+    if (!prof || !prof->on || !((prof->mask >> kernel) & 1u)) return;
     if (begin) {
         Profiler::Pair p;
         p.a = prof->get(); p.b = prof->get(); p.kernel = kernel; p.stream = stream; p.open = true;
@@ -98,7 +99,7 @@ struct clc_ctx {
     uint16_t* d_second = nullptr;
     uint2* d_partial = nullptr;
     size_t partial_cap = 0;
-    int target_blocks = 2048;
+    int target_blocks = 4096;
     // pnp
     double* d_pnp = nullptr;
     size_t pnp_cap = 0;   // doubles
@@ -299,6 +300,8 @@ int clc_profile_enable(clc_ctx* ctx, int on)
     (void)hipSetDevice(ctx->device);
     if (!on) ctx->prof.drain();
     ctx->prof.on = on != 0;
+    // on = 1: every kernel; otherwise bit (k + 1) selects kernel k, e.g. 1 << (CLC_KERNEL_K2NN_SWEEP + 1)
+    ctx->prof.mask = (on == 1 || on == 0) ? 0xFFFFFFFFu : ((unsigned)on >> 1);
     return CLC_OK;
 }
 
@@ -338,10 +341,8 @@ int clc_pyramid_build_dev(clc_ctx* ctx, const void* d_img, uint32_t width, uint3
         return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_build: image size differs from DetectorOptions width/height");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    const LevelDesc& L0 = ctx->pd.lv[0];
-    CLC_HIP(ctx, hipMemcpy2DAsync(ctx->d_arena + L0.offset, L0.pitch, d_img, pitch, width, height,
-                                  hipMemcpyDeviceToDevice, st));
-    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, st, &ctx->prof));
+    if (pitch > 0xFFFFFFFFull) return fail(ctx, CLC_ERR_BAD_ARG, "pyramid_build: pitch too large");
+    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, (const uint8_t*)d_img, (uint32_t)pitch, st, &ctx->prof));
     ctx->pyramid_valid = true;
     return CLC_OK;
 }
@@ -356,7 +357,7 @@ int clc_pyramid_build(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32
     const LevelDesc& L0 = ctx->pd.lv[0];
     CLC_HIP(ctx, hipMemcpy2DAsync(ctx->d_arena + L0.offset, L0.pitch, h_img, width, width, height,
                                   hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, ctx->stream, &ctx->prof));
+    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, ctx->d_arena + L0.offset, L0.pitch, ctx->stream, &ctx->prof));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->pyramid_valid = true;
     return CLC_OK;

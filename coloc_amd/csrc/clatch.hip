@@ -10,59 +10,104 @@
 //   * (s, c) = clc_sincosf(angle): the correctly rounded fp32 sine / cosine (clc_sincos.h).
 //
 // The ARCHITECTURE is not the reference's (512-thread block per keypoint, 32-lane butterflies):
-//   * one WAVE64 per keypoint, 4 independent waves per workgroup, persistent over keypoints --
-//     no workgroup barrier anywhere.
-//   * window fill: 64 steps of an 8x8 lane tile, so one gather instruction touches a ~11x11 pixel
-//     footprint (about a dozen cache lines) of the L2-resident level instead of a 64-pixel line.
-//   * the window lives in LDS four times, shifted by 0..3 bytes, so that EVERY patch row (8
-//     pixels at an arbitrary byte offset) is a dword-aligned 8-byte LDS read from the copy
-//     selected by (offset & 3).  The three extra copies cost 18 wave-iterations of
-//     ds_read2 + 3 v_alignbyte + 3 ds_write per keypoint.
-//   * lane = triplet (8 triplets per lane): no cross-lane reduction at all.  With four pixels per
-//     dword, S = sum(A*A) - sum(C*C) - 2*(sum(A*B) - sum(C*B)) is four v_dot4_u32_u8 per dword
-//     triple, i.e. ONE VALU op per pixel-test instead of ~6.  The 64 sign bits of one round are a
-//     single wave ballot = two output words.
+//   * one WAVE64 per keypoint and one wave per workgroup: no barrier anywhere, ~14 KB of LDS per
+//     wave, so 11 keypoints are in flight per CU and the hardware dispatcher balances the load.
+//   * only window rows/cols 5..60 are ever read by the learned patches, so only those 56x56 samples
+//     are gathered (49 steps of an 8x8 lane tile instead of 64: one gather instruction touches a
+//     ~11x11 pixel footprint of the L2-resident level, about a dozen cache lines).
+//   * the window lives in LDS four times, shifted by 0..3 bytes, so that EVERY patch row (8 pixels
+//     at an arbitrary byte offset) is a dword-aligned 8-byte LDS read (ds_read2_b32) from the copy
+//     selected by (offset & 3).
+//   * lane = triplet (8 rounds x 64 lanes): no cross-lane reduction.  With four pixels per dword,
+//     S = sum(A*A) - sum(C*C) - 2*(sum(A*B) - sum(C*B)) is four v_dot4_u32_u8 per dword triple,
+//     i.e. ONE VALU op per pixel-test.
+//   * WHICH triplet a (round, lane) slot evaluates is chosen offline (tools/opt_latch_layout.py) so
+//     that the 32 lanes of a half-wave hit distinct LDS banks as far as the learned pattern allows
+//     (average conflict degree 3.4 -> 1.7); one ds_bpermute per output round puts the sign bits
+//     back into descriptor order before the wave ballot that forms two output words.
 //
-// Bound: LDS reads (48 dwords per test, random banks) and the window gather; compulsory HBM is
-// 20 B in + 64 B out per keypoint.
+// Bound: LDS reads (48 dwords per test) and the window gather; compulsory HBM is 20 B in + 64 B
+// out per keypoint.
 #include "clc_internal.h"
 #include "clc_sincos.h"
+#include "latch_layout.inc"
 
 namespace clc {
 
-static constexpr int kRoiStride = 72;                 // reference ROI row stride (CLATCH.cu:158)
-static constexpr int kCopyBytes = 64 * kRoiStride + 32; // 4640: one shifted copy (+ slack for the +3 shift)
-static constexpr int kCopies = 4;
-static constexpr int kClatchWaves = 4;
-static constexpr int kWaveLds = kCopies * kCopyBytes;   // 18560 B per wave, 74240 B per workgroup
+static constexpr int kRow0 = LATCH_ROW0, kCol0 = LATCH_COL0;   // first window row/col kept in LDS
+static constexpr int kStride = LATCH_STRIDE;                   // bytes per stored window row
+static constexpr int kWinDwords = LATCH_NROWS * LATCH_STRIDE / 4;
+static constexpr int kWaveLds = LATCH_WAVE_BYTES;
+static constexpr int kCopyBase[4] = LATCH_COPY_BASES;
+static constexpr int kTile0 = 5;                               // learned patches cover rows/cols 5..60
+static constexpr int kTiles = 7;
 
 struct PatchRow { uint8_t v[6]; };
 static constexpr PatchRow k_pattern[512] = {
 #include "latch_pattern.inc"
 };
+static constexpr uint16_t k_slot_triplet[512] = LATCH_SLOT_TRIPLET;
 
-// LDS byte address (inside one wave's region) of the dword-aligned start of a patch whose top-left
-// ROI byte offset is p = row*72 + col: copy (p & 3) holds roi[i + (p & 3)] at byte i.
-struct PatchTable { uint16_t a[512][4]; };
+// LDS byte address (inside the wave's region) of the dword-aligned start of the patch whose
+// top-left window pixel is (row, col): copy k = (p & 3) holds win[i + k] at byte i.
 static constexpr uint16_t patch_lds_addr(int row, int col)
 {
-    const int p = row * kRoiStride + col;
-    return (uint16_t)((p & 3) * kCopyBytes + (p & ~3));
+    const int p = (row - kRow0) * kStride + (col - kCol0);
+#if CLATCH_NOCOPY
+    return (uint16_t)p;
+#else
+    return (uint16_t)(kCopyBase[p & 3] + (p & ~3));
+#endif
 }
-static constexpr PatchTable make_patch_table()
+struct SlotTable {
+    uint16_t addr[512][4];   // per slot: LDS addresses of patches a, b, c (+ pad)
+    uint16_t src[512];       // per OUTPUT bit n: (source lane * 4) | (source round << 8)
+};
+static constexpr SlotTable make_slot_table()
 {
-    PatchTable t{};
-    for (int n = 0; n < 512; ++n) {
-        t.a[n][0] = patch_lds_addr(k_pattern[n].v[0], k_pattern[n].v[1]);
-        t.a[n][1] = patch_lds_addr(k_pattern[n].v[2], k_pattern[n].v[3]);
-        t.a[n][2] = patch_lds_addr(k_pattern[n].v[4], k_pattern[n].v[5]);
-        t.a[n][3] = 0;
+    SlotTable t{};
+    for (int slot = 0; slot < 512; ++slot) {
+        const int n = k_slot_triplet[slot];
+        t.addr[slot][0] = patch_lds_addr(k_pattern[n].v[0], k_pattern[n].v[1]);
+        t.addr[slot][1] = patch_lds_addr(k_pattern[n].v[2], k_pattern[n].v[3]);
+        t.addr[slot][2] = patch_lds_addr(k_pattern[n].v[4], k_pattern[n].v[5]);
+        t.addr[slot][3] = 0;
+        t.src[n] = (uint16_t)(((slot & 63) << 2) | ((slot >> 6) << 8));
     }
     return t;
 }
-__device__ const PatchTable k_patch_table = make_patch_table();
+__device__ const SlotTable k_slots = make_slot_table();
 
+#if CLATCH_NOCOPY
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(1)));
+#else
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+#endif
+
+// Experiment switches for tools/clatch_microbench.hip (defaults are what ships).
+#ifndef CLATCH_ABLATE
+#define CLATCH_ABLATE 0      // 1: skip tests, 2: skip fill gather, 3: skip copies (timing only; wrong output)
+#endif
+#ifndef CLATCH_NOCOPY
+#define CLATCH_NOCOPY 0      // 1: no shifted copies, byte-unaligned 8-byte LDS reads (experiment)
+#endif
+#ifndef CLATCH_READ2
+#define CLATCH_READ2 0       // 1: two volatile dword reads (experiment), 0: compiler's 8-byte read at a dword-aligned address
+#endif
+
+// 8 bytes at a dword-aligned LDS address
+__device__ __forceinline__ u32x2_a4 lds_read8(const uint8_t* p)
+{
+#if CLATCH_READ2
+    const volatile uint32_t* q = reinterpret_cast<const volatile uint32_t*>(p);   // volatile: not merged into a b64
+    u32x2_a4 r;
+    r.x = q[0];
+    r.y = q[1];
+    return r;
+#else
+    return *reinterpret_cast<const u32x2_a4*>(p);
+#endif
+}
 
 struct ClatchArgs {
     PyramidDesc pd;
@@ -72,27 +117,46 @@ __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
 {
     return __builtin_amdgcn_udot4(a, b, c, false);
 }
-
-__global__ __launch_bounds__(64 * kClatchWaves) void clatch_kernel(const ClatchArgs args,
-                                                                    const uint8_t* __restrict__ arena,
-                                                                    const clc_keypoint* __restrict__ kps,
-                                                                    const int n, uint64_t* __restrict__ desc)
+__device__ __forceinline__ int clamp_i32(int v, int hi)   // min(max(v, 0), hi) in one v_med3_i32
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kClatchWaves * kWaveLds];
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint8_t* const roi = lds + wave * kWaveLds;
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(hi));
+    return r;
+}
 
-    // this lane's 8 triplets: n = j*64 + lane
-    uint32_t pa[8], pb[8], pc[8];
+__global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena,
+                                                    const clc_keypoint* __restrict__ kps, const int n,
+                                                    uint64_t* __restrict__ desc)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t roi[kWaveLds];
+    const uint32_t lane = threadIdx.x;
+#if CLATCH_ABLATE == 7     // launch + LDS allocation only
+    if (n > 0) { roi[lane] = 1; if (lane == 0) desc[blockIdx.x * 8] = roi[5]; return; }
+#endif
+
+    // this lane's 8 slots (round j, lane) and, for the output, where bit 64*j + lane was computed
+    uint32_t pa[8], pb[8], pc[8], src[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint16_t* e = k_patch_table.a[j * 64 + lane];
+        const uint16_t* e = k_slots.addr[j * 64 + lane];
         pa[j] = e[0]; pb[j] = e[1]; pc[j] = e[2];
+        src[j] = k_slots.src[j * 64 + lane];
     }
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
+#if CLATCH_ABLATE == 6     // + table prologue
+    if (n > 0) { uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x ^= pa[j] ^ pb[j] ^ pc[j] ^ src[j];
+        desc[blockIdx.x * 8 + (lane & 7)] = x; return; }
+#endif
+#if CLATCH_ABLATE == 8     // + keypoint load and sincos
+    if (n > 0) { const clc_keypoint pt = kps[blockIdx.x]; float s, c; clc_sincosf(pt.angle, &s, &c); uint32_t x = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x ^= pa[j] ^ pb[j] ^ pc[j] ^ src[j];
+        desc[blockIdx.x * 8 + (lane & 7)] = x ^ __float_as_uint(s) ^ __float_as_uint(c); return; }
+#endif
 
-    for (int kp = (int)(blockIdx.x * kClatchWaves + wave); kp < n; kp += (int)(gridDim.x * kClatchWaves)) {
+    for (int kp = (int)blockIdx.x; kp < n; kp += (int)gridDim.x) {
         const clc_keypoint pt = kps[kp];                      // wave-uniform
         const int lv = min((int)pt.scale, args.pd.levels - 1);
         const LevelDesc L = args.pd.lv[lv];
@@ -102,62 +166,85 @@ __global__ __launch_bounds__(64 * kClatchWaves) void clatch_kernel(const ClatchA
         const float fpx = (float)pt.x, fpy = (float)pt.y;
         const int wmax = (int)L.w - 1, hmax = (int)L.h - 1;
 
-        // ---- window fill: step (by, bx) covers rows by*8.., cols bx*8.. with an 8x8 lane tile
-        float xc[8], xs[8], ys[8], yc[8];
+#if CLATCH_ABLATE == 5
+        uint32_t bits_sink = 0;
+#endif
+        // ---- window fill: tile (by, bx) covers rows 5+8*by.., cols 5+8*bx.. with an 8x8 lane tile
+        float xc[kTiles], xs[kTiles], ys[kTiles], yc[kTiles];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const float xo = (float)(b * 8 + dx - 32);
-            const float yo = (float)(b * 8 + dy - 32);
+        for (int b = 0; b < kTiles; ++b) {
+            const float xo = (float)(kTile0 + b * 8 + dx - 32);
+            const float yo = (float)(kTile0 + b * 8 + dy - 32);
             xc[b] = xo * c; xs[b] = xo * s;
             ys[b] = yo * s; yc[b] = yo * c;
         }
 #pragma unroll
-        for (int by = 0; by < 8; ++by) {
+        for (int by = 0; by < kTiles; ++by) {
 #pragma unroll
-            for (int bx = 0; bx < 8; ++bx) {
+            for (int bx = 0; bx < kTiles; ++bx) {
                 const float fx = (fpx + (xc[bx] - ys[by])) + 0.5f;   // CLATCH.cu:166
                 const float fy = (fpy + (xs[bx] + yc[by])) + 0.5f;
-                int sx = (int)fx, sy = (int)fy;
-                sx = min(max(sx, 0), wmax);
-                sy = min(max(sy, 0), hmax);
-                const uint8_t v = img[(uint32_t)sy * L.pitch + (uint32_t)sx];
-                roi[(by * 8 + dy) * kRoiStride + bx * 8 + dx] = v;
+                const int sx = clamp_i32((int)fx, wmax);
+                const int sy = clamp_i32((int)fy, hmax);
+                const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
+#if CLATCH_ABLATE == 2
+                roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = (uint8_t)off;
+#elif CLATCH_ABLATE == 4   // conflict-free dword writes instead of byte writes (timing only)
+                reinterpret_cast<uint32_t*>(roi)[(by * kTiles + bx) * 64 + lane] = img[off];
+#elif CLATCH_ABLATE == 5   // no LDS writes at all in the fill (timing only)
+                bits_sink ^= img[off];
+#else
+                roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = img[off];
+#endif
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // ---- shifted copies 1..3: copy_s[i] = roi[i + s]
+        // ---- shifted copies 1..3: copy_k[i] = win[i + k]
+#if CLATCH_ABLATE != 3 && !CLATCH_NOCOPY
 #pragma unroll 2
-        for (int i = (int)lane; i < (64 * kRoiStride) / 4; i += 64) {
+        for (int i = (int)lane; i < kWinDwords; i += 64) {
             const u32x2_a4 d = *reinterpret_cast<const u32x2_a4*>(roi + 4 * i);
-            uint32_t* w1 = reinterpret_cast<uint32_t*>(roi + 1 * kCopyBytes + 4 * i);
-            uint32_t* w2 = reinterpret_cast<uint32_t*>(roi + 2 * kCopyBytes + 4 * i);
-            uint32_t* w3 = reinterpret_cast<uint32_t*>(roi + 3 * kCopyBytes + 4 * i);
-            *w1 = __builtin_amdgcn_alignbyte(d.y, d.x, 1);
-            *w2 = __builtin_amdgcn_alignbyte(d.y, d.x, 2);
-            *w3 = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
+            *reinterpret_cast<uint32_t*>(roi + kCopyBase[1] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 1);
+            *reinterpret_cast<uint32_t*>(roi + kCopyBase[2] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 2);
+            *reinterpret_cast<uint32_t*>(roi + kCopyBase[3] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
         }
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        // ---- 512 tests, 8 per lane; one ballot = 64 descriptor bits
-        uint64_t mine = 0;
+        // ---- 512 tests, 8 per lane
+        uint32_t bits8 = 0;
+#if CLATCH_ABLATE == 5
+        bits8 = bits_sink & 1u;
+#endif
+#if CLATCH_ABLATE == 1
+        bits8 = *reinterpret_cast<const uint32_t*>(roi + pa[0]) ^ *reinterpret_cast<const uint32_t*>(roi + kCopyBase[3] + pb[1]);
+#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint32_t aa = 0, cc = 0, ab = 0, cb = 0;
 #pragma unroll
             for (int row = 0; row < 8; ++row) {
-                const u32x2_a4 A = *reinterpret_cast<const u32x2_a4*>(roi + pa[j] + row * kRoiStride);
-                const u32x2_a4 B = *reinterpret_cast<const u32x2_a4*>(roi + pb[j] + row * kRoiStride);
-                const u32x2_a4 C = *reinterpret_cast<const u32x2_a4*>(roi + pc[j] + row * kRoiStride);
+                const u32x2_a4 A = lds_read8(roi + pa[j] + row * kStride);
+                const u32x2_a4 B = lds_read8(roi + pb[j] + row * kStride);
+                const u32x2_a4 C = lds_read8(roi + pc[j] + row * kStride);
                 aa = udot4(A.x, A.x, aa); aa = udot4(A.y, A.y, aa);
                 cc = udot4(C.x, C.x, cc); cc = udot4(C.y, C.y, cc);
                 ab = udot4(A.x, B.x, ab); ab = udot4(A.y, B.y, ab);
                 cb = udot4(C.x, B.x, cb); cb = udot4(C.y, B.y, cb);
             }
             const int32_t S = ((int32_t)aa - (int32_t)cc) - 2 * ((int32_t)ab - (int32_t)cb);
-            const uint64_t bits = __ballot(S < 0);
+            bits8 |= (S < 0 ? 1u : 0u) << j;
+        }
+#endif
+        // ---- back to descriptor order: output round j, lane l <- bit of triplet 64*j + l
+        uint64_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src[j] & 0xFFu), (int)bits8);
+            const uint64_t bits = __ballot((got >> (src[j] >> 8)) & 1u);
             if (lane == (uint32_t)j) mine = bits;
         }
         if (lane < 8u) desc[(size_t)kp * 8u + lane] = mine;
@@ -172,10 +259,9 @@ hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_
     if (n <= 0) return hipSuccess;
     ClatchArgs a;
     a.pd = pd;
-    int blocks = (n + kClatchWaves - 1) / kClatchWaves;
-    if (blocks > 512) blocks = 512;   // 2 workgroups (74 KB LDS each) per CU x 256 CUs, persistent
+    const int blocks = n < 65536 ? n : 65536;   // one wave per keypoint; grid-stride beyond 64k
     prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
-    hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64 * kClatchWaves), 0, stream, a, arena, d_kps, n, d_desc);
+    hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64), 0, stream, a, arena, d_kps, n, d_desc);
     prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
     return hipGetLastError();
 }

@@ -28,8 +28,10 @@ struct PyramidDesc {
     int       levels;
 };
 
-// Resample levels 1..L-1 from level 0 (all inside `arena`) in one launch.
-hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream, Profiler* prof = nullptr);
+// One launch: copy the caller's device image (d_src, src_pitch bytes per row) into level 0 of the
+// arena and resample levels 1..L-1 from it.
+hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, const uint8_t* d_src, uint32_t src_pitch,
+                          hipStream_t stream, Profiler* prof = nullptr);
 
 // ---- CLATCH ----------------------------------------------------------------------------------
 hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,

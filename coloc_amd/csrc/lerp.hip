@@ -9,7 +9,7 @@
 // written in the source, no FMA contraction (the file is built with -ffp-contract=off).
 //
 // MI355X shape: the reference issues 7 launches on 7 streams (GPUDetector.hpp:250-255); here ALL
-// levels are one launch.  Each lane produces 4 horizontally adjacent output pixels and stores one
+// levels AND the level-0 copy into the pyramid arena are one launch.  Each lane produces 4 horizontally adjacent output pixels and stores one
 // dword, so a wave writes 256 contiguous bytes; the source taps are plain byte loads from the
 // L2-resident level-0 image (640x480 = 300 KB).  HBM-trivial: writes 2.09 x W x H bytes.
 #include "clc_internal.h"
@@ -18,6 +18,8 @@ namespace clc {
 
 struct LerpArgs {
     PyramidDesc pd;
+    uint32_t src_pitch;      // bytes per row of the caller's level-0 image
+    uint32_t copy_blocks;    // leading workgroups that copy level 0 into the arena (0 = already there)
 };
 
 __device__ __forceinline__ float tap(const uint8_t* __restrict__ img, uint32_t pitch, int W, int H, int x, int y)
@@ -27,22 +29,39 @@ __device__ __forceinline__ float tap(const uint8_t* __restrict__ img, uint32_t p
     return (float)img[(size_t)y * pitch + (size_t)x] / 255.0f;
 }
 
-__global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t* __restrict__ arena)
+__global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t* __restrict__ arena,
+                                                      const uint8_t* __restrict__ src0)
 {
+    const LevelDesc L0 = a.pd.lv[0];
+    if (blockIdx.x < a.copy_blocks) {
+        // level 0: copy the caller's image into the arena (dword stores; CLATCH samples it from there).
+        // The resample workgroups below read the CALLER's image, so there is no ordering between the two.
+        const uint32_t dpr = L0.pitch >> 2;
+        const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+        if (idx >= dpr * L0.h) return;
+        const uint32_t y = idx / dpr, x0 = (idx - y * dpr) << 2;
+        const uint8_t* __restrict__ row = src0 + (size_t)y * a.src_pitch;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (x0 + k < L0.w) packed |= (uint32_t)row[x0 + k] << (8 * k);
+        *reinterpret_cast<uint32_t*>(arena + L0.offset + (size_t)y * L0.pitch + x0) = packed;
+        return;
+    }
+    const uint32_t bid = blockIdx.x - a.copy_blocks;
     // which level does this workgroup belong to?  (wave-uniform scan over <= 7 entries)
     int lv = 1;
 #pragma unroll
     for (int i = 2; i < CLC_MAX_LEVELS; ++i)
-        if (i < a.pd.levels && blockIdx.x >= a.pd.blk_begin[i]) lv = i;
+        if (i < a.pd.levels && bid >= a.pd.blk_begin[i]) lv = i;
     const LevelDesc L = a.pd.lv[lv];
-    const LevelDesc L0 = a.pd.lv[0];
     const float gs = a.pd.f[lv];
     const uint32_t dpr = L.pitch >> 2;                       // dwords per output row
-    const uint32_t idx = (blockIdx.x - a.pd.blk_begin[lv]) * 256u + threadIdx.x;
+    const uint32_t idx = (bid - a.pd.blk_begin[lv]) * 256u + threadIdx.x;
     if (idx >= dpr * L.h) return;
     const uint32_t y = idx / dpr;
     const uint32_t x0 = (idx - y * dpr) << 2;
-    const uint8_t* __restrict__ src = arena + L0.offset;
+    const uint8_t* __restrict__ src = src0;
     const int W = (int)L0.w, H = (int)L0.h;
 
     const float fy = ((float)y + 0.5f) * gs - 0.5f;          // CUDALERP.cu:160
@@ -57,10 +76,10 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t*
         const float fx = ((float)x + 0.5f) * gs - 0.5f;      // :165
         const float fl_x = floorf(fx);
         const int i = (int)fl_x;
-        const float f_w = tap(src, L0.pitch, W, H, i, j);
-        const float f_z = tap(src, L0.pitch, W, H, i + 1, j);
-        const float f_x = tap(src, L0.pitch, W, H, i, j + 1);
-        const float f_y = tap(src, L0.pitch, W, H, i + 1, j + 1);
+        const float f_w = tap(src, a.src_pitch, W, H, i, j);
+        const float f_z = tap(src, a.src_pitch, W, H, i + 1, j);
+        const float f_x = tap(src, a.src_pitch, W, H, i, j + 1);
+        const float f_y = tap(src, a.src_pitch, W, H, i + 1, j + 1);
         const float wt_x = fx - fl_x;
         const float invwt_x = 1.0f - wt_x;
         const float xa = invwt_x * f_w + wt_x * f_z;         // :172
@@ -72,15 +91,19 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t*
     *reinterpret_cast<uint32_t*>(arena + L.offset + (size_t)y * L.pitch + x0) = packed;
 }
 
-hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, hipStream_t stream, Profiler* prof)
+hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, const uint8_t* d_src, uint32_t src_pitch,
+                          hipStream_t stream, Profiler* prof)
 {
-    if (pd.levels <= 1) return hipSuccess;
     LerpArgs a;
     a.pd = pd;
-    const uint32_t nblk = pd.blk_begin[pd.levels] - pd.blk_begin[1];
+    // d_src == level 0 inside the arena: nothing to copy
+    const bool in_place = d_src == arena + pd.lv[0].offset;
+    a.src_pitch = in_place ? pd.lv[0].pitch : src_pitch;
+    a.copy_blocks = in_place ? 0u : (pd.lv[0].pitch / 4 * pd.lv[0].h + 255) / 256;
+    const uint32_t nblk = a.copy_blocks + (pd.levels > 1 ? pd.blk_begin[pd.levels] : 0u);
     if (nblk == 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_PYRAMID, true, stream);
-    hipLaunchKernelGGL(pyramid_kernel, dim3(pd.blk_begin[pd.levels]), dim3(256), 0, stream, a, arena);
+    hipLaunchKernelGGL(pyramid_kernel, dim3(nblk), dim3(256), 0, stream, a, arena, d_src);
     prof_mark(prof, CLC_KERNEL_PYRAMID, false, stream);
     return hipGetLastError();
 }

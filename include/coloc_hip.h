@@ -119,6 +119,7 @@ enum {
     CLC_KERNEL_PNP_SCORE = 5,
     CLC_KERNEL_COUNT = 6
 };
+/* on = 0: off; 1: bracket every kernel; otherwise a mask, bit (k + 1) selecting kernel k. */
 int clc_profile_enable(clc_ctx* ctx, int on);
 int clc_profile_reset(clc_ctx* ctx);
 int clc_profile_read(clc_ctx* ctx, int kernel, double* total_ms, int* launches);

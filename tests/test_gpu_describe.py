@@ -118,3 +118,24 @@ def test_full_size_describe_then_match_roundtrip(oracle):
     assert np.array_equal(descs[0], odescs[0]) and np.array_equal(descs[1], odescs[1])
     assert np.array_equal(ctx.match_2nn(descs[0], descs[1], 40), oracle.k2nn(odescs[0], odescs[1], 40))
     ctx.close()
+
+
+def test_pyramid_from_device_image_with_pitch(oracle):
+    """clc_pyramid_build_dev: level 0 comes from a caller-owned device image with pitch > width; the
+    copy into the arena and the 7 resamples are one launch."""
+    import torch
+    W, H = 640, 480
+    img = synth.rect_image(W, H, seed=5, noise_sigma=2.0)
+    pitch = 704
+    padded = np.full((H, pitch), 0xAB, np.uint8)
+    padded[:, :W] = img
+    d = torch.from_numpy(padded).cuda()
+    ctx = _ctx(W, H, 64)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        ctx.pyramid_build_dev(d.data_ptr(), W, H, pitch, st.cuda_stream)
+    st.synchronize()
+    pyr = oracle.pyramid(img)
+    for lv in range(8):
+        assert np.array_equal(ctx.pyramid_download(lv), pyr[lv]), "level %d" % lv
+    ctx.close()

@@ -89,6 +89,67 @@ __global__ __launch_bounds__(64 * WAVES) void sweep(const u32x4* __restrict__ Q,
     for (int r = 0; r < R; ++r) { const uint32_t qi = qbase + 64u * r; if (qi < (uint32_t)nq) prow[qi] = u32x2{ best[r], second[r] }; }
 }
 
+// MODE 3: train tiles staged in LDS (double buffered), broadcast-read into VGPRs -> v_xor_b32 v,v,v (2-cycle form)
+template <int R, int WAVES, int TT>
+__global__ __launch_bounds__(64 * WAVES) void sweep_lds(const u32x4* __restrict__ Q, int nq, const u32x4* __restrict__ T, int nt,
+                                                       int splits, int t_per_split, u32x2* __restrict__ partial, int nq_pad)
+{
+    __shared__ u32x4 tile[2][TT * 4];
+    const uint32_t qblock = blockIdx.x / splits;
+    const uint32_t split = blockIdx.x - qblock * splits;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t qbase = qblock * (64u * R * WAVES) + wave * (64u * R) + lane;
+    uint32_t q[R][16];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t qi = qbase + 64u * r; if (qi >= (uint32_t)nq) qi = nq - 1;
+        const global_cu4_ptr qp = (global_cu4_ptr)(uintptr_t)Q + (size_t)qi * 4u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const u32x4 v = qp[k]; q[r][4*k] = v.x; q[r][4*k+1] = v.y; q[r][4*k+2] = v.z; q[r][4*k+3] = v.w; }
+    }
+    uint32_t best[R], second[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best[r] = 0xFFFFFFFFu; second[r] = 0xFFFFFFFFu; }
+    const uint32_t t0 = split * t_per_split;
+    uint32_t t1 = t0 + t_per_split; if (t1 > (uint32_t)nt) t1 = nt;
+    const global_cu4_ptr tg = (global_cu4_ptr)(uintptr_t)T;
+    constexpr int NT = 64 * WAVES;                 // threads
+    constexpr int PER = (TT * 4 + NT - 1) / NT;    // u32x4 per thread per tile
+    const uint32_t ntiles = (t1 - t0 + TT - 1) / TT;
+    u32x4 stage[PER];
+    auto gload = [&](uint32_t tile_i) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) {
+            const uint32_t e = threadIdx.x + p * NT;             // u32x4 index inside the tile
+            uint32_t row = t0 + tile_i * TT + (e >> 2);
+            if (row >= t1) row = t1 - 1;
+            stage[p] = (e < TT * 4) ? tg[(size_t)row * 4u + (e & 3u)] : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < PER; ++p) { const uint32_t e = threadIdx.x + p * NT; if (e < TT * 4) tile[buf][e] = stage[p]; }
+    };
+    gload(0); lstore(0);
+    __syncthreads();
+    for (uint32_t ti = 0; ti < ntiles; ++ti) {
+        const int buf = ti & 1;
+        if (ti + 1 < ntiles) gload(ti + 1);
+        const uint32_t base = t0 + ti * TT;
+        const uint32_t cnt = min((uint32_t)TT, t1 - base);
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const u32x4 a = tile[buf][j * 4], b = tile[buf][j * 4 + 1], c = tile[buf][j * 4 + 2], d = tile[buf][j * 4 + 3];
+            sweep_one<R>(q, a, b, c, d, base + j - t0, best, second);
+        }
+        if (ti + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    u32x2 __attribute__((address_space(1)))* prow = (u32x2 __attribute__((address_space(1)))*)(uintptr_t)partial + (size_t)split * nq_pad;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t qi = qbase + 64u * r; if (qi < (uint32_t)nq) prow[qi] = u32x2{ best[r], second[r] }; }
+}
+
+static unsigned long long g_checksum = 0;
 template <int R, int WAVES, int MODE>
 float run(const u32x4* dQ, int nq, const u32x4* dT, int nt, int target_blocks, u32x2* dP, int reps, int* out_splits)
 {
@@ -100,16 +161,28 @@ float run(const u32x4* dQ, int nq, const u32x4* dT, int nt, int target_blocks, u
     *out_splits = splits;
     const int nq_pad = (nq + 63) & ~63;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((sweep<R, WAVES, MODE>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+    auto launch = [&]() {
+        if (MODE == 3) hipLaunchKernelGGL((sweep_lds<R, WAVES, 64>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+        else if (MODE == 4) hipLaunchKernelGGL((sweep_lds<R, WAVES, 32>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+        else hipLaunchKernelGGL((sweep<R, WAVES, (MODE > 2 ? 0 : MODE)>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+    };
+    for (int i = 0; i < 3; ++i) launch();
     CHECK(hipDeviceSynchronize());
     std::vector<float> ts;
     for (int i = 0; i < reps; ++i) {
         CHECK(hipEventRecord(e0));
-        hipLaunchKernelGGL((sweep<R, WAVES, MODE>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+        launch();
         CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
         float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
     }
     std::sort(ts.begin(), ts.end());
+    {   // order-free checksum of (best, second) over splits: variants with equal split counts must agree
+        std::vector<u32x2> hp((size_t)splits * nq_pad);
+        CHECK(hipMemcpy(hp.data(), dP, hp.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long cs = 0;
+        for (int sp = 0; sp < splits; ++sp) for (int qq = 0; qq < nq; ++qq) { const u32x2 e = hp[(size_t)sp * nq_pad + qq]; cs += (unsigned long long)e.x * 2654435761u + e.y; }
+        g_checksum = cs;
+    }
     return ts[ts.size() / 2];
 }
 
@@ -130,18 +203,14 @@ int main(int argc, char** argv)
     const int targets[] = { 256, 512, 1024, 2048, 4096 };
     printf("%-28s %8s %7s %9s %9s\n", "variant", "target", "splits", "us", "Gcmp/s");
 #define RUN(R, WV, MODE, name) for (int tb : targets) { int sp; float ms = run<R, WV, MODE>(dQ, nq, dT, nt, tb, dP, 15, &sp); \
-        printf("%-28s %8d %7d %9.1f %9.1f\n", name, tb, sp, ms * 1e3, cmp / (ms * 1e-3) / 1e9); }
-    RUN(2, 4, 0, "R2 W4 plain");
-    RUN(2, 4, 1, "R2 W4 noload(ceiling)");
-    RUN(2, 4, 2, "R2 W4 prefetch");
-    RUN(1, 4, 0, "R1 W4 plain");
-    RUN(1, 4, 1, "R1 W4 noload(ceiling)");
-    RUN(1, 4, 2, "R1 W4 prefetch");
-    RUN(4, 4, 0, "R4 W4 plain");
-    RUN(4, 4, 1, "R4 W4 noload(ceiling)");
-    RUN(4, 4, 2, "R4 W4 prefetch");
-    RUN(2, 1, 2, "R2 W1 prefetch");
-    RUN(2, 2, 2, "R2 W2 prefetch");
-    RUN(2, 8, 2, "R2 W8 prefetch");
+        printf("%-28s %8d %7d %9.1f %9.1f  cs %016llx\n", name, tb, sp, ms * 1e3, cmp / (ms * 1e-3) / 1e9, g_checksum); }
+    RUN(2, 4, 0, "R2 W4 plain (sgpr)");
+    RUN(2, 4, 3, "R2 W4 lds TT64");
+    RUN(2, 4, 4, "R2 W4 lds TT32");
+    RUN(1, 4, 3, "R1 W4 lds TT64");
+    RUN(4, 4, 3, "R4 W4 lds TT64");
+    RUN(2, 8, 3, "R2 W8 lds TT64");
+    RUN(2, 2, 3, "R2 W2 lds TT64");
+    RUN(3, 4, 3, "R3 W4 lds TT64");
     return 0;
 }
