@@ -43,10 +43,11 @@ EXPORTS = [
     "clc_pyramid_download", "clc_describe", "clc_describe_dev", "clc_keypoints_to_features",
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
-    "clc_kernel_name",
+    "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
+    "clc_detect_and_describe",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
-           "pnp_score_kernel"]
+           "pnp_score_kernel", "detect_kernels"]
 
 _lib = None
 
@@ -111,6 +112,11 @@ def load_library():
     lib.clc_match_map.argtypes = [vp, vp, ci, ci, vp]
     lib.clc_pnp_residuals.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
     lib.clc_pnp_score.argtypes = [vp, vp, ci, vp, vp, ci, vp, C.c_double, vp, vp]
+    lib.clc_detect.argtypes = [vp, vp, ci, C.POINTER(ci), C.POINTER(ci)]
+    lib.clc_detect_dev.argtypes = [vp, vp]
+    lib.clc_detect_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.clc_describe_detected_dev.argtypes = [vp, vp, vp]
+    lib.clc_detect_and_describe.argtypes = [vp, vp, u32, u32, vp, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     lib.clc_profile_enable.argtypes = [vp, ci]
     lib.clc_profile_reset.argtypes = [vp]
     lib.clc_profile_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(ci)]
@@ -212,6 +218,36 @@ class Context:
         out = np.zeros((h, w), dtype=np.uint8)
         self._chk(self.lib.clc_pyramid_download(self.h, level, _p(out)))
         return out
+
+    # -- detect (GPU FAST-9 + NMS + orientation)
+    def detect(self, capacity=None):
+        """Keypoints of the current pyramid in the reference's order; returns (kps, n_found)."""
+        cap = int(capacity if capacity is not None else self.dopts.maxkp)
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        n, found = C.c_int(), C.c_int()
+        self._chk(self.lib.clc_detect(self.h, _p(kps), cap, C.byref(n), C.byref(found)))
+        return kps[:n.value], found.value
+
+    def detect_dev(self, stream=None):
+        self._chk(self.lib.clc_detect_dev(self.h, stream))
+
+    def detect_buffers(self):
+        k, c, d = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.clc_detect_buffers(self.h, C.byref(k), C.byref(c), C.byref(d)))
+        return k.value, c.value, d.value
+
+    def describe_detected_dev(self, d_desc=None, stream=None):
+        self._chk(self.lib.clc_describe_detected_dev(self.h, d_desc, stream))
+
+    def detect_and_describe(self, img, capacity=None):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        cap = int(capacity if capacity is not None else self.dopts.maxkp)
+        kps = np.zeros(cap, dtype=KP_DTYPE)
+        desc = np.zeros((cap, 64), dtype=np.uint8)
+        n, found = C.c_int(), C.c_int()
+        self._chk(self.lib.clc_detect_and_describe(self.h, _p(img), img.shape[1], img.shape[0], _p(kps), _p(desc), cap,
+                                                   C.byref(n), C.byref(found)))
+        return kps[:n.value], desc[:n.value], found.value
 
     # -- describe
     def describe(self, kps):

@@ -11,7 +11,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libcoloc_hip.so")
-SOURCES = ["capi.hip", "k2nn.hip", "clatch.hip", "lerp.hip", "pnp.hip"]
+SOURCES = ["capi.hip", "k2nn.hip", "clatch.hip", "lerp.hip", "pnp.hip", "detect.hip"]
 HEADERS = ["clc_internal.h", "clc_sincos.h", "latch_pattern.inc", "latch_layout.inc", os.path.join("..", "..", "include", "coloc_hip.h")]
 # -ffp-contract=off: the fp32 sample-coordinate / bilinear expressions and the fp64 residuals must
 # evaluate in source order without fused multiply-add.

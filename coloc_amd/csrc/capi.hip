@@ -86,9 +86,13 @@ struct clc_ctx {
     uint8_t* d_arena = nullptr;
     size_t arena_bytes = 0;
     bool pyramid_valid = false;
-    // describe
+    // detect + describe
     clc_keypoint* d_kps = nullptr;
     uint64_t* d_desc = nullptr;
+    uint8_t* d_score = nullptr;      // arena-shaped FAST score map
+    uint32_t* d_rows = nullptr;      // [row_count | row_off | count(2)]
+    uint32_t total_rows = 0;
+    bool detected = false;
     // match
     uint8_t* d_q = nullptr;
     uint8_t* d_t = nullptr;
@@ -245,6 +249,10 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         CREATE_HIP(hipMemsetAsync(ctx->d_arena, 0, ctx->arena_bytes, ctx->stream));
         CREATE_HIP(hipMalloc((void**)&ctx->d_kps, (size_t)dopts->maxkp * sizeof(clc_keypoint)));
         CREATE_HIP(hipMalloc((void**)&ctx->d_desc, (size_t)dopts->maxkp * CLC_DESC_BYTES));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_score, ctx->arena_bytes));
+        ctx->total_rows = detect_total_rows(ctx->pd);
+        CREATE_HIP(hipMalloc((void**)&ctx->d_rows, ((size_t)2 * ctx->total_rows + 4) * sizeof(uint32_t)));
+        CREATE_HIP(hipMemsetAsync(ctx->d_rows, 0, ((size_t)2 * ctx->total_rows + 4) * sizeof(uint32_t), ctx->stream));
     }
     if (mopts) {
         ctx->has_mat = true;
@@ -275,7 +283,7 @@ int clc_ctx_destroy(clc_ctx* ctx)
     if (!ctx) return CLC_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = { ctx->d_arena, ctx->d_kps, ctx->d_desc, ctx->d_q, ctx->d_t, ctx->d_m, ctx->d_match,
+    void* bufs[] = { ctx->d_arena, ctx->d_kps, ctx->d_desc, ctx->d_score, ctx->d_rows, ctx->d_q, ctx->d_t, ctx->d_m, ctx->d_match,
                      ctx->d_best, ctx->d_second, ctx->d_partial, ctx->d_pnp };
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -327,7 +335,8 @@ int clc_profile_read(clc_ctx* ctx, int kernel, double* total_ms, int* launches)
 const char* clc_kernel_name(int kernel)
 {
     static const char* names[CLC_KERNEL_COUNT] = { "pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel",
-                                                    "k2nn_merge_kernel", "pnp_residual_kernel", "pnp_score_kernel" };
+                                                    "k2nn_merge_kernel", "pnp_residual_kernel", "pnp_score_kernel",
+                                                    "detect_kernels" };
     return (kernel >= 0 && kernel < CLC_KERNEL_COUNT) ? names[kernel] : "?";
 }
 
@@ -383,6 +392,92 @@ int clc_pyramid_download(clc_ctx* ctx, int level, uint8_t* h_out)
     const LevelDesc& L = ctx->pd.lv[level];
     CLC_HIP(ctx, hipMemcpy2DAsync(h_out, L.w, ctx->d_arena + L.offset, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
+/* ---- detect -------------------------------------------------------------------------------- */
+
+static uint32_t* count_ptr(clc_ctx* ctx) { return ctx->d_rows + (size_t)2 * ctx->total_rows; }
+
+int clc_detect_dev(clc_ctx* ctx, void* stream)
+{
+    if (!ctx) return CLC_ERR_BAD_ARG;
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "detect: context created without detector options");
+    if (!ctx->pyramid_valid) return fail(ctx, CLC_ERR_STATE, "detect before pyramid_build");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    CLC_HIP(ctx, launch_detect(ctx->pd, ctx->d_arena, ctx->d_score, ctx->dopts.thresh, ctx->dopts.maxkp, ctx->d_rows,
+                               ctx->d_rows + ctx->total_rows, count_ptr(ctx), ctx->d_kps, pick(ctx, stream), &ctx->prof));
+    ctx->detected = true;
+    return CLC_OK;
+}
+
+int clc_detect_buffers(clc_ctx* ctx, const clc_keypoint** d_kps, const uint32_t** d_count, void** d_desc)
+{
+    if (!ctx || !ctx->has_det) return CLC_ERR_BAD_ARG;
+    if (d_kps) *d_kps = ctx->d_kps;
+    if (d_count) *d_count = count_ptr(ctx);
+    if (d_desc) *d_desc = ctx->d_desc;
+    return CLC_OK;
+}
+
+int clc_detect(clc_ctx* ctx, clc_keypoint* h_kps, int capacity, int* n_written, int* n_found)
+{
+    if (!ctx || capacity < 0 || (capacity > 0 && !h_kps)) return fail(ctx, CLC_ERR_BAD_ARG, "detect: bad argument");
+    const int rc = clc_detect_dev(ctx, nullptr);
+    if (rc != CLC_OK) return rc;
+    uint32_t cnt[2] = { 0, 0 };
+    CLC_HIP(ctx, hipMemcpyAsync(cnt, count_ptr(ctx), sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = (int)cnt[0] < capacity ? (int)cnt[0] : capacity;
+    if (n > 0) {
+        CLC_HIP(ctx, hipMemcpyAsync(h_kps, ctx->d_kps, (size_t)n * sizeof(clc_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n_written) *n_written = n;
+    if (n_found) *n_found = (int)cnt[1];
+    return CLC_OK;
+}
+
+int clc_describe_detected_dev(clc_ctx* ctx, void* d_desc, void* stream)
+{
+    if (!ctx) return CLC_ERR_BAD_ARG;
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "describe_detected: context created without detector options");
+    if (!ctx->detected) return fail(ctx, CLC_ERR_STATE, "describe_detected before detect");
+    if ((uintptr_t)d_desc & 7u) return fail(ctx, CLC_ERR_BAD_ARG, "describe_detected: misaligned device pointer");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    CLC_HIP(ctx, launch_clatch_counted(ctx->pd, ctx->d_arena, ctx->d_kps, count_ptr(ctx), (int)ctx->dopts.maxkp,
+                                       d_desc ? (uint64_t*)d_desc : ctx->d_desc, pick(ctx, stream), &ctx->prof));
+    return CLC_OK;
+}
+
+int clc_detect_and_describe(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32_t height, clc_keypoint* h_kps,
+                            uint8_t* h_desc, int capacity, int* n_written, int* n_found)
+{
+    if (!ctx || !h_img || capacity < 0 || (capacity > 0 && (!h_kps || !h_desc)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "detect_and_describe: bad argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "detect_and_describe: context created without detector options");
+    if (width != ctx->dopts.width || height != ctx->dopts.height)
+        return fail(ctx, CLC_ERR_BAD_ARG, "detect_and_describe: image size differs from DetectorOptions width/height");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    const LevelDesc& L0 = ctx->pd.lv[0];
+    CLC_HIP(ctx, hipMemcpy2DAsync(ctx->d_arena + L0.offset, L0.pitch, h_img, width, width, height, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_pyramid(ctx->pd, ctx->d_arena, ctx->d_arena + L0.offset, L0.pitch, ctx->stream, &ctx->prof));
+    ctx->pyramid_valid = true;
+    int rc = clc_detect_dev(ctx, nullptr);
+    if (rc != CLC_OK) return rc;
+    rc = clc_describe_detected_dev(ctx, nullptr, nullptr);
+    if (rc != CLC_OK) return rc;
+    uint32_t cnt[2] = { 0, 0 };
+    CLC_HIP(ctx, hipMemcpyAsync(cnt, count_ptr(ctx), sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int n = (int)cnt[0] < capacity ? (int)cnt[0] : capacity;
+    if (n > 0) {
+        CLC_HIP(ctx, hipMemcpyAsync(h_kps, ctx->d_kps, (size_t)n * sizeof(clc_keypoint), hipMemcpyDeviceToHost, ctx->stream));
+        CLC_HIP(ctx, hipMemcpyAsync(h_desc, ctx->d_desc, (size_t)n * CLC_DESC_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n_written) *n_written = n;
+    if (n_found) *n_found = (int)cnt[1];
     return CLC_OK;
 }
 

@@ -125,9 +125,12 @@ __device__ __forceinline__ int clamp_i32(int v, int hi)   // min(max(v, 0), hi) 
 }
 
 __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena,
-                                                    const clc_keypoint* __restrict__ kps, const int n,
-                                                    uint64_t* __restrict__ desc)
+                                                    const clc_keypoint* __restrict__ kps, const int n_arg,
+                                                    const uint32_t* __restrict__ n_dev, uint64_t* __restrict__ desc)
 {
+    // keypoint count: a launch argument, or (after the GPU detector) read from device memory
+    const int n = n_dev ? min((int)*n_dev, n_arg) : n_arg;
+    if ((int)blockIdx.x >= n) return;
     __shared__ __attribute__((aligned(16))) uint8_t roi[kWaveLds];
     const uint32_t lane = threadIdx.x;
 #if CLATCH_ABLATE == 7     // launch + LDS allocation only
@@ -261,7 +264,20 @@ hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_
     a.pd = pd;
     const int blocks = n < 65536 ? n : 65536;   // one wave per keypoint; grid-stride beyond 64k
     prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
-    hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64), 0, stream, a, arena, d_kps, n, d_desc);
+    hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64), 0, stream, a, arena, d_kps, n, (const uint32_t*)nullptr, d_desc);
+    prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_clatch_counted(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
+                                 const uint32_t* d_count, int max_n, uint64_t* d_desc, hipStream_t stream, Profiler* prof)
+{
+    if (max_n <= 0) return hipSuccess;
+    ClatchArgs a;
+    a.pd = pd;
+    const int blocks = max_n < 65536 ? max_n : 65536;
+    prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
+    hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64), 0, stream, a, arena, d_kps, max_n, d_count, d_desc);
     prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
     return hipGetLastError();
 }

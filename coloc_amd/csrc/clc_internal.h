@@ -37,6 +37,17 @@ hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, const uint8_t* 
 hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
                          int n, uint64_t* d_desc, hipStream_t stream, Profiler* prof = nullptr);
 
+// ---- detector (FAST-9 + NMS + orientation) ---------------------------------------------------
+// score: arena-shaped u8 scratch; d_count[0] = keypoints written (<= maxkp), d_count[1] = found.
+hipError_t launch_detect(const PyramidDesc& pd, const uint8_t* arena, uint8_t* score, uint32_t threshold,
+                         uint32_t maxkp, uint32_t* d_row_count, uint32_t* d_row_off, uint32_t* d_count,
+                         clc_keypoint* d_kps, hipStream_t stream, Profiler* prof = nullptr);
+uint32_t detect_total_rows(const PyramidDesc& pd);
+// CLATCH with the keypoint count read from device memory (no host round trip after detect)
+hipError_t launch_clatch_counted(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
+                                 const uint32_t* d_count, int max_n, uint64_t* d_desc, hipStream_t stream,
+                                 Profiler* prof = nullptr);
+
 // ---- K2NN ------------------------------------------------------------------------------------
 struct K2nnJobDev {
     const uint4* q;        // first query row of this job

@@ -117,7 +117,8 @@ enum {
     CLC_KERNEL_K2NN_MERGE = 3,
     CLC_KERNEL_PNP_RESIDUALS = 4,
     CLC_KERNEL_PNP_SCORE = 5,
-    CLC_KERNEL_COUNT = 6
+    CLC_KERNEL_DETECT = 6,      /* the FAST-9 / NMS / emit launch group, bracketed as one */
+    CLC_KERNEL_COUNT = 7
 };
 /* on = 0: off; 1: bracket every kernel; otherwise a mask, bit (k + 1) selecting kernel k. */
 int clc_profile_enable(clc_ctx* ctx, int on);
@@ -137,6 +138,26 @@ int clc_pyramid_level(const clc_ctx* ctx, int level, uint32_t* w, uint32_t* h, s
                       const void** d_ptr);
 /* Download one level into tight host rows (the reference's per-level D2H, GPUDetector.hpp:265). */
 int clc_pyramid_download(clc_ctx* ctx, int level, uint8_t* h_out);
+
+/* ---- detect: replaces the host loop KFAST<true,true> + featureAngle per level ---------------
+ * (GPUDetector.hpp:262-277; KFAST.h:502-540; FeatureAngle.h:197-246) -- on the GPU, all levels.
+ * Keypoints come out in the reference's order: level-major, then (y, x) ascending, with level-local
+ * integer coordinates, corner score, orientation and level.  FAST threshold = opts.thresh.
+ * At most DetectorOptions.maxkp keypoints are kept (the first ones in that order; the reference
+ * overflows its buffers instead, GPUDetector.hpp:135,281); *n_found reports how many there were. */
+int clc_detect(clc_ctx* ctx, clc_keypoint* h_kps, int capacity, int* n_written, int* n_found);
+/* Device-resident: keypoints stay in the context (clc_detect_buffers), nothing is copied back. */
+int clc_detect_dev(clc_ctx* ctx, void* stream);
+/* Device addresses of the context's keypoint array, of its uint32 count pair {written, found} and
+ * of its descriptor array (valid for the context's lifetime). */
+int clc_detect_buffers(clc_ctx* ctx, const clc_keypoint** d_kps, const uint32_t** d_count, void** d_desc);
+/* CLATCH over the context's own keypoints with the count taken from device memory; writes
+ * descriptors to d_desc (NULL = the context's descriptor array). */
+int clc_describe_detected_dev(clc_ctx* ctx, void* d_desc, void* stream);
+/* Whole front end on host buffers, like GPUDetector::detectAndDescribe (GPUDetector.hpp:216-291):
+ * upload image -> pyramid -> detect -> describe -> download keypoints + descriptors. */
+int clc_detect_and_describe(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32_t height,
+                            clc_keypoint* h_kps, uint8_t* h_desc, int capacity, int* n_written, int* n_found);
 
 /* ---- describe: replaces CLATCH() (CLATCH.h:168) + GPUDetector.hpp:280-290 ------------------ */
 
