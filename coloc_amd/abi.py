@@ -44,7 +44,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe",
+    "clc_detect_and_describe", "clc_match_pairs",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -108,6 +108,7 @@ def load_library():
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
     lib.clc_match_2nn_dev.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
     lib.clc_match_jobs_dev.argtypes = [vp, vp, vp, ci, vp, vp]
+    lib.clc_match_pairs.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp]
     lib.clc_set_map.argtypes = [vp, vp, ci]
     lib.clc_match_map.argtypes = [vp, vp, ci, ci, vp]
     lib.clc_pnp_residuals.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
@@ -275,6 +276,17 @@ class Context:
     def match_jobs_dev(self, d_desc_base, jobs, d_match, stream=None):
         arr = (MatchJob * len(jobs))(*[MatchJob(*j) for j in jobs])
         self._chk(self.lib.clc_match_jobs_dev(self.h, d_desc_base, arr, len(jobs), d_match, stream))
+
+    def match_pairs(self, descs, pairs, threshold=40):
+        """All listed (first, second) pairs over per-camera descriptor arrays; returns a list of int32 arrays."""
+        descs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, 64) for d in descs]
+        counts = (C.c_int * len(descs))(*[d.shape[0] for d in descs])
+        dptr = (C.c_void_p * len(descs))(*[d.ctypes.data for d in descs])
+        flat = (C.c_int * (2 * len(pairs)))(*[v for p in pairs for v in p])
+        outs = [np.full(descs[a].shape[0], -2, dtype=np.int32) for a, _ in pairs]
+        optr = (C.c_void_p * len(pairs))(*[o.ctypes.data for o in outs])
+        self._chk(self.lib.clc_match_pairs(self.h, dptr, counts, len(descs), flat, len(pairs), int(threshold), optr))
+        return outs
 
     def set_map(self, desc):
         desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 64)

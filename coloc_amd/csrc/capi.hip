@@ -105,6 +105,8 @@ struct clc_ctx {
     size_t partial_cap = 0;
     int target_blocks = 4096;
     // pnp
+    uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
+    size_t pairs_cap = 0;
     double* d_pnp = nullptr;
     size_t pnp_cap = 0;   // doubles
     Profiler prof;
@@ -284,7 +286,7 @@ int clc_ctx_destroy(clc_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     void* bufs[] = { ctx->d_arena, ctx->d_kps, ctx->d_desc, ctx->d_score, ctx->d_rows, ctx->d_q, ctx->d_t, ctx->d_m, ctx->d_match,
-                     ctx->d_best, ctx->d_second, ctx->d_partial, ctx->d_pnp };
+                     ctx->d_best, ctx->d_second, ctx->d_partial, ctx->d_pnp, ctx->d_pairs };
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -608,6 +610,69 @@ int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     if (nt > 0) CLC_HIP(ctx, hipMemcpyAsync(ctx->d_t, h_t, (size_t)nt * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
     return match_host(ctx, h_q, nq, ctx->d_t, nt, threshold, h_match, h_best, h_second);
+}
+
+int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, int ncams, const int* pairs,
+                    int npairs, int threshold, int32_t* const* h_match)
+{
+    if (!ctx || ncams < 0 || npairs < 0 || (ncams > 0 && (!h_desc || !counts)) || (npairs > 0 && (!pairs || !h_match)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_pairs: bad argument");
+    if (npairs == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<size_t> cam_off(ncams + 1, 0);
+    for (int c = 0; c < ncams; ++c) {
+        if (counts[c] < 0 || (counts[c] > 0 && !h_desc[c])) return fail(ctx, CLC_ERR_BAD_ARG, "match_pairs: bad camera entry");
+        cam_off[c + 1] = cam_off[c] + (size_t)counts[c];
+    }
+    size_t out_rows = 0;
+    for (int p = 0; p < npairs; ++p) {
+        const int a = pairs[2 * p], b = pairs[2 * p + 1];
+        if (a < 0 || a >= ncams || b < 0 || b >= ncams || (counts[a] > 0 && !h_match[p]))
+            return fail(ctx, CLC_ERR_BAD_ARG, "match_pairs: bad pair entry");
+        out_rows += (size_t)counts[a];
+    }
+    const size_t desc_bytes = cam_off[ncams] * CLC_DESC_BYTES;
+    const size_t need = desc_bytes + out_rows * sizeof(int32_t) + 256;
+    if (need > ctx->pairs_cap) {
+        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_pairs) CLC_HIP(ctx, hipFree(ctx->d_pairs));
+        ctx->d_pairs = nullptr; ctx->pairs_cap = 0;
+        CLC_HIP(ctx, hipMalloc((void**)&ctx->d_pairs, need));
+        ctx->pairs_cap = need;
+    }
+    for (int c = 0; c < ncams; ++c)
+        if (counts[c] > 0)
+            CLC_HIP(ctx, hipMemcpyAsync(ctx->d_pairs + cam_off[c] * CLC_DESC_BYTES, h_desc[c], (size_t)counts[c] * CLC_DESC_BYTES,
+                                        hipMemcpyHostToDevice, ctx->stream));
+    int32_t* d_out = (int32_t*)(ctx->d_pairs + ((desc_bytes + 255) & ~(size_t)255));
+    std::vector<K2nnJobDev> jobs;
+    std::vector<size_t> out_off(npairs, 0);
+    size_t o = 0;
+    for (int p = 0; p < npairs; ++p) {
+        const int a = pairs[2 * p], b = pairs[2 * p + 1];
+        out_off[p] = o;
+        if (counts[a] == 0) continue;
+        K2nnJobDev jb{};
+        jb.q = (const uint4*)(ctx->d_pairs + cam_off[a] * CLC_DESC_BYTES);
+        jb.t = (const uint4*)(ctx->d_pairs + cam_off[b] * CLC_DESC_BYTES);
+        jb.out = d_out + o;
+        jb.nq = (uint32_t)counts[a];
+        jb.nt = (uint32_t)counts[b];
+        jb.thr = (uint32_t)(uint8_t)threshold;
+        jobs.push_back(jb);
+        o += (size_t)counts[a];
+    }
+    if (!jobs.empty()) {
+        const int rc = run_jobs(ctx, jobs, ctx->stream);
+        if (rc != CLC_OK) return rc;
+    }
+    for (int p = 0; p < npairs; ++p) {
+        const int a = pairs[2 * p];
+        if (counts[a] > 0)
+            CLC_HIP(ctx, hipMemcpyAsync(h_match[p], d_out + out_off[p], (size_t)counts[a] * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
 }
 
 int clc_set_map(clc_ctx* ctx, const void* h_desc, int n)

@@ -185,6 +185,14 @@ int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, in
 int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs,
                        int njobs, int32_t* d_match, void* stream);
 
+/* The all-pairs loop of GPUMatcher::computeMatches (GPUMatcher.hpp:143-155) on host buffers: uploads
+ * each camera's descriptors once (the reference re-uploads both sides for every pair,
+ * GPUMatcher.hpp:188-196), sweeps every listed (first, second) pair in one launch group (Q = first,
+ * T = second) and downloads one int32 array of counts[first] entries per pair into h_match[p]. */
+int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, int ncams,
+                    const int* pairs /* npairs x {first, second} */, int npairs, int threshold,
+                    int32_t* const* h_match);
+
 /* Map database: GPUMatcher::setMapData (GPUMatcher.hpp:110-117) / matchFeaturesWithMap (:252-271). */
 int clc_set_map(clc_ctx* ctx, const void* h_desc, int n);
 int clc_match_map(clc_ctx* ctx, const void* h_q, int nq, int threshold, int32_t* h_match);

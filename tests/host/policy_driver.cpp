@@ -1,0 +1,93 @@
+// policy_driver.cpp -- exercises HIPDetector<bool> / HIPMatcher<bool> exactly the way ColoC /
+// DiskInterface use GPUDetector / GPUMatcher (reference include/coloc/coloc.hpp:162,197,219,287,323;
+// InterfaceDisk.hpp:15) and dumps the results as raw files for tests/test_gpu_policy.py to compare
+// with the oracle.  usage: policy_driver <dir> <ncams> <width> <height> <maxkp>
+#include <cstdio>
+#include <fstream>
+#include <string>
+
+#include "HIPDetector.hpp"
+#include "HIPMatcher.hpp"
+
+using namespace openMVG;
+using namespace openMVG::matching;
+
+template <typename T, template <class> class ProcessorType>
+class FeatureDetector : public ProcessorType<T> {   // policy host, reference FeatureDetector.hpp:21-32
+public:
+    explicit FeatureDetector(coloc::DetectorOptions& opts) : ProcessorType<T>(opts) {}
+    T detectFeaturesFile(unsigned int idx, coloc::FeatureMap& regions, std::string& imageName)
+    {
+        return ProcessorType<T>::detectFeaturesFile(idx, regions, imageName);
+    }
+};
+template <typename T, template <class> class ProcessorType>
+class FeatureMatcher : public ProcessorType<T> {    // reference FeatureMatcher.hpp:23-34
+public:
+    explicit FeatureMatcher(coloc::MatcherOptions& opts) : ProcessorType<T>(opts) {}
+    bool computeMatches(coloc::FeatureMap& regions, PairWiseMatches& putativeMatches)
+    {
+        return ProcessorType<T>::computeMatches(regions, putativeMatches);
+    }
+};
+
+static void dump(const std::string& path, const void* p, size_t bytes)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(static_cast<const char*>(p), static_cast<std::streamsize>(bytes));
+}
+static void dump_matches(const std::string& path, const IndMatches& m)
+{
+    std::vector<uint32_t> flat;
+    for (const auto& e : m) { flat.push_back(e.i_); flat.push_back(e.j_); }
+    dump(path, flat.data(), flat.size() * 4);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 6) { std::fprintf(stderr, "usage: %s dir ncams width height maxkp\n", argv[0]); return 2; }
+    const std::string dir = argv[1];
+    const int ncams = std::atoi(argv[2]);
+    coloc::DetectorOptions dopts{ 1.2f, 8, static_cast<unsigned>(std::atoi(argv[3])), static_cast<unsigned>(std::atoi(argv[4])),
+                                  static_cast<unsigned>(std::atoi(argv[5])), 40 };           // coloc_node.cpp:76-81
+    coloc::MatcherOptions mopts{ 0.8f, 60, static_cast<unsigned>(std::atoi(argv[5])) };      // coloc_node.cpp:83-85
+    FeatureDetector<bool, coloc::HIPDetector> detector(dopts);
+    FeatureMatcher<bool, coloc::HIPMatcher> matcher(mopts);
+
+    coloc::colocData data;
+    for (int c = 0; c < ncams; ++c) {
+        std::string name = dir + "/img" + std::to_string(c) + ".pgm";
+        if (detector.detectFeaturesFile(c, data.regions, name) != EXIT_SUCCESS) { std::fprintf(stderr, "detect failed\n"); return 1; }
+        dump(dir + "/kps" + std::to_string(c) + ".bin", detector.kps.data(), detector.kps.size() * sizeof(Keypoint));
+        dump(dir + "/desc" + std::to_string(c) + ".bin", data.regions[c]->DescriptorRawData(), data.regions[c]->RegionCount() * 64);
+        dump(dir + "/feat" + std::to_string(c) + ".bin", data.regions[c]->Features().data(), data.regions[c]->RegionCount() * 16);
+    }
+    // bad file -> EXIT_FAILURE (true), nothing inserted
+    {
+        std::string bad = dir + "/does_not_exist.pgm";
+        coloc::FeatureMap tmp;
+        if (detector.detectFeaturesFile(0, tmp, bad) != EXIT_FAILURE || !tmp.empty()) { std::fprintf(stderr, "bad-file convention broken\n"); return 1; }
+    }
+    // initMap: all pairs (coloc.hpp:162)
+    PairWiseMatches putative;
+    if (matcher.computeMatches(data.regions, putative) != EXIT_SUCCESS) return 1;
+    for (const auto& kv : putative)
+        dump_matches(dir + "/pair_" + std::to_string(kv.first.first) + "_" + std::to_string(kv.first.second) + ".bin", kv.second);
+    // interPoseEstimator: one pair (coloc.hpp:287)
+    IndMatches one;
+    matcher.computeMatchesPair({ 0, 1 }, data.regions, one);
+    dump_matches(dir + "/single_0_1.bin", one);
+    // map tracking (coloc.hpp:196-198, 219): map = camera 0's regions, query = camera 1
+    data.mapRegions.reset(new features::AKAZE_Binary_Regions(*data.regions[0]));
+    matcher.setMapData(static_cast<int>(data.mapRegions->RegionCount()), const_cast<void*>(data.mapRegions->DescriptorRawData()));
+    int drone = 1;
+    IndMatches mapMatches;
+    matcher.matchSceneWithMap(drone, data, mapMatches);
+    dump_matches(dir + "/map_1.bin", mapMatches);
+    // map <-> map (coloc.hpp:323), thr 60
+    IndMatches common;
+    matcher.matchMapFeatures(data.regions[0], data.regions[1], common);
+    dump_matches(dir + "/mapmap_0_1.bin", common);
+    std::printf("ok %d cams, %zu pairs with matches\n", ncams, putative.size());
+    return 0;
+}
