@@ -201,6 +201,22 @@ def main():
             "roofline": roof,
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
         }
+        # p50 pose-solve (BASELINE metric, config[2] sizes): whole robust solve on host buffers --
+        # 256 P3P samples -> <= 1024 hypotheses scored over N matches -> best pose + inlier mask
+        pose = {}
+        for n_pts in (200, 1000, 5000):
+            sc = synth.pnp_scene(n_pts, seed=4000 + n_pts)
+            ts = []
+            for it in range(60 if n_pts != 1000 else 200):
+                t1 = time.perf_counter()
+                Rt, mask, _ = ctx.pnp_ransac(sc["X"], sc["x"], sc["K"], n_samples=256, seed=it + 1, thr2=16.0)
+                ts.append((time.perf_counter() - t1) * 1e3)
+            ts = np.sort(np.array(ts[5:]))
+            pose["N%d" % n_pts] = {"p50_ms": float(ts[len(ts) // 2]), "p95_ms": float(ts[int(len(ts) * 0.95)]),
+                                   "solves": int(len(ts)), "inliers": int(mask.sum())}
+        out["pose_solve"] = {"what": "clc_pnp_ransac: 256 P3P samples, <=1024 hypotheses x N matches, thr 4 px, host buffers in/out",
+                             **pose}
+        out["pose_solve_p50_ms"] = pose["N1000"]["p50_ms"]
         if not args.no_cpu_baseline and world == 1:
             dq = arena[0].cpu().numpy()
             dt_ = arena[1].cpu().numpy()

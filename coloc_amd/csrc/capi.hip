@@ -757,4 +757,75 @@ int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, co
     return CLC_OK;
 }
 
+static void draw_samples(uint64_t seed, int S, int N, std::vector<int32_t>& out)
+{
+    out.resize((size_t)3 * S);
+    uint64_t st = seed ? seed : 0x9E3779B97F4A7C15ull;
+    auto next = [&]() { st ^= st >> 12; st ^= st << 25; st ^= st >> 27; return st * 0x2545F4914F6CDD1Dull; };   // xorshift64*
+    for (int s = 0; s < S; ++s) {
+        int32_t a = (int32_t)(next() % (uint64_t)N), b, c;
+        do { b = (int32_t)(next() % (uint64_t)N); } while (N > 1 && b == a);
+        do { c = (int32_t)(next() % (uint64_t)N); } while (N > 2 && (c == a || c == b));
+        out[3 * s] = a; out[3 * s + 1] = b; out[3 * s + 2] = c;
+    }
+}
+
+static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
+                           const int32_t* h_samples, int S, uint64_t seed, double thr2, double* h_Rt, uint8_t* h_mask,
+                           int* n_inliers, double* cost, double* h_all_Rt)
+{
+    if (!ctx || N < 0 || S < 0 || !h_K || (N > 0 && (!h_X || !h_x))) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_ransac: bad argument");
+    if (n_inliers) *n_inliers = 0;
+    if (N < 3 || S == 0) return CLC_OK;
+    if (S > 16384) return fail(ctx, CLC_ERR_CAPACITY, "pnp_ransac: more than 16384 samples per call");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> drawn;
+    if (!h_samples) { draw_samples(seed, S, N, drawn); h_samples = drawn.data(); }
+    // workspace (doubles): X 3N | x 2N | K 16 | Rt 48S | cost 4S | Rt_best 12 | then int32: count 4S, best 2, samples 3S | mask N bytes
+    const size_t nd = (size_t)5 * N + 16 + (size_t)48 * S + (size_t)4 * S + 12;
+    const size_t ni = (size_t)4 * S + 2 + (size_t)3 * S;
+    const size_t need = nd + (ni + 1) / 2 + ((size_t)N + 7) / 8 + 8;
+    const int rc = ensure_pnp(ctx, need);
+    if (rc != CLC_OK) return rc;
+    double* dX = ctx->d_pnp;
+    double* dx = dX + (size_t)3 * N;
+    double* dK = dx + (size_t)2 * N;
+    double* dRt = dK + 16;
+    double* dCost = dRt + (size_t)48 * S;
+    double* dBestRt = dCost + (size_t)4 * S;
+    int32_t* dCount = (int32_t*)(dBestRt + 12);
+    int32_t* dBest = dCount + (size_t)4 * S;
+    int32_t* dSamples = dBest + 2;
+    uint8_t* dMask = (uint8_t*)(ctx->d_pnp + nd + (ni + 1) / 2);
+    CLC_HIP(ctx, hipMemcpyAsync(dX, h_X, sizeof(double) * 3 * N, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, hipMemcpyAsync(dx, h_x, sizeof(double) * 2 * N, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, hipMemcpyAsync(dK, h_K, sizeof(double) * 9, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, hipMemcpyAsync(dSamples, h_samples, sizeof(int32_t) * 3 * S, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_pnp_ransac(dX, dx, N, dK, dSamples, S, thr2, dRt, dCount, dCost, dBest, dMask, dBestRt, ctx->stream, &ctx->prof));
+    int32_t best[2] = { -1, 0 };
+    CLC_HIP(ctx, hipMemcpyAsync(best, dBest, sizeof best, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_Rt) CLC_HIP(ctx, hipMemcpyAsync(h_Rt, dBestRt, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_mask) CLC_HIP(ctx, hipMemcpyAsync(h_mask, dMask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_all_Rt) CLC_HIP(ctx, hipMemcpyAsync(h_all_Rt, dRt, sizeof(double) * 48 * S, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_inliers) *n_inliers = best[0] >= 0 ? best[1] : 0;
+    if (cost && best[0] >= 0) {
+        CLC_HIP(ctx, hipMemcpy(cost, dCost + best[0], sizeof(double), hipMemcpyDeviceToHost));
+    }
+    return CLC_OK;
+}
+
+int clc_pnp_ransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const int32_t* h_samples,
+                   int S, uint64_t seed, double thr2, double* h_Rt, uint8_t* h_inlier_mask, int* n_inliers, double* cost)
+{
+    return pnp_ransac_impl(ctx, h_X, h_x, N, h_K, h_samples, S, seed, thr2, h_Rt, h_inlier_mask, n_inliers, cost, nullptr);
+}
+
+int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const int32_t* h_samples, int S,
+                double* h_Rt_out)
+{
+    if (!h_samples || !h_Rt_out) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_p3p: bad argument");
+    return pnp_ransac_impl(ctx, h_X, h_x, N, h_K, h_samples, S, 0, 1.0, nullptr, nullptr, nullptr, nullptr, h_Rt_out);
+}
+
 } // extern "C"

@@ -86,5 +86,10 @@ hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const 
                             const double* d_K, double thr2, int32_t* d_count, double* d_cost,
                             hipStream_t stream, Profiler* prof = nullptr);
 
+// P3P hypotheses for S minimal samples (4 slots each) -> score -> select -> inlier mask of the winner
+hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
+                             int S, double thr2, double* d_Rt, int32_t* d_count, double* d_cost, int32_t* d_best,
+                             uint8_t* d_mask, double* d_Rt_best, hipStream_t stream, Profiler* prof = nullptr);
+
 } // namespace clc
 #endif

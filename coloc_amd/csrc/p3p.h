@@ -1,0 +1,196 @@
+// p3p.h -- minimal perspective-three-point solver, one problem per lane (host + device inline).
+//
+// Role: hypothesis generator for the batched PnP RANSAC (clc_pnp_ransac).  The reference asks
+// OpenMVG for resection::SolverType::P3P_KE_CVPR17 inside AC-RANSAC (include/coloc/Localizer.hpp:93);
+// OpenMVG is an empty, unpinned submodule in the reference snapshot, so no line of that solver is
+// available to follow.  Any exact minimal solver yields the same pose set; this one is the classic
+// distance formulation (Grunert 1841 / Haralick et al. 1994) derived from scratch:
+//   unknown depths s1, s2 = u s1, s3 = v s1 along the unit bearings f1, f2, f3;
+//   law of cosines on the three point pairs; eliminating s1 and u leaves a quartic in v whose
+//   coefficients are BUILT BY POLYNOMIAL ARITHMETIC (no closed-form coefficient table to mistype):
+//       q = (a^2 - c^2) / b^2,   N(v) = (q-1) v^2 - 2 q cos(beta) v + q + 1,   D(v) = 2 (cos(gamma) - v cos(alpha)),
+//       W(v) = 1 + v^2 - 2 v cos(beta),     u = N / D,
+//       b^2 (D^2 + N^2 - 2 cos(gamma) N D) - c^2 D^2 W = 0.
+//   The quartic is solved in closed form (Ferrari, trigonometric / Cardano resolvent) and each real
+//   root is polished with Newton steps on the original polynomial; the rigid transform follows from
+//   the two orthonormal triads spanned by the three points in the world and in the camera frame.
+// fp64 throughout.
+#ifndef CLC_P3P_H
+#define CLC_P3P_H
+
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define P3P_HD __host__ __device__ inline
+#else
+#define P3P_HD static inline
+#endif
+
+// real roots of x^3 + a x^2 + b x + c: returns count (1 or 3)
+P3P_HD int p3p_solve_cubic(double a, double b, double c, double* x)
+{
+    const double a3 = a / 3.0;
+    const double p = b - a * a3;
+    const double q = 2.0 * a3 * a3 * a3 - a3 * b + c;
+    const double disc = 0.25 * q * q + p * p * p / 27.0;
+    if (disc > 0.0) {
+        const double s = sqrt(disc);
+        const double u = cbrt(-0.5 * q + s), v = cbrt(-0.5 * q - s);
+        x[0] = u + v - a3;
+        return 1;
+    }
+    const double r = sqrt(-p * p * p / 27.0);
+    double cosphi = r > 0.0 ? -0.5 * q / r : 0.0;
+    cosphi = cosphi > 1.0 ? 1.0 : (cosphi < -1.0 ? -1.0 : cosphi);
+    const double phi = acos(cosphi);
+    const double m = 2.0 * sqrt(-p / 3.0);
+    x[0] = m * cos(phi / 3.0) - a3;
+    x[1] = m * cos((phi + 2.0 * M_PI) / 3.0) - a3;
+    x[2] = m * cos((phi + 4.0 * M_PI) / 3.0) - a3;
+    return 3;
+}
+
+// real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (c4 != 0); returns count (0..4)
+P3P_HD int p3p_solve_quartic(const double* co, double* roots)
+{
+    const double a = co[3] / co[4], b = co[2] / co[4], c = co[1] / co[4], d = co[0] / co[4];
+    // depressed quartic y^4 + p y^2 + q y + r, x = y - a/4
+    const double a2 = a * a;
+    const double p = b - 0.375 * a2;
+    const double q = c - 0.5 * a * b + 0.125 * a2 * a;
+    const double r = d - 0.25 * a * c + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
+    int n = 0;
+    double y[4];
+    if (fabs(q) < 1e-14 * (1.0 + fabs(p) + fabs(r))) {
+        // biquadratic
+        const double disc = p * p - 4.0 * r;
+        if (disc >= 0.0) {
+            const double s = sqrt(disc);
+            const double z0 = 0.5 * (-p + s), z1 = 0.5 * (-p - s);
+            if (z0 >= 0.0) { y[n++] = sqrt(z0); y[n++] = -sqrt(z0); }
+            if (z1 >= 0.0) { y[n++] = sqrt(z1); y[n++] = -sqrt(z1); }
+        }
+    } else {
+        // resolvent: m^3 + p m^2 + (p^2/4 - r) m - q^2/8 = 0, take the largest real root (it is > 0)
+        double m3[3];
+        const int nm = p3p_solve_cubic(p, 0.25 * p * p - r, -0.125 * q * q, m3);
+        double m = m3[0];
+        for (int i = 1; i < nm; ++i) m = m3[i] > m ? m3[i] : m;
+        if (m > 0.0) {
+            const double s = sqrt(2.0 * m);
+            const double t0 = 0.5 * p + m;
+            const double t1 = q / (2.0 * s);
+            // y^2 + s y + (t0 - t1) = 0  and  y^2 - s y + (t0 + t1) = 0
+            double disc = s * s - 4.0 * (t0 - t1);
+            if (disc >= 0.0) { const double sq = sqrt(disc); y[n++] = 0.5 * (-s + sq); y[n++] = 0.5 * (-s - sq); }
+            disc = s * s - 4.0 * (t0 + t1);
+            if (disc >= 0.0) { const double sq = sqrt(disc); y[n++] = 0.5 * (s + sq); y[n++] = 0.5 * (s - sq); }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        double x = y[i] - 0.25 * a;
+        for (int it = 0; it < 3; ++it) {   // Newton polish on the original polynomial
+            const double f = (((co[4] * x + co[3]) * x + co[2]) * x + co[1]) * x + co[0];
+            const double df = ((4.0 * co[4] * x + 3.0 * co[3]) * x + 2.0 * co[2]) * x + co[1];
+            if (df == 0.0) break;
+            x -= f / df;
+        }
+        roots[i] = x;
+    }
+    return n;
+}
+
+P3P_HD void p3p_cross(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+P3P_HD double p3p_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+P3P_HD bool p3p_normalize(double* a)
+{
+    const double n = sqrt(p3p_dot(a, a));
+    if (!(n > 1e-300)) return false;
+    a[0] /= n; a[1] /= n; a[2] /= n;
+    return true;
+}
+// orthonormal triad (columns e1,e2,e3) of three points
+P3P_HD bool p3p_triad(const double* A, const double* B, const double* C, double E[3][3])
+{
+    double e1[3] = { B[0] - A[0], B[1] - A[1], B[2] - A[2] };
+    double w[3] = { C[0] - A[0], C[1] - A[1], C[2] - A[2] };
+    double e3[3], e2[3];
+    if (!p3p_normalize(e1)) return false;
+    p3p_cross(e1, w, e3);
+    if (!p3p_normalize(e3)) return false;
+    p3p_cross(e3, e1, e2);
+    for (int i = 0; i < 3; ++i) { E[i][0] = e1[i]; E[i][1] = e2[i]; E[i][2] = e3[i]; }
+    return true;
+}
+
+// X: three world points (3x3 row-major, one point per row); f: three UNIT bearing vectors.
+// Rt_out: up to 4 poses, 12 doubles each, row-major [R|t] with x_cam = R X + t.  Returns the count.
+P3P_HD int p3p_solve(const double X[3][3], const double f[3][3], double* Rt_out)
+{
+    double d12[3], d13[3], d23[3];
+    for (int i = 0; i < 3; ++i) { d12[i] = X[0][i] - X[1][i]; d13[i] = X[0][i] - X[2][i]; d23[i] = X[1][i] - X[2][i]; }
+    const double c2 = p3p_dot(d12, d12), b2 = p3p_dot(d13, d13), a2 = p3p_dot(d23, d23);
+    if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return 0;
+    const double ca = p3p_dot(f[1], f[2]), cb = p3p_dot(f[0], f[2]), cg = p3p_dot(f[0], f[1]);
+    const double q = (a2 - c2) / b2;
+    // polynomials in v, ascending coefficients
+    const double N[3] = { q + 1.0, -2.0 * q * cb, q - 1.0 };
+    const double D[2] = { 2.0 * cg, -2.0 * ca };
+    const double W[3] = { 1.0, -2.0 * cb, 1.0 };
+    double DD[3] = { D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1] };
+    double NN[5] = { 0, 0, 0, 0, 0 }, ND[4] = { 0, 0, 0, 0 }, DDW[5] = { 0, 0, 0, 0, 0 };
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) NN[i + j] += N[i] * N[j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) ND[i + j] += N[i] * D[j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) DDW[i + j] += DD[i] * W[j];
+    double co[5];
+    for (int k = 0; k < 5; ++k) {
+        const double dd = k < 3 ? DD[k] : 0.0, nd = k < 4 ? ND[k] : 0.0;
+        co[k] = b2 * (dd + NN[k] - 2.0 * cg * nd) - c2 * DDW[k];
+    }
+    double roots[4];
+    int nr = 0;
+    const double scale = fabs(co[0]) + fabs(co[1]) + fabs(co[2]) + fabs(co[3]) + fabs(co[4]);
+    if (!(scale > 0.0)) return 0;
+    if (fabs(co[4]) > 1e-12 * scale) {
+        nr = p3p_solve_quartic(co, roots);
+    } else if (fabs(co[3]) > 1e-12 * scale) {
+        nr = p3p_solve_cubic(co[2] / co[3], co[1] / co[3], co[0] / co[3], roots);
+    } else {
+        return 0;
+    }
+    double E[3][3];
+    if (!p3p_triad(X[0], X[1], X[2], E)) return 0;
+    int ns = 0;
+    for (int k = 0; k < nr && ns < 4; ++k) {
+        const double v = roots[k];
+        if (!(v > 0.0)) continue;
+        const double den = D[0] + D[1] * v;
+        if (fabs(den) < 1e-12) continue;
+        const double u = (N[0] + (N[1] + N[2] * v) * v) / den;
+        if (!(u > 0.0)) continue;
+        const double w = W[0] + (W[1] + W[2] * v) * v;
+        if (!(w > 0.0)) continue;
+        const double s1 = sqrt(b2 / w), s2 = u * s1, s3 = v * s1;
+        const double Q0[3] = { s1 * f[0][0], s1 * f[0][1], s1 * f[0][2] };
+        const double Q1[3] = { s2 * f[1][0], s2 * f[1][1], s2 * f[1][2] };
+        const double Q2[3] = { s3 * f[2][0], s3 * f[2][1], s3 * f[2][2] };
+        double G[3][3];
+        if (!p3p_triad(Q0, Q1, Q2, G)) continue;
+        double* P = Rt_out + 12 * ns;
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) P[4 * i + j] = G[i][0] * E[j][0] + G[i][1] * E[j][1] + G[i][2] * E[j][2];   // R = G E^T
+        }
+        for (int i = 0; i < 3; ++i) P[4 * i + 3] = Q0[i] - (P[4 * i] * X[0][0] + P[4 * i + 1] * X[0][1] + P[4 * i + 2] * X[0][2]);
+        bool finite = true;
+        for (int i = 0; i < 12; ++i) finite = finite && (P[i] == P[i]) && fabs(P[i]) < 1e300;
+        if (finite) ++ns;
+    }
+    return ns;
+}
+
+#endif

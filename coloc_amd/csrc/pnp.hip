@@ -15,6 +15,7 @@
 // fused score kernel reduces in a different order than a sequential sum, hence the 1e-12
 // relative tolerance on `cost` in the tests.
 #include "clc_internal.h"
+#include "p3p.h"
 
 namespace clc {
 
@@ -75,6 +76,92 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const double* __restrict
         if (count) count[h] = s_cnt[0];
         if (cost) cost[h] = s_cost[0];
     }
+}
+
+// ---- batched minimal solver: one P3P problem per lane -------------------------------------------
+// samples: S x 3 point indices.  Writes 4 pose slots per sample (H = 4 S); unused slots are NaN so
+// that they score worst (every comparison with NaN is false: 0 inliers, cost = N * thr2).
+__global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, const double* __restrict__ x,
+                                                 const double* __restrict__ K, const int32_t* __restrict__ samples,
+                                                 const int S, const int N, double* __restrict__ Rt)
+{
+    const int sidx = blockIdx.x * 64 + threadIdx.x;
+    if (sidx >= S) return;
+    double Xs[3][3], f[3][3];
+    bool ok = true;
+    const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        int i = samples[3 * sidx + p];
+        if (i < 0 || i >= N) { ok = false; i = 0; }
+        Xs[p][0] = X[3 * i]; Xs[p][1] = X[3 * i + 1]; Xs[p][2] = X[3 * i + 2];
+        const double yn = (x[2 * i + 1] - cy) / fy;
+        const double xn = (x[2 * i] - cx - sk * yn) / fx;
+        const double nrm = sqrt(xn * xn + yn * yn + 1.0);
+        f[p][0] = xn / nrm; f[p][1] = yn / nrm; f[p][2] = 1.0 / nrm;
+    }
+    double sol[48];
+    const int n = ok ? p3p_solve(Xs, f, sol) : 0;
+    double* out = Rt + (size_t)48 * sidx;
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int k = 0; k < 4; ++k)
+        for (int e = 0; e < 12; ++e) out[12 * k + e] = k < n ? sol[12 * k + e] : qnan;
+}
+
+// best hypothesis: most inliers, then lowest cost, then lowest index; then its inlier mask
+__global__ __launch_bounds__(256) void pnp_select_kernel(const int32_t* __restrict__ count, const double* __restrict__ cost,
+                                                         const int H, int32_t* __restrict__ best /* [0]=h, [1]=count */)
+{
+    __shared__ int s_h[256];
+    int bh = -1;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        if (bh < 0 || count[h] > count[bh] || (count[h] == count[bh] && cost[h] < cost[bh])) bh = h;
+    }
+    s_h[threadIdx.x] = bh;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const int a = s_h[threadIdx.x], b = s_h[threadIdx.x + st];
+            int w = a;
+            if (a < 0) w = b;
+            else if (b >= 0) {
+                if (count[b] > count[a] || (count[b] == count[a] && (cost[b] < cost[a] || (cost[b] == cost[a] && b < a)))) w = b;
+            }
+            s_h[threadIdx.x] = w;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { best[0] = s_h[0]; best[1] = s_h[0] >= 0 ? count[s_h[0]] : 0; }
+}
+
+__global__ __launch_bounds__(256) void pnp_mask_kernel(const double* __restrict__ Rt, const int32_t* __restrict__ best,
+                                                       const double* __restrict__ X, const double* __restrict__ x, const int N,
+                                                       const double* __restrict__ K, const double thr2,
+                                                       uint8_t* __restrict__ mask, double* __restrict__ Rt_best)
+{
+    const int h = best[0];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (h < 0) { if (i < N) mask[i] = 0; return; }
+    const double* P = Rt + (size_t)12 * h;
+    if (blockIdx.x == 0 && threadIdx.x < 12) Rt_best[threadIdx.x] = P[threadIdx.x];
+    if (i >= N) return;
+    const double e = reproj_err(P, K, X[3 * i], X[3 * i + 1], X[3 * i + 2], x[2 * i], x[2 * i + 1]);
+    mask[i] = e < thr2 ? 1 : 0;
+}
+
+hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
+                             int S, double thr2, double* d_Rt /* 48*S */, int32_t* d_count, double* d_cost,
+                             int32_t* d_best, uint8_t* d_mask, double* d_Rt_best, hipStream_t stream, Profiler* prof)
+{
+    if (S <= 0 || N <= 0) return hipSuccess;
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
+    hipLaunchKernelGGL(p3p_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt);
+    hipLaunchKernelGGL(pnp_score_kernel, dim3(4 * S), dim3(256), 0, stream, (const double*)d_Rt, d_X, d_x, N, d_K, thr2, d_count, d_cost);
+    hipLaunchKernelGGL(pnp_select_kernel, dim3(1), dim3(256), 0, stream, (const int32_t*)d_count, (const double*)d_cost, 4 * S, d_best);
+    hipLaunchKernelGGL(pnp_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_Rt, (const int32_t*)d_best,
+                       d_X, d_x, N, d_K, thr2, d_mask, d_Rt_best);
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
+    return hipGetLastError();
 }
 
 hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,

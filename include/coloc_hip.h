@@ -208,6 +208,20 @@ int clc_pnp_residuals(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X
 int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, const double* h_x,
                   int N, const double* h_K, double thr2, int32_t* h_count, double* h_cost);
 
+/* Whole robust pose solve on the GPU -- the role of SfM_Localizer::Localize(P3P, max_iteration = 256)
+ * at Localizer.hpp:82-93: S minimal samples -> one P3P problem per lane (<= 4 poses each) -> all
+ * 4 S hypotheses scored over all N correspondences in one launch -> best = most inliers (err < thr2),
+ * then lowest truncated cost, then lowest index -> its inlier mask.  h_samples: S x 3 point indices
+ * (NULL = drawn from a xorshift64* stream seeded with `seed`; OpenMVG draws from std::mt19937 and
+ * scores a contrario -- unpinned).  Outputs: h_Rt 12 doubles row-major [R|t],
+ * h_inlier_mask N bytes (nullable), *n_inliers, *cost (nullable).  *n_inliers == 0 means no pose. */
+int clc_pnp_ransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
+                   const int32_t* h_samples, int S, uint64_t seed, double thr2, double* h_Rt,
+                   uint8_t* h_inlier_mask, int* n_inliers, double* cost);
+/* The hypotheses of the minimal solver alone: h_Rt_out receives 4 S x 12 doubles (NaN = no solution). */
+int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
+                const int32_t* h_samples, int S, double* h_Rt_out);
+
 #ifdef __cplusplus
 }
 #endif
