@@ -87,6 +87,7 @@ def main():
     n_cams = 2 if world == 1 else world
     counts = [NKP] * n_cams
     arena = torch.zeros((n_cams, NKP, 64), dtype=torch.uint8, device=dev)
+    mine = torch.zeros((NKP, 64), dtype=torch.uint8, device=dev)      # this rank's block (all-gather input)
     jobs = multicam.shard_pairs(counts, world, rank)
     abi_jobs = multicam.jobs_to_abi(jobs, counts, NKP, THR)
     n_out = sum(j.nq for j in jobs)
@@ -97,9 +98,9 @@ def main():
     def step():
         for k, c in enumerate(cams):
             ctx.pyramid_build_dev(imgs[k].data_ptr(), W, H, W, sptr)
-            ctx.describe_dev(kps[k].data_ptr(), NKP, arena[c].data_ptr(), sptr)
+            ctx.describe_dev(kps[k].data_ptr(), NKP, (arena[c] if world == 1 else mine).data_ptr(), sptr)
         if world > 1:
-            dist.all_gather_into_tensor(arena.view(-1), arena[rank].reshape(-1))
+            dist.all_gather_into_tensor(arena.view(-1), mine.view(-1))   # RCCL over xGMI, 640 KB per rank
         if abi_jobs:
             ctx.match_jobs_dev(arena.data_ptr(), abi_jobs, d_match.data_ptr(), sptr)
 

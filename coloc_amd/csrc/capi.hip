@@ -103,6 +103,7 @@ struct clc_ctx {
     uint16_t* d_second = nullptr;
     uint2* d_partial = nullptr;
     size_t partial_cap = 0;
+    bool partial_dirty = false;      // armed (all-ones) state of the atomic top-2 rows was lost
     int target_blocks = 4096;
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
@@ -167,6 +168,8 @@ int ensure_partial(clc_ctx* ctx, size_t elems)
     ctx->partial_cap = 0;
     size_t cap = elems + elems / 4;
     CLC_HIP(ctx, hipMalloc((void**)&ctx->d_partial, cap * sizeof(uint2)));
+    CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, cap * sizeof(uint2), ctx->stream));   // armed top-2 rows
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->partial_cap = cap;
     return CLC_OK;
 }
@@ -188,7 +191,13 @@ int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
     const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), ctx->target_blocks);
     const int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;
-    CLC_HIP(ctx, launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, &ctx->prof));
+    if (!plan.atomic_merge) ctx->partial_dirty = true;           // slab mode scribbles over the armed rows
+    else if (ctx->partial_dirty) {
+        CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
+        ctx->partial_dirty = false;
+    }
+    const hipError_t e = launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, &ctx->prof);
+    if (e != hipSuccess) { ctx->partial_dirty = true; return fail(ctx, CLC_ERR_HIP, "launch_k2nn", e); }
     return CLC_OK;
 }
 
@@ -272,6 +281,7 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         const size_t cap = dopts || mopts ? (size_t)(mopts ? mopts->maxkp : dopts->maxkp) : 16384;
         const size_t elems = ((cap + 63) & ~(size_t)63) * 128 + 4096;
         CREATE_HIP(hipMalloc((void**)&ctx->d_partial, elems * sizeof(uint2)));
+        CREATE_HIP(hipMemsetAsync(ctx->d_partial, 0xFF, elems * sizeof(uint2), ctx->stream));   // armed top-2 rows
         ctx->partial_cap = elems;
     }
     CREATE_HIP(hipStreamSynchronize(ctx->stream));

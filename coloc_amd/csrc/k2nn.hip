@@ -10,19 +10,22 @@
 //     distance needs NO cross-lane traffic at all.
 //   * the train vector is wave-uniform: it is fetched with ONE scalar load (s_load_dwordx16, 64 B)
 //     into SGPRs and used directly as the scalar operand of v_xor_b32 -- no LDS, no VGPRs, no
-//     vector-memory instructions in the inner loop.  Per (query, train) pair the VALU executes
+//     vector-memory instructions in the inner loop; the load of vector t+1 is issued before the
+//     VALU work on vector t (explicit double buffer in SGPRs).  Per (query, train) pair the VALU executes
 //     16 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate) = 32 lane-ops.
 //   * top-2 without branches or an index register: key = (distance << 22) | train_index_in_split.
 //     Unsigned order on keys is (distance, index) lexicographic, so best' = min(best, key) keeps
 //     the lowest index among equal distances, and second' = med3(best, second, key) is the second
 //     smallest key = the second smallest distance of the multiset.  3 more lane-ops per pair.
 //   * 2-D decomposition: (query block) x (train split) so that 10k x 10k fills 256 CUs x 8
-//     waves/SIMD; every (split, query) writes an 8-byte partial {best_key, second_key} and a tiny
-//     second kernel folds the splits left-to-right with the exact merge rule of SURVEY.md 8(a)
-//     note N1 (A = lower train indices), applies the threshold and writes the int32 result.
+//     waves/SIMD.  Splits are folded into one {best_key, second_key} row per query with two
+//     atomicMin (keys carry the global train index, so the fold is order-free and exact -- the
+//     merge rule of SURVEY.md 8(a) note N1 with "lowest index wins" built into the key order); a
+//     tiny finalize kernel applies the threshold, writes the int32 result and re-arms the row.
+//     Train sets beyond 2^22 vectors fall back to per-split slabs + an ordered merge kernel.
 //
 // Bound: integer VALU (32 of the 35 lane-ops per pair are the algorithmic xor+popcount); HBM
-// traffic is the compulsory 64*(nq+nt) B plus 16*splits*nq B of partials.
+// traffic is the compulsory 64*(nq+nt) B plus 8 B of atomics per (query, split).
 #include "clc_internal.h"
 
 namespace clc {
@@ -118,18 +121,72 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
     const uint32_t t0 = split * job.t_per_split;
     uint32_t t1 = t0 + job.t_per_split;
     if (t1 > job.nt) t1 = job.nt;
+    // Software-pipelined scalar loads: wait for the CURRENT train vector, immediately issue the
+    // s_load_dwordx16 of the NEXT one, then run the 70 VALU ops of the current one while it is in
+    // flight.  (Left to itself the compiler issues the load and waits for it at the loop top; the
+    // explicit order is worth ~11 % at 8 waves/SIMD.)  The prefetch never reads past the split.
     const_u4_ptr tp = (const_u4_ptr)(uintptr_t)job.t + (size_t)t0 * 4u;   // wave-uniform -> s_load_dwordx16
-    for (uint32_t t = t0; t < t1; ++t, tp += 4) {
-        const u32x4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        sweep_one<R>(q, a, b, c, d, t - t0, best, second);
+    if (t0 < t1) {
+        u32x4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
+        for (uint32_t t = t0; t < t1; ++t) {
+            tp += 4;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the current vector has landed
+            __builtin_amdgcn_sched_barrier(0);
+            const_u4_ptr np = (t + 1 < t1) ? tp : tp - 4;
+            const u32x4 na = np[0], nb = np[1], nc = np[2], nd = np[3];
+            __builtin_amdgcn_sched_barrier(0);
+            sweep_one<R>(q, a, b, c, d, t - t0, best, second);
+            __builtin_amdgcn_sched_barrier(0);
+            a = na; b = nb; c = nc; d = nd;
+        }
     }
 
+    if (job.atomic_merge) {
+        // Fold this split into the query's global top-2 with two 32-bit atomicMin.  Keys carry the
+        // GLOBAL train index here (t0 + index in split < 2^22), so unsigned order on keys is the total
+        // order (distance, index) and the fold is commutative: whichever value leaves the `best` slot
+        // (because a smaller key arrived) is offered to `second` by the arrival that displaced it.
+        unsigned int* top = reinterpret_cast<unsigned int*>(partial + job.partial_off);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t qi = qbase + 64u * r;
+            if (qi < job.nq && best[r] != kEmpty) {
+                const uint32_t bkey = best[r] + t0;
+                const uint32_t skey = second[r] == kEmpty ? kEmpty : second[r] + t0;
+                const uint32_t old = atomicMin(top + 2u * qi, bkey);
+                const uint32_t cand = bkey < old ? min(old, skey) : bkey;
+                if (cand != kEmpty) atomicMin(top + 2u * qi + 1u, cand);
+            }
+        }
+        return;
+    }
     const global_u2_ptr prow = (global_u2_ptr)(uintptr_t)partial + job.partial_off + (size_t)split * job.nq_pad;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t qi = qbase + 64u * r;
         if (qi < job.nq) prow[qi] = u32x2{ best[r], second[r] };
     }
+}
+
+// Atomic mode: one thread per query turns the folded {best_key, second_key} into the result and
+// re-arms the row (all ones) for the next call.
+__global__ __launch_bounds__(256) void k2nn_finalize_kernel(const K2nnJobList jobs, uint2* __restrict__ top2)
+{
+    const K2nnJobDev& job = jobs.j[blockIdx.y];
+    const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
+    if (qi >= job.nq) return;
+    uint2* row = top2 + job.partial_off + qi;
+    const uint2 e = *row;
+    *row = make_uint2(kEmpty, kEmpty);
+    int best_v = 100000, second_v = 200000, best_i = -1;      // CUDAK2NN.cu:54 sentinels
+    if (e.x != kEmpty) {
+        best_v = (int)(e.x >> kKeyShift);
+        best_i = (int)(e.x & kIdxMask);
+        second_v = e.y == kEmpty ? 100000 : (int)(e.y >> kKeyShift);
+    }
+    job.out[qi] = (best_i >= 0 && second_v - best_v > (int)job.thr) ? best_i : -1;
+    if (job.best_out) job.best_out[qi] = (uint16_t)min(best_v, 65535);
+    if (job.second_out) job.second_out[qi] = (uint16_t)min(second_v, 65535);
 }
 
 // Fold the per-split partials of one query and threshold.
@@ -206,7 +263,9 @@ __global__ __launch_bounds__(kMergeQ * kMergeGroups) void k2nn_merge_kernel(cons
 
 K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
 {
-    K2nnPlan plan{0};
+    K2nnPlan plan{0, true};
+    for (int j = 0; j < njobs; ++j)
+        if (jobs[j].nt > kIdxMask + 1u) plan.atomic_merge = false;
     uint32_t total_qblocks = 0;
     for (int j = 0; j < njobs; ++j) {
         jobs[j].qblocks = (jobs[j].nq + kQPerBlock - 1) / kQPerBlock;
@@ -228,7 +287,8 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
         jb.t_per_split = per;
         jb.nq_pad = (jb.nq + 63u) & ~63u;
         jb.partial_off = (uint32_t)off;
-        off += (size_t)splits * jb.nq_pad;
+        jb.atomic_merge = plan.atomic_merge ? 1u : 0u;
+        off += plan.atomic_merge ? (size_t)jb.nq_pad : (size_t)splits * jb.nq_pad;
     }
     plan.partial_elems = off;
     return plan;
@@ -254,8 +314,11 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, false, stream);
         }
         prof_mark(prof, CLC_KERNEL_K2NN_MERGE, true, stream);
-        hipLaunchKernelGGL(k2nn_merge_kernel, dim3((max_nq + kMergeQ - 1) / kMergeQ, cnt), dim3(kMergeQ * kMergeGroups),
-                           0, stream, list, (const uint2*)d_partial);
+        if (list.j[0].atomic_merge)
+            hipLaunchKernelGGL(k2nn_finalize_kernel, dim3((max_nq + 255) / 256, cnt), dim3(256), 0, stream, list, d_partial);
+        else
+            hipLaunchKernelGGL(k2nn_merge_kernel, dim3((max_nq + kMergeQ - 1) / kMergeQ, cnt), dim3(kMergeQ * kMergeGroups),
+                               0, stream, list, (const uint2*)d_partial);
         prof_mark(prof, CLC_KERNEL_K2NN_MERGE, false, stream);
     }
     return hipGetLastError();

@@ -1,0 +1,52 @@
+"""The per-rank compute of the one-camera-per-GPU path (coloc_amd/multicam.py job lists ->
+clc_match_jobs_dev over the gathered descriptor arena), executed for EVERY rank of a virtual world on
+the one GPU of the test box and reassembled: must equal the single-GPU all-pairs loop
+(GPUMatcher.hpp:143-155) and the oracle, bit for bit.  The collective itself is covered by the gloo
+test (tests/test_multicam.py); an N > 1 RCCL run is the driver's."""
+import numpy as np
+import pytest
+
+import synth
+from coloc_amd import multicam
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world,counts", [(1, [3000, 2500]), (2, [3000, 2500]), (4, [2000, 1500, 2500, 1800]),
+                                          (8, [1200] * 8), (3, [700, 0, 1300, 512, 513])])
+def test_every_ranks_jobs_reassemble_to_the_all_pairs_loop(oracle, world, counts):
+    import torch
+    from coloc_amd import Context
+    cap = max(max(counts), 1)
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    base = synth.random_descriptors(cap, seed=1)
+    descs = []
+    for c, n in enumerate(counts):
+        d = synth.random_descriptors(n, seed=3000 + c)
+        k = n // 2
+        d[:k] = base[:k]
+        d[:k, c % 64] ^= (np.arange(k) % 251).astype(np.uint8)      # near-duplicates across cameras
+        descs.append(d)
+    arena_h = np.zeros((len(counts), cap, 64), np.uint8)
+    for c, d in enumerate(descs):
+        arena_h[c, :len(d)] = d
+    arena = torch.from_numpy(arena_h).cuda()
+    st = torch.cuda.Stream()
+    results, world_jobs = [], []
+    for r in range(world):
+        jobs = multicam.shard_pairs(counts, world, r)
+        world_jobs.append(jobs)
+        out = torch.full((max(1, sum(j.nq for j in jobs)),), -9, dtype=torch.int32, device="cuda")
+        with torch.cuda.stream(st):
+            ctx.match_jobs_dev(arena.data_ptr(), multicam.jobs_to_abi(jobs, counts, cap, 40), out.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        results.append(out.cpu().numpy())
+    got = multicam.assemble_pairwise(results, world_jobs, counts)
+    pairs = [(i, j) for (i, j) in multicam.exhaustive_pairs(len(counts)) if counts[i] and counts[j]]
+    assert sorted(got) == pairs
+    loop = ctx.match_pairs(descs, pairs, 40)                     # the single-GPU loop through the host ABI
+    for p, m in zip(pairs, loop):
+        want = oracle.k2nn(descs[p[0]], descs[p[1]], 40)
+        assert np.array_equal(got[p], want) and np.array_equal(m, want)
+        assert (want >= 0).sum() > 50
+    ctx.close()
