@@ -53,11 +53,7 @@ static constexpr uint16_t k_slot_triplet[512] = LATCH_SLOT_TRIPLET;
 static constexpr uint16_t patch_lds_addr(int row, int col)
 {
     const int p = (row - kRow0) * kStride + (col - kCol0);
-#if CLATCH_NOCOPY
-    return (uint16_t)p;
-#else
     return (uint16_t)(kCopyBase[p & 3] + (p & ~3));
-#endif
 }
 struct SlotTable {
     uint16_t addr[512][4];   // per slot: LDS addresses of patches a, b, c (+ pad)
@@ -78,35 +74,13 @@ static constexpr SlotTable make_slot_table()
 }
 __device__ const SlotTable k_slots = make_slot_table();
 
-#if CLATCH_NOCOPY
-typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(1)));
-#else
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-#endif
 
-// Experiment switches for tools/clatch_microbench.hip (defaults are what ships).
-#ifndef CLATCH_ABLATE
-#define CLATCH_ABLATE 0      // 1: skip tests, 2: skip fill gather, 3: skip copies (timing only; wrong output)
-#endif
-#ifndef CLATCH_NOCOPY
-#define CLATCH_NOCOPY 0      // 1: no shifted copies, byte-unaligned 8-byte LDS reads (experiment)
-#endif
-#ifndef CLATCH_READ2
-#define CLATCH_READ2 0       // 1: two volatile dword reads (experiment), 0: compiler's 8-byte read at a dword-aligned address
-#endif
-
-// 8 bytes at a dword-aligned LDS address
+// 8 bytes at a dword-aligned LDS address (gfx950 executes a 4-byte-aligned ds_read_b64 at full rate; a
+// byte-misaligned one is legal but was measured 4.6x slower end to end, hence the shifted copies)
 __device__ __forceinline__ u32x2_a4 lds_read8(const uint8_t* p)
 {
-#if CLATCH_READ2
-    const volatile uint32_t* q = reinterpret_cast<const volatile uint32_t*>(p);   // volatile: not merged into a b64
-    u32x2_a4 r;
-    r.x = q[0];
-    r.y = q[1];
-    return r;
-#else
     return *reinterpret_cast<const u32x2_a4*>(p);
-#endif
 }
 
 struct ClatchArgs {
@@ -133,9 +107,6 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     if ((int)blockIdx.x >= n) return;
     __shared__ __attribute__((aligned(16))) uint8_t roi[kWaveLds];
     const uint32_t lane = threadIdx.x;
-#if CLATCH_ABLATE == 7     // launch + LDS allocation only
-    if (n > 0) { roi[lane] = 1; if (lane == 0) desc[blockIdx.x * 8] = roi[5]; return; }
-#endif
 
     // this lane's 8 slots (round j, lane) and, for the output, where bit 64*j + lane was computed
     uint32_t pa[8], pb[8], pc[8], src[8];
@@ -146,18 +117,6 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
         src[j] = k_slots.src[j * 64 + lane];
     }
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
-#if CLATCH_ABLATE == 6     // + table prologue
-    if (n > 0) { uint32_t x = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x ^= pa[j] ^ pb[j] ^ pc[j] ^ src[j];
-        desc[blockIdx.x * 8 + (lane & 7)] = x; return; }
-#endif
-#if CLATCH_ABLATE == 8     // + keypoint load and sincos
-    if (n > 0) { const clc_keypoint pt = kps[blockIdx.x]; float s, c; clc_sincosf(pt.angle, &s, &c); uint32_t x = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x ^= pa[j] ^ pb[j] ^ pc[j] ^ src[j];
-        desc[blockIdx.x * 8 + (lane & 7)] = x ^ __float_as_uint(s) ^ __float_as_uint(c); return; }
-#endif
 
     for (int kp = (int)blockIdx.x; kp < n; kp += (int)gridDim.x) {
         const clc_keypoint pt = kps[kp];                      // wave-uniform
@@ -169,9 +128,6 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
         const float fpx = (float)pt.x, fpy = (float)pt.y;
         const int wmax = (int)L.w - 1, hmax = (int)L.h - 1;
 
-#if CLATCH_ABLATE == 5
-        uint32_t bits_sink = 0;
-#endif
         // ---- window fill: tile (by, bx) covers rows 5+8*by.., cols 5+8*bx.. with an 8x8 lane tile
         float xc[kTiles], xs[kTiles], ys[kTiles], yc[kTiles];
 #pragma unroll
@@ -181,6 +137,8 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
             xc[b] = xo * c; xs[b] = xo * s;
             ys[b] = yo * s; yc[b] = yo * c;
         }
+        // (A clamp-free variant for keypoints >= 42 px inside the level was measured 17 % SLOWER -- the
+        // second copy of the unrolled fill costs more in instruction fetch than the two v_med3 save.)
 #pragma unroll
         for (int by = 0; by < kTiles; ++by) {
 #pragma unroll
@@ -190,22 +148,13 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
                 const int sx = clamp_i32((int)fx, wmax);
                 const int sy = clamp_i32((int)fy, hmax);
                 const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
-#if CLATCH_ABLATE == 2
-                roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = (uint8_t)off;
-#elif CLATCH_ABLATE == 4   // conflict-free dword writes instead of byte writes (timing only)
-                reinterpret_cast<uint32_t*>(roi)[(by * kTiles + bx) * 64 + lane] = img[off];
-#elif CLATCH_ABLATE == 5   // no LDS writes at all in the fill (timing only)
-                bits_sink ^= img[off];
-#else
                 roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = img[off];
-#endif
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         // ---- shifted copies 1..3: copy_k[i] = win[i + k]
-#if CLATCH_ABLATE != 3 && !CLATCH_NOCOPY
 #pragma unroll 2
         for (int i = (int)lane; i < kWinDwords; i += 64) {
             const u32x2_a4 d = *reinterpret_cast<const u32x2_a4*>(roi + 4 * i);
@@ -213,18 +162,11 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
             *reinterpret_cast<uint32_t*>(roi + kCopyBase[2] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 2);
             *reinterpret_cast<uint32_t*>(roi + kCopyBase[3] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
         }
-#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         // ---- 512 tests, 8 per lane
         uint32_t bits8 = 0;
-#if CLATCH_ABLATE == 5
-        bits8 = bits_sink & 1u;
-#endif
-#if CLATCH_ABLATE == 1
-        bits8 = *reinterpret_cast<const uint32_t*>(roi + pa[0]) ^ *reinterpret_cast<const uint32_t*>(roi + kCopyBase[3] + pb[1]);
-#else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             uint32_t aa = 0, cc = 0, ab = 0, cb = 0;
@@ -241,7 +183,6 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
             const int32_t S = ((int32_t)aa - (int32_t)cc) - 2 * ((int32_t)ab - (int32_t)cb);
             bits8 |= (S < 0 ? 1u : 0u) << j;
         }
-#endif
         // ---- back to descriptor order: output round j, lane l <- bit of triplet 64*j + l
         uint64_t mine = 0;
 #pragma unroll

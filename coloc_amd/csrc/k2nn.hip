@@ -17,8 +17,9 @@
 //     Unsigned order on keys is (distance, index) lexicographic, so best' = min(best, key) keeps
 //     the lowest index among equal distances, and second' = med3(best, second, key) is the second
 //     smallest key = the second smallest distance of the multiset.  3 more lane-ops per pair.
-//   * 2-D decomposition: (query block) x (train split) so that 10k x 10k fills 256 CUs x 8
-//     waves/SIMD.  Splits are folded into one {best_key, second_key} row per query with two
+//   * 2-D decomposition: (query block of 128) x (train split), and the 4 waves of a workgroup cut
+//     their split in four and fold their results through LDS, so that 10k x 10k fills 256 CUs x 8
+//     waves/SIMD with only one 8-byte result per (query, workgroup).  Splits are folded into one {best_key, second_key} row per query with two
 //     atomicMin (keys carry the global train index, so the fold is order-free and exact -- the
 //     merge rule of SURVEY.md 8(a) note N1 with "lowest index wins" built into the key order); a
 //     tiny finalize kernel applies the threshold, writes the int32 result and re-arms the row.
@@ -32,7 +33,7 @@ namespace clc {
 
 static constexpr int kR = 2;                 // queries per lane
 static constexpr int kWaves = 4;             // waves per workgroup
-static constexpr int kQPerBlock = 64 * kR * kWaves;
+static constexpr int kQPerBlock = 64 * kR;   // the kWaves waves of a workgroup share these queries and cut the train slice in kWaves
 static constexpr uint32_t kKeyShift = 22;    // distance <= 512 needs 10 bits; 22 bits of index
 static constexpr uint32_t kIdxMask = (1u << kKeyShift) - 1u;
 static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
@@ -91,6 +92,7 @@ template <int R>
 __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobList jobs,
                                                                   uint2* __restrict__ partial)
 {
+    __shared__ uint32_t s_best[kWaves - 1][R][64], s_second[kWaves - 1][R][64];
     const K2nnJobDev& job = jobs.j[blockIdx.y];
     const uint32_t nblk = job.qblocks * job.splits;
     if (blockIdx.x >= nblk) return;
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
     const uint32_t split = blockIdx.x - qblock * job.splits;
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t qbase = qblock * (64u * R * kWaves) + wave * (64u * R) + lane;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t qbase = qblock * (64u * R) + lane;
 
     uint32_t q[R][16];
 #pragma unroll
@@ -118,32 +120,65 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
 #pragma unroll
     for (int r = 0; r < R; ++r) { best[r] = kEmpty; second[r] = kEmpty; }
 
-    const uint32_t t0 = split * job.t_per_split;
-    uint32_t t1 = t0 + job.t_per_split;
-    if (t1 > job.nt) t1 = job.nt;
+    // this wave's quarter [t0, t1) of the workgroup's split [s0, s1)
+    const uint32_t s0 = split * job.t_per_split;
+    const uint32_t s1 = min(s0 + job.t_per_split, job.nt);
+    const uint32_t per_wave = (s1 - s0 + kWaves - 1) / kWaves;
+    const uint32_t t0 = min(s0 + wave * per_wave, s1);
+    const uint32_t t1 = min(t0 + per_wave, s1);
+
     // Software-pipelined scalar loads: wait for the CURRENT train vector, immediately issue the
     // s_load_dwordx16 of the NEXT one, then run the 70 VALU ops of the current one while it is in
     // flight.  (Left to itself the compiler issues the load and waits for it at the loop top; the
-    // explicit order is worth ~11 % at 8 waves/SIMD.)  The prefetch never reads past the split.
+    // explicit order is worth ~11 % at 8 waves/SIMD.)  The prefetch never reads past the slice.
+    // Keys carry the index relative to s0 (the workgroup's split), so the waves' results merge by key.
     const_u4_ptr tp = (const_u4_ptr)(uintptr_t)job.t + (size_t)t0 * 4u;   // wave-uniform -> s_load_dwordx16
     if (t0 < t1) {
-        u32x4 a = tp[0], b = tp[1], c = tp[2], d = tp[3];
-        for (uint32_t t = t0; t < t1; ++t) {
-            tp += 4;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): the current vector has landed
+        // two SGPR buffers used alternately (no register copies: the scalar ALU is shared by the CU and
+        // 16 s_mov per train vector made it the bottleneck); an odd tail vector is handled after the loop
+        const uint32_t n = t1 - t0;
+        u32x4 a0 = tp[0], b0 = tp[1], c0 = tp[2], d0 = tp[3];
+        uint32_t t = t0;
+        for (uint32_t pair = 0; pair < (n >> 1); ++pair, t += 2) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): buffer 0 (vector t) has landed
             __builtin_amdgcn_sched_barrier(0);
-            const_u4_ptr np = (t + 1 < t1) ? tp : tp - 4;
-            const u32x4 na = np[0], nb = np[1], nc = np[2], nd = np[3];
+            const u32x4 a1 = tp[4], b1 = tp[5], c1 = tp[6], d1 = tp[7];          // vector t+1 -> buffer 1
             __builtin_amdgcn_sched_barrier(0);
-            sweep_one<R>(q, a, b, c, d, t - t0, best, second);
+            sweep_one<R>(q, a0, b0, c0, d0, t - s0, best, second);
             __builtin_amdgcn_sched_barrier(0);
-            a = na; b = nb; c = nc; d = nd;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                 // buffer 1 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            const_u4_ptr np = (t + 2 < t1) ? tp + 8 : tp;       // vector t+2 -> buffer 0 (never past the slice)
+            a0 = np[0]; b0 = np[1]; c0 = np[2]; d0 = np[3];
+            __builtin_amdgcn_sched_barrier(0);
+            sweep_one<R>(q, a1, b1, c1, d1, t + 1 - s0, best, second);
+            __builtin_amdgcn_sched_barrier(0);
+            tp += 8;
+        }
+        if (n & 1u) sweep_one<R>(q, a0, b0, c0, d0, t - s0, best, second);
+    }
+
+    // fold the kWaves waves through LDS: keys are unique and totally ordered, so
+    // (b, s) (+) (b', s') = (min(b, b'), min(max(b, b'), s, s')) in any order
+    if (wave != 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s_best[wave - 1][r][lane] = best[r]; s_second[wave - 1][r][lane] = second[r]; }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 0; w < kWaves - 1; ++w) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t ob = s_best[w][r][lane], os = s_second[w][r][lane];
+            second[r] = min(min(second[r], os), max(best[r], ob));
+            best[r] = min(best[r], ob);
         }
     }
 
     if (job.atomic_merge) {
         // Fold this split into the query's global top-2 with two 32-bit atomicMin.  Keys carry the
-        // GLOBAL train index here (t0 + index in split < 2^22), so unsigned order on keys is the total
+        // GLOBAL train index here (s0 + index in split < 2^22), so unsigned order on keys is the total
         // order (distance, index) and the fold is commutative: whichever value leaves the `best` slot
         // (because a smaller key arrived) is offered to `second` by the arrival that displaced it.
         unsigned int* top = reinterpret_cast<unsigned int*>(partial + job.partial_off);
@@ -151,8 +186,8 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
         for (int r = 0; r < R; ++r) {
             const uint32_t qi = qbase + 64u * r;
             if (qi < job.nq && best[r] != kEmpty) {
-                const uint32_t bkey = best[r] + t0;
-                const uint32_t skey = second[r] == kEmpty ? kEmpty : second[r] + t0;
+                const uint32_t bkey = best[r] + s0;
+                const uint32_t skey = second[r] == kEmpty ? kEmpty : second[r] + s0;
                 const uint32_t old = atomicMin(top + 2u * qi, bkey);
                 const uint32_t cand = bkey < old ? min(old, skey) : bkey;
                 if (cand != kEmpty) atomicMin(top + 2u * qi + 1u, cand);
@@ -278,7 +313,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
     for (int j = 0; j < njobs; ++j) {
         K2nnJobDev& jb = jobs[j];
         uint32_t splits = want;
-        const uint32_t max_splits = jb.nt / 32u > 0 ? jb.nt / 32u : 1u;   // >= 32 train vectors per split
+        const uint32_t max_splits = jb.nt / 64u > 0 ? jb.nt / 64u : 1u;   // >= 64 train vectors per split (16 per wave)
         if (splits > max_splits) splits = max_splits;
         uint32_t per = jb.nt ? (jb.nt + splits - 1) / splits : 1u;
         if (per > kIdxMask + 1u) per = kIdxMask + 1u;                     // index field is 22 bits

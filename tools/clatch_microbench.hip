@@ -1,6 +1,9 @@
 // clatch_microbench.hip -- times clatch_kernel variants (compile-time -D switches) on synthetic data.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off [-DCLATCH_...] -o tools/clmb tools/clatch_microbench.hip
 #include "../coloc_amd/csrc/clatch.hip"
+#ifndef VARIANT
+#define VARIANT "production"
+#endif
 #include <cstdio>
 #include <vector>
 #include <algorithm>

@@ -21,9 +21,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # LDS geometry (emitted into latch_layout.inc; coloc_amd/csrc/clatch.hip takes it from there)
-ROW0, COL0 = 4, 4            # window region kept in LDS starts at ROI row/col 4 (patches span 5..60)
-STRIDE = 60                  # bytes per stored row (cols 4..63)
-NROWS = 58                   # rows 4..61
+ROW0, COL0 = 5, 5            # window region kept in LDS = ROI rows/cols 5..60, exactly what the patches span
+STRIDE = 56                  # bytes per stored row (cols 5..60)
+NROWS = 56                   # rows 5..60
 COPY_BYTES = NROWS * STRIDE + 8          # 3488: one shifted copy incl. slack for the +3 shift
 COPY_BASE = [0, 0, 0, 0]     # byte offset of shifted copy k inside a wave's region (filled by choose_bases)
 
