@@ -202,6 +202,23 @@ def main():
             "roofline": roof,
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
         }
+        # GPU-resident front end on a real frame (informational): pyramid -> FAST-9/NMS/orientation ->
+        # CLATCH with the keypoint count kept in device memory (no host round trip)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for _ in range(20):
+            ctx.pyramid_build_dev(imgs[0].data_ptr(), W, H, W, sptr)
+            ctx.detect_dev(sptr)
+            ctx.describe_detected_dev(None, sptr)
+        fence()
+        ctx.profile_enable(False)
+        pf = ctx.profile_read()
+        _, n_found = ctx.detect(capacity=1)
+        out["front_end"] = {"what": "640x480 synthetic frame, all on device: pyramid + FAST-9/NMS/angle (8 levels) + CLATCH",
+                            "keypoints": int(n_found),
+                            "pyramid_us": pf["pyramid_kernel"][0] / max(pf["pyramid_kernel"][1], 1) * 1e3,
+                            "detect_us": pf["detect_kernels"][0] / max(pf["detect_kernels"][1], 1) * 1e3,
+                            "clatch_us": pf["clatch_kernel"][0] / max(pf["clatch_kernel"][1], 1) * 1e3}
         # p50 pose-solve (BASELINE metric, config[2] sizes): whole robust solve on host buffers --
         # 256 P3P samples -> <= 1024 hypotheses scored over N matches -> best pose + inlier mask
         pose = {}

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world,counts", [(1, [3000, 2500]), (2, [3000, 2500]), (4, [2000, 1500, 2500, 1800]),
-                                          (8, [1200] * 8), (3, [700, 0, 1300, 512, 513])])
+                                          (8, [1200] * 8), (3, [700, 0, 1300, 512, 513]),
+                                          (1, [600] * 8)])   # 28 jobs in one call: two launch chunks of 16
 def test_every_ranks_jobs_reassemble_to_the_all_pairs_loop(oracle, world, counts):
     import torch
     from coloc_amd import Context
