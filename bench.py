@@ -23,7 +23,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H, NKP, THR = 640, 480, 10000, 40
-VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s
+# VALU issue bound for the K2NN instruction mix: v_bcnt_u32_b32, v_med3/min, v_lshl_add and every VALU op
+# with an SGPR operand issue one wave64 instruction per 4 cycles per SIMD on MI355X (measured,
+# profiles/r01_valu_issue_rates.txt) = 64 lane-ops/clk/CU; only add/sub/mul/fma_f32, add/sub_u32 and
+# and/or/xor on VGPRs reach the 2-cycle rate, and not when interleaved with 4-cycle ops.
+VALU_PEAK_TLANEOPS = 256 * 64 * 2.4e9 / 1e12        # 39.3 T lane-ops/s
+VALU_FAST_PATH_TLANEOPS = 256 * 128 * 2.4e9 / 1e12  # 78.6 (the fp32-FMA style rate; not reachable by this mix)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -182,7 +187,9 @@ def main():
                     "binding": "valu",
                     "valu": {"achieved": laneops, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlaneop/s",
                              "frac": laneops / VALU_PEAK_TLANEOPS,
-                             "lane_ops_per_comparison": 32,
+                             "peak_note": "256 CU x 64 lanes/clk x 2.4 GHz: measured 4-cycle issue of v_bcnt / SGPR-operand ops",
+                             "fast_path_peak": VALU_FAST_PATH_TLANEOPS,
+                             "lane_ops_per_comparison": 32, "issued_lane_ops_per_comparison": 35,
                              "Gcmp_per_s_kernel": cmp_per_launch / t / 1e9}}
         out = {
             "metric": "Mmatches/s (512-bit Hamming comparisons) at 10k kp/img, describe+match step",
