@@ -139,3 +139,18 @@ def test_pyramid_from_device_image_with_pitch(oracle):
     for lv in range(8):
         assert np.array_equal(ctx.pyramid_download(lv), pyr[lv]), "level %d" % lv
     ctx.close()
+
+
+def test_more_than_65536_keypoints_grid_stride(oracle):
+    """n > 65536: the one-wave-per-keypoint grid wraps and waves stride over the keypoints."""
+    W, H, n = 640, 480, 70001
+    img = synth.rect_image(W, H, seed=31, noise_sigma=2.0)
+    kps = synth.random_keypoints(n, W, H, seed=32)
+    ctx = _ctx(W, H, n)
+    ctx.pyramid_build(img)
+    d = ctx.describe(kps)
+    pyr = oracle.pyramid(img)
+    idx = np.concatenate([np.arange(0, 2000), np.arange(65000, 67000), np.arange(n - 2000, n)])
+    assert np.array_equal(d[idx], oracle.clatch(pyr, kps[idx]))
+    assert len({bytes(r) for r in d[::97]}) > 500
+    ctx.close()

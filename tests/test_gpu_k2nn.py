@@ -95,3 +95,26 @@ def test_full_size_properties(gpu_ctx, oracle):
     acc = m1 >= 0
     assert np.array_equal(acc, m2 >= 0)
     assert np.array_equal(perm[m2[acc]], m1[acc])
+
+
+def test_train_set_beyond_22_bit_index_uses_slab_merge(oracle):
+    """nt > 2^22: the global train index no longer fits the key, so the sweep writes per-split slabs and
+    the ordered merge kernel folds them.  Planted duplicates straddle split borders."""
+    from coloc_amd import Context
+    nt, nq = (1 << 22) + 4099, 96
+    ctx = Context(device=0, width=160, height=120, maxkp=nt, detector=False)
+    rng = np.random.default_rng(12)
+    T = rng.integers(0, 256, size=(nt, 64), dtype=np.uint8)
+    Q = rng.integers(0, 256, size=(nq, 64), dtype=np.uint8)
+    for i in range(0, 64, 2):                       # near-duplicates deep in the set and in the last rows
+        src = int(rng.integers(0, nt)) if i % 4 else nt - 1 - i
+        Q[i] = T[src]
+        Q[i, i % 64] ^= 0x11
+    T[nt - 3] = T[5]; Q[64] = T[5]                  # exact duplicate pair 5 / nt-3 -> tie -> rejected
+    m, b, s = ctx.match_2nn(Q, T, 40, want_dist=True)
+    mo, bo, so = oracle.k2nn(Q, T, 40, want_dist=True)
+    assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so)
+    assert (m[:64:2] >= 0).all() and m[64] == -1
+    # and the atomic path still works on the same context afterwards (workspace re-armed)
+    assert np.array_equal(ctx.match_2nn(Q, T[:5000], 40), oracle.k2nn(Q, T[:5000], 40))
+    ctx.close()
