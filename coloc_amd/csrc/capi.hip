@@ -110,6 +110,8 @@ struct clc_ctx {
     size_t pairs_cap = 0;
     double* d_pnp = nullptr;
     size_t pnp_cap = 0;   // doubles
+    void* h_pin = nullptr;        // pinned staging for the pose solve
+    size_t pin_cap = 0;
     Profiler prof;
 };
 
@@ -299,6 +301,7 @@ int clc_ctx_destroy(clc_ctx* ctx)
                      ctx->d_best, ctx->d_second, ctx->d_partial, ctx->d_pnp, ctx->d_pairs };
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CLC_OK;
@@ -780,48 +783,66 @@ static void draw_samples(uint64_t seed, int S, int N, std::vector<int32_t>& out)
     }
 }
 
+// Host staging for the robust pose solve: ONE pinned buffer, ONE H2D copy in, ONE D2H copy out.
+static int ensure_pinned(clc_ctx* ctx, size_t bytes)
+{
+    if (bytes <= ctx->pin_cap) return CLC_OK;
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pin) CLC_HIP(ctx, hipHostFree(ctx->h_pin));
+    ctx->h_pin = nullptr; ctx->pin_cap = 0;
+    CLC_HIP(ctx, hipHostMalloc(&ctx->h_pin, bytes, hipHostMallocDefault));
+    ctx->pin_cap = bytes;
+    return CLC_OK;
+}
+
 static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                            const int32_t* h_samples, int S, uint64_t seed, double thr2, double* h_Rt, uint8_t* h_mask,
                            int* n_inliers, double* cost, double* h_all_Rt)
 {
     if (!ctx || N < 0 || S < 0 || !h_K || (N > 0 && (!h_X || !h_x))) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_ransac: bad argument");
     if (n_inliers) *n_inliers = 0;
-    if (N < 3 || S == 0) return CLC_OK;
+    if (N < 3 || S == 0) { if (h_mask && N > 0) memset(h_mask, 0, (size_t)N); return CLC_OK; }
     if (S > 16384) return fail(ctx, CLC_ERR_CAPACITY, "pnp_ransac: more than 16384 samples per call");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<int32_t> drawn;
     if (!h_samples) { draw_samples(seed, S, N, drawn); h_samples = drawn.data(); }
-    // workspace (doubles): X 3N | x 2N | K 16 | Rt 48S | cost 4S | Rt_best 12 | then int32: count 4S, best 2, samples 3S | mask N bytes
-    const size_t nd = (size_t)5 * N + 16 + (size_t)48 * S + (size_t)4 * S + 12;
-    const size_t ni = (size_t)4 * S + 2 + (size_t)3 * S;
-    const size_t need = nd + (ni + 1) / 2 + ((size_t)N + 7) / 8 + 8;
-    const int rc = ensure_pnp(ctx, need);
+    // device workspace, in doubles:  [ X 3N | x 2N | K 16 | samples (3S int32) ]  <- one H2D copy
+    //                               [ Rt 48S | cost 4S | count (4S int32) ]      scratch
+    //                               [ result record | mask N bytes ]             <- one D2H copy
+    const size_t in_d = (size_t)5 * N + 16 + ((size_t)3 * S + 1) / 2;
+    const size_t scr_d = (size_t)48 * S + (size_t)4 * S + ((size_t)4 * S + 1) / 2;
+    const size_t res_d = (pnp_result_bytes() + 7) / 8;
+    const size_t out_d = res_d + ((size_t)N + 7) / 8;
+    int rc = ensure_pnp(ctx, in_d + scr_d + out_d + 8);
+    if (rc != CLC_OK) return rc;
+    rc = ensure_pinned(ctx, (in_d > out_d ? in_d : out_d) * sizeof(double) + 64);
     if (rc != CLC_OK) return rc;
     double* dX = ctx->d_pnp;
     double* dx = dX + (size_t)3 * N;
     double* dK = dx + (size_t)2 * N;
-    double* dRt = dK + 16;
+    int32_t* dSamples = (int32_t*)(dK + 16);
+    double* dRt = ctx->d_pnp + in_d;
     double* dCost = dRt + (size_t)48 * S;
-    double* dBestRt = dCost + (size_t)4 * S;
-    int32_t* dCount = (int32_t*)(dBestRt + 12);
-    int32_t* dBest = dCount + (size_t)4 * S;
-    int32_t* dSamples = dBest + 2;
-    uint8_t* dMask = (uint8_t*)(ctx->d_pnp + nd + (ni + 1) / 2);
-    CLC_HIP(ctx, hipMemcpyAsync(dX, h_X, sizeof(double) * 3 * N, hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, hipMemcpyAsync(dx, h_x, sizeof(double) * 2 * N, hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, hipMemcpyAsync(dK, h_K, sizeof(double) * 9, hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, hipMemcpyAsync(dSamples, h_samples, sizeof(int32_t) * 3 * S, hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, launch_pnp_ransac(dX, dx, N, dK, dSamples, S, thr2, dRt, dCount, dCost, dBest, dMask, dBestRt, ctx->stream, &ctx->prof));
-    int32_t best[2] = { -1, 0 };
-    CLC_HIP(ctx, hipMemcpyAsync(best, dBest, sizeof best, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_Rt) CLC_HIP(ctx, hipMemcpyAsync(h_Rt, dBestRt, sizeof(double) * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_mask) CLC_HIP(ctx, hipMemcpyAsync(h_mask, dMask, (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    int32_t* dCount = (int32_t*)(dCost + (size_t)4 * S);
+    double* dRes = ctx->d_pnp + in_d + scr_d;
+    uint8_t* dMask = (uint8_t*)(dRes + res_d);
+    // stage inputs
+    double* hp = (double*)ctx->h_pin;
+    memcpy(hp, h_X, sizeof(double) * 3 * N);
+    memcpy(hp + (size_t)3 * N, h_x, sizeof(double) * 2 * N);
+    memcpy(hp + (size_t)5 * N, h_K, sizeof(double) * 9);
+    memcpy(hp + (size_t)5 * N + 16, h_samples, sizeof(int32_t) * 3 * S);
+    CLC_HIP(ctx, hipMemcpyAsync(dX, hp, in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_pnp_ransac(dX, dx, N, dK, dSamples, S, thr2, dRt, dCount, dCost, dMask, dRes, ctx->stream, &ctx->prof));
+    CLC_HIP(ctx, hipMemcpyAsync(hp, dRes, out_d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (h_all_Rt) CLC_HIP(ctx, hipMemcpyAsync(h_all_Rt, dRt, sizeof(double) * 48 * S, hipMemcpyDeviceToHost, ctx->stream));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (n_inliers) *n_inliers = best[0] >= 0 ? best[1] : 0;
-    if (cost && best[0] >= 0) {
-        CLC_HIP(ctx, hipMemcpy(cost, dCost + best[0], sizeof(double), hipMemcpyDeviceToHost));
-    }
+    struct { double Rt[12]; double cost; int32_t h; int32_t count; } r;
+    memcpy(&r, hp, sizeof r);
+    if (h_Rt) memcpy(h_Rt, r.Rt, sizeof(double) * 12);
+    if (h_mask) memcpy(h_mask, (const uint8_t*)(hp + res_d), (size_t)N);
+    if (n_inliers) *n_inliers = r.h >= 0 ? r.count : 0;
+    if (cost) *cost = r.cost;
     return CLC_OK;
 }
 

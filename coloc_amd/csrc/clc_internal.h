@@ -90,10 +90,12 @@ hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const 
                             const double* d_K, double thr2, int32_t* d_count, double* d_cost,
                             hipStream_t stream, Profiler* prof = nullptr);
 
-// P3P hypotheses for S minimal samples (4 slots each) -> score -> select -> inlier mask of the winner
+// P3P hypotheses for S minimal samples (4 slots each) -> score -> select + inlier mask of the winner.
+// d_result receives one packed record {double Rt[12]; double cost; int32 h; int32 count} (pnp_result_bytes()).
 hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
-                             int S, double thr2, double* d_Rt, int32_t* d_count, double* d_cost, int32_t* d_best,
-                             uint8_t* d_mask, double* d_Rt_best, hipStream_t stream, Profiler* prof = nullptr);
+                             int S, double thr2, double* d_Rt, int32_t* d_count, double* d_cost, uint8_t* d_mask,
+                             void* d_result, hipStream_t stream, Profiler* prof = nullptr);
+size_t pnp_result_bytes();
 
 } // namespace clc
 #endif

@@ -108,61 +108,68 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
         for (int e = 0; e < 12; ++e) out[12 * k + e] = k < n ? sol[12 * k + e] : qnan;
 }
 
-// best hypothesis: most inliers, then lowest cost, then lowest index; then its inlier mask
-__global__ __launch_bounds__(256) void pnp_select_kernel(const int32_t* __restrict__ count, const double* __restrict__ cost,
-                                                         const int H, int32_t* __restrict__ best /* [0]=h, [1]=count */)
+// best hypothesis: most inliers, then lowest cost, then lowest index -- and its inlier mask, in ONE
+// launch: every workgroup recomputes the (cheap, deterministic) argmax over the <= 64k hypotheses, so no
+// inter-workgroup hand-off is needed; workgroup 0 also publishes {h, count, cost, pose}.
+struct PnpResult {      // one packed record so the host needs a single D2H copy
+    double Rt[12];
+    double cost;
+    int32_t h;
+    int32_t count;
+};
+
+__device__ __forceinline__ bool hyp_better(const int32_t* __restrict__ count, const double* __restrict__ cost, int b, int a)
+{
+    return count[b] > count[a] || (count[b] == count[a] && (cost[b] < cost[a] || (cost[b] == cost[a] && b < a)));
+}
+
+__global__ __launch_bounds__(256) void pnp_select_mask_kernel(const double* __restrict__ Rt, const int32_t* __restrict__ count,
+                                                              const double* __restrict__ cost, const int H,
+                                                              const double* __restrict__ X, const double* __restrict__ x, const int N,
+                                                              const double* __restrict__ K, const double thr2,
+                                                              uint8_t* __restrict__ mask, PnpResult* __restrict__ res)
 {
     __shared__ int s_h[256];
     int bh = -1;
-    for (int h = threadIdx.x; h < H; h += 256) {
-        if (bh < 0 || count[h] > count[bh] || (count[h] == count[bh] && cost[h] < cost[bh])) bh = h;
-    }
+    for (int h = threadIdx.x; h < H; h += 256)
+        if (bh < 0 || hyp_better(count, cost, h, bh)) bh = h;
     s_h[threadIdx.x] = bh;
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
         if ((int)threadIdx.x < st) {
             const int a = s_h[threadIdx.x], b = s_h[threadIdx.x + st];
-            int w = a;
-            if (a < 0) w = b;
-            else if (b >= 0) {
-                if (count[b] > count[a] || (count[b] == count[a] && (cost[b] < cost[a] || (cost[b] == cost[a] && b < a)))) w = b;
-            }
-            s_h[threadIdx.x] = w;
+            s_h[threadIdx.x] = a < 0 ? b : ((b >= 0 && hyp_better(count, cost, b, a)) ? b : a);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { best[0] = s_h[0]; best[1] = s_h[0] >= 0 ? count[s_h[0]] : 0; }
-}
-
-__global__ __launch_bounds__(256) void pnp_mask_kernel(const double* __restrict__ Rt, const int32_t* __restrict__ best,
-                                                       const double* __restrict__ X, const double* __restrict__ x, const int N,
-                                                       const double* __restrict__ K, const double thr2,
-                                                       uint8_t* __restrict__ mask, double* __restrict__ Rt_best)
-{
-    const int h = best[0];
+    const int h = s_h[0];
+    const bool ok = h >= 0 && count[h] > 0;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (h < 0) { if (i < N) mask[i] = 0; return; }
-    const double* P = Rt + (size_t)12 * h;
-    if (blockIdx.x == 0 && threadIdx.x < 12) Rt_best[threadIdx.x] = P[threadIdx.x];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 12) res->Rt[threadIdx.x] = ok ? Rt[(size_t)12 * h + threadIdx.x] : 0.0;
+        if (threadIdx.x == 12) { res->h = ok ? h : -1; res->count = ok ? count[h] : 0; res->cost = ok ? cost[h] : 0.0; }
+    }
     if (i >= N) return;
-    const double e = reproj_err(P, K, X[3 * i], X[3 * i + 1], X[3 * i + 2], x[2 * i], x[2 * i + 1]);
+    if (!ok) { mask[i] = 0; return; }
+    const double e = reproj_err(Rt + (size_t)12 * h, K, X[3 * i], X[3 * i + 1], X[3 * i + 2], x[2 * i], x[2 * i + 1]);
     mask[i] = e < thr2 ? 1 : 0;
 }
 
 hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
                              int S, double thr2, double* d_Rt /* 48*S */, int32_t* d_count, double* d_cost,
-                             int32_t* d_best, uint8_t* d_mask, double* d_Rt_best, hipStream_t stream, Profiler* prof)
+                             uint8_t* d_mask, void* d_result, hipStream_t stream, Profiler* prof)
 {
     if (S <= 0 || N <= 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
     hipLaunchKernelGGL(p3p_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt);
     hipLaunchKernelGGL(pnp_score_kernel, dim3(4 * S), dim3(256), 0, stream, (const double*)d_Rt, d_X, d_x, N, d_K, thr2, d_count, d_cost);
-    hipLaunchKernelGGL(pnp_select_kernel, dim3(1), dim3(256), 0, stream, (const int32_t*)d_count, (const double*)d_cost, 4 * S, d_best);
-    hipLaunchKernelGGL(pnp_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_Rt, (const int32_t*)d_best,
-                       d_X, d_x, N, d_K, thr2, d_mask, d_Rt_best);
+    hipLaunchKernelGGL(pnp_select_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_Rt,
+                       (const int32_t*)d_count, (const double*)d_cost, 4 * S, d_X, d_x, N, d_K, thr2, d_mask, (PnpResult*)d_result);
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
     return hipGetLastError();
 }
+
+size_t pnp_result_bytes() { return sizeof(PnpResult); }
 
 hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,
                                 const double* d_K, double* d_err, hipStream_t stream, Profiler* prof)
