@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real path). gloo = REHEARSAL of the N>1 code path on a box with fewer "
+                         "GPUs than ranks: ranks share GPUs and the all-gather is staged through host memory")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events)")
     args = ap.parse_args()
 
@@ -73,12 +76,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if args.backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    ctx = Context(device=local_rank, width=W, height=H, maxkp=NKP)
+    ctx = Context(device=dev_index, width=W, height=H, maxkp=NKP)
     # everything (our kernels and torch.distributed's collectives) is ordered on ONE explicit stream
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
@@ -105,7 +112,12 @@ def main():
             ctx.pyramid_build_dev(imgs[k].data_ptr(), W, H, W, sptr)
             ctx.describe_dev(kps[k].data_ptr(), NKP, (arena[c] if world == 1 else mine).data_ptr(), sptr)
         if world > 1:
-            dist.all_gather_into_tensor(arena.view(-1), mine.view(-1))   # RCCL over xGMI, 640 KB per rank
+            if args.backend == "nccl":
+                dist.all_gather_into_tensor(arena.view(-1), mine.view(-1))   # RCCL over xGMI, 640 KB per rank
+            else:                                                            # rehearsal: staged through the host
+                host = [torch.empty((NKP, 64), dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(host, mine.cpu())
+                arena.copy_(torch.stack(host).to(dev))
         if abi_jobs:
             ctx.match_jobs_dev(arena.data_ptr(), abi_jobs, d_match.data_ptr(), sptr)
 
@@ -150,7 +162,7 @@ def main():
     if graph is not None:
         prof = prof_all
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -208,6 +220,8 @@ def main():
                        "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6},
             "roofline": roof,
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
+            "collective": ("none" if world == 1 else ("RCCL all_gather_into_tensor" if args.backend == "nccl"
+                                                      else "REHEARSAL: gloo all_gather staged through host memory")),
         }
         # GPU-resident front end on a real frame (informational): pyramid -> FAST-9/NMS/orientation ->
         # CLATCH with the keypoint count kept in device memory (no host round trip)
@@ -217,7 +231,7 @@ def main():
             ctx.pyramid_build_dev(imgs[0].data_ptr(), W, H, W, sptr)
             ctx.detect_dev(sptr)
             ctx.describe_detected_dev(None, sptr)
-        fence()
+        torch.cuda.synchronize()          # rank-0-only section: no collective here
         ctx.profile_enable(False)
         pf = ctx.profile_read()
         _, n_found = ctx.detect(capacity=1)

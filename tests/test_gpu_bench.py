@@ -1,0 +1,49 @@
+"""bench.py contract checks on the GPU box: the default N=1 line has every required field, and the N>1
+code path (one camera per rank, all-gather, sharded pair jobs, max-over-ranks timing) runs end to end in
+REHEARSAL mode (2 ranks sharing the one GPU, gloo all-gather staged through the host -- the RCCL run
+itself is the driver's, on a multi-GPU node)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out):
+    for line in reversed(out.strip().splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)
+    raise AssertionError("no JSON line in output:\n" + out[-2000:])
+
+
+def test_default_line_has_contract_fields():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "3"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["valu"]["frac"] > 0.3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert d["value"] > 10 * c["value"]          # north-star target: >= 10x the host-CPU matcher
+
+
+def test_two_rank_rehearsal_runs():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+           "--backend", "gloo"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["pairs"] == 1 and d["value"] > 0 and "REHEARSAL" in d["collective"]
