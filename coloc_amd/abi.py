@@ -44,7 +44,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p",
+    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -120,6 +120,7 @@ def load_library():
     lib.clc_detect_and_describe.argtypes = [vp, vp, u32, u32, vp, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     lib.clc_pnp_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_uint64, C.c_double, vp, vp, C.POINTER(ci), C.POINTER(C.c_double)]
     lib.clc_pnp_p3p.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp]
+    lib.clc_pnp_refine.argtypes = [vp, vp, vp, ci, vp, vp, vp, C.c_double, ci, vp, vp, C.POINTER(C.c_double), C.POINTER(ci)]
     lib.clc_profile_enable.argtypes = [vp, ci]
     lib.clc_profile_reset.argtypes = [vp]
     lib.clc_profile_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(ci)]
@@ -324,6 +325,19 @@ class Context:
         self._chk(self.lib.clc_pnp_ransac(self.h, _p(X), _p(x), X.shape[0], _p(K), _p(samples), int(n_samples), int(seed),
                                           float(thr2), _p(Rt), _p(mask), C.byref(n), C.byref(cost)))
         return (Rt.reshape(3, 4) if n.value > 0 else None), mask.astype(bool), cost.value
+
+    def pnp_refine(self, X, x, K, Rt0, mask=None, huber_a=16.0, max_iter=50):
+        """LM refinement of one pose: returns (Rt (3,4), cov (6,6), rmse, iterations)."""
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        Rt0 = np.ascontiguousarray(Rt0, dtype=np.float64).reshape(12)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        Rt = np.zeros(12); cov = np.zeros(36)
+        rmse, it = C.c_double(), C.c_int()
+        self._chk(self.lib.clc_pnp_refine(self.h, _p(X), _p(x), X.shape[0], _p(K), _p(m), _p(Rt0), float(huber_a), int(max_iter),
+                                          _p(Rt), _p(cov), C.byref(rmse), C.byref(it)))
+        return Rt.reshape(3, 4), cov.reshape(6, 6), rmse.value, it.value
 
     def pnp_p3p(self, X, x, K, samples):
         X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)

@@ -852,6 +852,47 @@ int clc_pnp_ransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, co
     return pnp_ransac_impl(ctx, h_X, h_x, N, h_K, h_samples, S, seed, thr2, h_Rt, h_inlier_mask, n_inliers, cost, nullptr);
 }
 
+int clc_pnp_refine(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const uint8_t* h_inlier_mask,
+                   const double* h_Rt_in, double huber_a, int max_iter, double* h_Rt_out, double* h_cov, double* rmse, int* iterations)
+{
+    if (!ctx || N < 0 || !h_K || !h_Rt_in || (N > 0 && (!h_X || !h_x))) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_refine: bad argument");
+    if (N < 3) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_refine: needs at least 3 correspondences");
+    if (!(huber_a > 0.0)) huber_a = 16.0;          // ceres::HuberLoss(Square(4.0)), Refiner.hpp:122
+    if (max_iter <= 0) max_iter = 50;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    // workspace in doubles: [ X 3N | x 2N | K 16 | Rt_in 12 | mask (N bytes) ] in, [ RefineOut ] out
+    const size_t mask_d = ((size_t)N + 7) / 8;
+    const size_t in_d = (size_t)5 * N + 16 + 12 + mask_d;
+    const size_t out_d = (pnp_refine_out_bytes() + 7) / 8;
+    int rc = ensure_pnp(ctx, in_d + out_d + 8);
+    if (rc != CLC_OK) return rc;
+    rc = ensure_pinned(ctx, (in_d > out_d ? in_d : out_d) * sizeof(double) + 64);
+    if (rc != CLC_OK) return rc;
+    double* dX = ctx->d_pnp;
+    double* dx = dX + (size_t)3 * N;
+    double* dK = dx + (size_t)2 * N;
+    double* dRt = dK + 16;
+    uint8_t* dMask = (uint8_t*)(dRt + 12);
+    double* dOut = ctx->d_pnp + in_d;
+    double* hp = (double*)ctx->h_pin;
+    memcpy(hp, h_X, sizeof(double) * 3 * N);
+    memcpy(hp + (size_t)3 * N, h_x, sizeof(double) * 2 * N);
+    memcpy(hp + (size_t)5 * N, h_K, sizeof(double) * 9);
+    memcpy(hp + (size_t)5 * N + 16, h_Rt_in, sizeof(double) * 12);
+    if (h_inlier_mask) memcpy(hp + (size_t)5 * N + 28, h_inlier_mask, (size_t)N);
+    CLC_HIP(ctx, hipMemcpyAsync(dX, hp, in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_pnp_refine(dRt, dX, dx, h_inlier_mask ? dMask : nullptr, N, dK, huber_a, max_iter, dOut, ctx->stream, &ctx->prof));
+    CLC_HIP(ctx, hipMemcpyAsync(hp, dOut, out_d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    struct { double Rt[12]; double cov[36]; double cost; double rmse; int32_t iterations; int32_t n_used; } r;
+    memcpy(&r, hp, sizeof r);
+    if (h_Rt_out) memcpy(h_Rt_out, r.Rt, sizeof r.Rt);
+    if (h_cov) memcpy(h_cov, r.cov, sizeof r.cov);
+    if (rmse) *rmse = r.rmse;
+    if (iterations) *iterations = r.iterations;
+    return CLC_OK;
+}
+
 int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const int32_t* h_samples, int S,
                 double* h_Rt_out)
 {

@@ -96,6 +96,12 @@ hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const 
                              int S, double thr2, double* d_Rt, int32_t* d_count, double* d_cost, uint8_t* d_mask,
                              void* d_result, hipStream_t stream, Profiler* prof = nullptr);
 size_t pnp_result_bytes();
+// Levenberg-Marquardt refinement of one pose over the (masked) correspondences + 6x6 covariance.
+// d_out: {double Rt[12]; double cov[36]; double cost; double rmse; int32 iterations; int32 n_used}
+hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,
+                             const double* d_K, double huber_a, int max_iter, void* d_out, hipStream_t stream,
+                             Profiler* prof = nullptr);
+size_t pnp_refine_out_bytes();
 
 } // namespace clc
 #endif

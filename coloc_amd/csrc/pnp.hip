@@ -155,6 +155,258 @@ __global__ __launch_bounds__(256) void pnp_select_mask_kernel(const double* __re
     mask[i] = e < thr2 ? 1 : 0;
 }
 
+// ---- single-pose refinement + 6x6 covariance ------------------------
+// Role: Localizer::refine -> PoseRefiner::refinePose (reference include/coloc/Localizer.hpp:110-177,
+// include/coloc/Refiner.hpp:47-239): minimise 1/2 sum_i rho(||r_i||^2) over the 6 pose parameters
+// [angle-axis w | t] (x_cam = R(w) X + t), structure and intrinsics fixed, r_i = observed - projected
+// pixel, rho = ceres::HuberLoss(Square(4.0)) (Refiner.hpp:122): rho(s) = s for s <= 256, 2*16*sqrt(s) - 256
+// beyond; then the 6x6 covariance block of the pose = (J^T W J)^-1 at the solution (:177-197).
+// Ceres itself is absent (OpenMVG third_party, empty submodule) -> unpinned; this is a
+// Levenberg-Marquardt on the same cost with the same parametrisation, one workgroup per pose,
+// every iteration = one pass over the points (residual + 2x6 Jacobian + 27 sums reduced through
+// wave shuffles and LDS) + a 6x6 Cholesky solve by lane 0.
+struct RefineOut {
+    double Rt[12];
+    double cov[36];
+    double cost;        // final 1/2 sum rho
+    double rmse;        // sqrt(final_cost / (2 n_used))  (Refiner.hpp:226)
+    int32_t iterations;
+    int32_t n_used;
+};
+
+__device__ __forceinline__ void rodrigues(const double* w, double* R)
+{
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (th2 < 1e-24) {
+        R[0] = 1; R[1] = -w[2]; R[2] = w[1]; R[3] = w[2]; R[4] = 1; R[5] = -w[0]; R[6] = -w[1]; R[7] = w[0]; R[8] = 1;
+        return;
+    }
+    const double th = sqrt(th2), c = cos(th), s = sin(th), k0 = w[0] / th, k1 = w[1] / th, k2 = w[2] / th, v = 1.0 - c;
+    R[0] = c + k0 * k0 * v;      R[1] = k0 * k1 * v - k2 * s; R[2] = k0 * k2 * v + k1 * s;
+    R[3] = k1 * k0 * v + k2 * s; R[4] = c + k1 * k1 * v;      R[5] = k1 * k2 * v - k0 * s;
+    R[6] = k2 * k0 * v - k1 * s; R[7] = k2 * k1 * v + k0 * s; R[8] = c + k2 * k2 * v;
+}
+
+// angle-axis of a rotation matrix (row-major)
+__device__ __forceinline__ void log_so3(const double* R, double* w)
+{
+    const double tr = R[0] + R[4] + R[8];
+    double c = 0.5 * (tr - 1.0);
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    const double th = acos(c);
+    const double ax = R[7] - R[5], ay = R[2] - R[6], az = R[3] - R[1];
+    if (th < 1e-9) { w[0] = 0.5 * ax; w[1] = 0.5 * ay; w[2] = 0.5 * az; return; }
+    if (M_PI - th < 1e-6) {
+        // near pi: take the axis from the diagonal
+        const double xx = 0.5 * (R[0] + 1.0), yy = 0.5 * (R[4] + 1.0), zz = 0.5 * (R[8] + 1.0);
+        double x = sqrt(xx > 0 ? xx : 0), y = sqrt(yy > 0 ? yy : 0), z = sqrt(zz > 0 ? zz : 0);
+        if (ax < 0) x = -x; if (ay < 0) y = -y; if (az < 0) z = -z;
+        w[0] = th * x; w[1] = th * y; w[2] = th * z;
+        return;
+    }
+    const double f = th / (2.0 * sin(th));
+    w[0] = f * ax; w[1] = f * ay; w[2] = f * az;
+}
+
+// dR/dw_k (Gallego & Yezzi 2015): (w_k [w]x + [w x (I - R) e_k]x) R / |w|^2 ; generators at w -> 0
+__device__ __forceinline__ void d_rodrigues(const double* w, const double* R, double (*dR)[9])
+{
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    for (int k = 0; k < 3; ++k) {
+        double A[9];
+        if (th2 < 1e-16) {
+            for (int i = 0; i < 9; ++i) A[i] = 0.0;
+            if (k == 0) { A[5] = -1; A[7] = 1; } else if (k == 1) { A[2] = 1; A[6] = -1; } else { A[1] = -1; A[3] = 1; }
+            for (int i = 0; i < 9; ++i) dR[k][i] = A[i];
+            continue;
+        }
+        // u = w x ((I - R) e_k)
+        const double m0 = (k == 0 ? 1.0 : 0.0) - R[0 + k], m1 = (k == 1 ? 1.0 : 0.0) - R[3 + k], m2 = (k == 2 ? 1.0 : 0.0) - R[6 + k];
+        const double u0 = w[1] * m2 - w[2] * m1, u1 = w[2] * m0 - w[0] * m2, u2 = w[0] * m1 - w[1] * m0;
+        const double b0 = w[k] * w[0] + u0, b1 = w[k] * w[1] + u1, b2 = w[k] * w[2] + u2;   // w_k w + u
+        // A = [b]x / th2
+        A[0] = 0; A[1] = -b2; A[2] = b1; A[3] = b2; A[4] = 0; A[5] = -b0; A[6] = -b1; A[7] = b0; A[8] = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                dR[k][3 * i + j] = (A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j] + A[3 * i + 2] * R[6 + j]) / th2;
+    }
+}
+
+// Cholesky solve of the damped 6x6 system (A + lambda diag(A)) d = g; returns false if not SPD
+__device__ __forceinline__ bool solve6(const double* A, const double* g, double lambda, double* d)
+{
+    double L[36];
+    for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j <= i; ++j) {
+            double sum = A[6 * i + j] + (i == j ? lambda * (A[6 * i + i] > 1e-12 ? A[6 * i + i] : 1e-12) : 0.0);
+            for (int k = 0; k < j; ++k) sum -= L[6 * i + k] * L[6 * j + k];
+            if (i == j) { if (!(sum > 0.0)) return false; L[6 * i + i] = sqrt(sum); }
+            else L[6 * i + j] = sum / L[6 * j + j];
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; ++i) { double sum = g[i]; for (int k = 0; k < i; ++k) sum -= L[6 * i + k] * y[k]; y[i] = sum / L[6 * i + i]; }
+    for (int i = 5; i >= 0; --i) { double sum = y[i]; for (int k = i + 1; k < 6; ++k) sum -= L[6 * k + i] * d[k]; d[i] = sum / L[6 * i + i]; }
+    return true;
+}
+
+__device__ __forceinline__ bool invert6(const double* A, double* inv)
+{
+    for (int c = 0; c < 6; ++c) {
+        double e[6] = { 0, 0, 0, 0, 0, 0 }, col[6];
+        e[c] = 1.0;
+        if (!solve6(A, e, 0.0, col)) return false;
+        for (int r = 0; r < 6; ++r) inv[6 * r + c] = col[r];
+    }
+    return true;
+}
+
+static constexpr int kRefineSums = 28;   // 21 (upper JtWJ) + 6 (JtWr) + 1 (cost)
+
+__global__ __launch_bounds__(256) void pnp_refine_kernel(const double* __restrict__ Rt_in, const double* __restrict__ X,
+                                                         const double* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                         const int N, const double* __restrict__ K, const double huber_a,
+                                                         const int max_iter, RefineOut* __restrict__ out)
+{
+    __shared__ double s_par[6], s_R[9], s_dR[3][9], s_sum[4][kRefineSums], s_tot[kRefineSums], s_try[6];
+    __shared__ double s_A[kRefineSums];   // sums (JtWJ, JtWr, cost) at the CURRENT parameters s_par
+    __shared__ int s_flag;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const double b2 = huber_a * huber_a;
+    if (tid == 0) {
+        double R0[9] = { Rt_in[0], Rt_in[1], Rt_in[2], Rt_in[4], Rt_in[5], Rt_in[6], Rt_in[8], Rt_in[9], Rt_in[10] };
+        double w[3];
+        log_so3(R0, w);
+        s_par[0] = w[0]; s_par[1] = w[1]; s_par[2] = w[2]; s_par[3] = Rt_in[3]; s_par[4] = Rt_in[7]; s_par[5] = Rt_in[11];
+    }
+    __syncthreads();
+
+    // one pass: sums of JtWJ / JtWr / cost at parameters `par` (jac = false: cost only)
+    auto pass = [&](const double* par, bool jac) {
+        if (tid == 0) { rodrigues(par, s_R); if (jac) d_rodrigues(par, s_R, s_dR); }
+        __syncthreads();
+        double acc[kRefineSums];
+#pragma unroll
+        for (int i = 0; i < kRefineSums; ++i) acc[i] = 0.0;
+        for (int i = tid; i < N; i += 256) {
+            if (mask && !mask[i]) continue;
+            const double X0 = X[3 * i], X1 = X[3 * i + 1], X2 = X[3 * i + 2];
+            const double xc = s_R[0] * X0 + s_R[1] * X1 + s_R[2] * X2 + par[3];
+            const double yc = s_R[3] * X0 + s_R[4] * X1 + s_R[5] * X2 + par[4];
+            const double zc = s_R[6] * X0 + s_R[7] * X1 + s_R[8] * X2 + par[5];
+            const double iz = 1.0 / zc, xn = xc * iz, yn = yc * iz;
+            const double r0 = x[2 * i] - (fx * xn + sk * yn + cx), r1 = x[2 * i + 1] - (fy * yn + cy);
+            const double sq = r0 * r0 + r1 * r1;
+            const double rho = sq <= b2 ? sq : 2.0 * huber_a * sqrt(sq) - b2;
+            const double wgt = sq <= b2 ? 1.0 : huber_a / sqrt(sq);          // rho'(s)
+            acc[27] += 0.5 * rho;
+            if (!jac) continue;
+            // d(proj)/d(xc,yc,zc)
+            const double pu0 = fx * iz, pu1 = sk * iz, pu2 = -(fx * xn + sk * yn) * iz;
+            const double pv1 = fy * iz, pv2 = -fy * yn * iz;
+            double Ju[6], Jv[6];      // Jacobian of the PROJECTION (residual = obs - proj -> J_r = -J)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double d0 = s_dR[k][0] * X0 + s_dR[k][1] * X1 + s_dR[k][2] * X2;
+                const double d1 = s_dR[k][3] * X0 + s_dR[k][4] * X1 + s_dR[k][5] * X2;
+                const double d2 = s_dR[k][6] * X0 + s_dR[k][7] * X1 + s_dR[k][8] * X2;
+                Ju[k] = pu0 * d0 + pu1 * d1 + pu2 * d2;
+                Jv[k] = pv1 * d1 + pv2 * d2;
+            }
+            Ju[3] = pu0; Ju[4] = pu1; Ju[5] = pu2;
+            Jv[3] = 0.0; Jv[4] = pv1; Jv[5] = pv2;
+            int idx = 0;
+#pragma unroll
+            for (int a_ = 0; a_ < 6; ++a_) {
+#pragma unroll
+                for (int b_ = a_; b_ < 6; ++b_) acc[idx++] += wgt * (Ju[a_] * Ju[b_] + Jv[a_] * Jv[b_]);
+            }
+#pragma unroll
+            for (int a_ = 0; a_ < 6; ++a_) acc[21 + a_] += wgt * (Ju[a_] * r0 + Jv[a_] * r1);   // = -J_r^T W r : descent rhs
+        }
+#pragma unroll
+        for (int i = 0; i < kRefineSums; ++i) {
+            double v = acc[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) s_sum[wv][i] = v;
+        }
+        __syncthreads();
+        if (tid < kRefineSums) s_tot[tid] = (s_sum[0][tid] + s_sum[1][tid]) + (s_sum[2][tid] + s_sum[3][tid]);
+        __syncthreads();
+    };
+
+    double lambda = 1e-4;
+    int it = 0;
+    pass(s_par, true);
+    if (tid < kRefineSums) s_A[tid] = s_tot[tid];
+    __syncthreads();
+    double cost = s_A[27];
+    for (; it < max_iter; ++it) {
+        if (tid == 0) {
+            double A[36], g[6], d[6];
+            int idx = 0;
+            for (int a_ = 0; a_ < 6; ++a_) for (int b_ = a_; b_ < 6; ++b_) { A[6 * a_ + b_] = s_A[idx]; A[6 * b_ + a_] = s_A[idx]; ++idx; }
+            for (int a_ = 0; a_ < 6; ++a_) g[a_] = s_A[21 + a_];
+            bool ok = solve6(A, g, lambda, d);
+            double gn = 0, dn = 0, pn = 0;
+            for (int a_ = 0; a_ < 6; ++a_) { gn = fmax(gn, fabs(g[a_])); dn += d[a_] * d[a_]; pn += s_par[a_] * s_par[a_]; }
+            // convergence like the reference's settings (gradient / parameter tolerance 1e-8, Refiner.hpp:169-171)
+            s_flag = !ok ? 2 : ((gn < 1e-8 * fmax(1.0, cost) || sqrt(dn) < 1e-8 * (sqrt(pn) + 1e-8)) ? 1 : 0);
+            for (int a_ = 0; a_ < 6; ++a_) s_try[a_] = s_par[a_] + (ok ? d[a_] : 0.0);
+        }
+        __syncthreads();
+        const int flag = s_flag;
+        if (flag == 1) break;
+        if (flag == 2) { lambda *= 10.0; if (lambda > 1e10) break; __syncthreads(); continue; }
+        pass(s_try, false);
+        const double new_cost = s_tot[27];
+        __syncthreads();
+        if (new_cost < cost) {
+            if (tid < 6) s_par[tid] = s_try[tid];
+            const double rel = (cost - new_cost) / fmax(cost, 1e-300);
+            cost = new_cost;
+            lambda = fmax(lambda * 0.1, 1e-12);
+            __syncthreads();
+            pass(s_par, true);
+            if (tid < kRefineSums) s_A[tid] = s_tot[tid];
+            __syncthreads();
+            if (rel < 1e-8) { ++it; break; }                  // function tolerance 1e-8 (Refiner.hpp:169)
+        } else {
+            lambda *= 10.0;
+            if (lambda > 1e10) break;
+        }
+    }
+    // s_A holds the sums at s_par (last Jacobian pass)
+    if (tid == 0) {
+        double A[36];
+        int idx = 0;
+        for (int a_ = 0; a_ < 6; ++a_) for (int b_ = a_; b_ < 6; ++b_) { A[6 * a_ + b_] = s_A[idx]; A[6 * b_ + a_] = s_A[idx]; ++idx; }
+        double R[9];
+        rodrigues(s_par, R);
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) out->Rt[4 * i + j] = R[3 * i + j]; out->Rt[4 * i + 3] = s_par[3 + i]; }
+        if (!invert6(A, out->cov)) for (int i = 0; i < 36; ++i) out->cov[i] = 0.0;
+        int n_used = 0;
+        for (int i = 0; i < N; ++i) n_used += (!mask || mask[i]) ? 1 : 0;
+        out->cost = s_A[27];
+        out->rmse = n_used ? sqrt(s_A[27] / (2.0 * n_used)) : 0.0;
+        out->iterations = it;
+        out->n_used = n_used;
+    }
+}
+
+hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,
+                             const double* d_K, double huber_a, int max_iter, void* d_out, hipStream_t stream, Profiler* prof)
+{
+    if (N <= 0) return hipSuccess;
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
+    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, stream, d_Rt_in, d_X, d_x, d_mask, N, d_K, huber_a, max_iter,
+                       (RefineOut*)d_out);
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
+    return hipGetLastError();
+}
+size_t pnp_refine_out_bytes() { return sizeof(RefineOut); }
+
 hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
                              int S, double thr2, double* d_Rt /* 48*S */, int32_t* d_count, double* d_cost,
                              uint8_t* d_mask, void* d_result, hipStream_t stream, Profiler* prof)

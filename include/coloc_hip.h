@@ -218,6 +218,18 @@ int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, co
 int clc_pnp_ransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                    const int32_t* h_samples, int S, uint64_t seed, double thr2, double* h_Rt,
                    uint8_t* h_inlier_mask, int* n_inliers, double* cost);
+/* Single-pose refinement + covariance -- the role of Localizer::refine -> PoseRefiner::refinePose
+ * (Localizer.hpp:110-177, Refiner.hpp:47-239; Ceres LM, HuberLoss(Square(4.0)), structure and intrinsics
+ * fixed): Levenberg-Marquardt on 1/2 sum rho(||obs - proj||^2) over the 6 parameters [angle-axis | t],
+ * from the initial pose h_Rt_in, using the correspondences with h_inlier_mask[i] != 0 (NULL = all).
+ * Outputs (all nullable): h_Rt_out 12 doubles, h_cov 36 doubles = (J^T W J)^-1 in the [angle-axis | t]
+ * parametrisation (row-major), *rmse = sqrt(final_cost / (2 n_used)) (Refiner.hpp:226), *iterations.
+ * huber_a <= 0 selects the reference's 16.  Ceres is absent here, so results are defined by this
+ * cost, not by Ceres' iterates (unpinned). */
+int clc_pnp_refine(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
+                   const uint8_t* h_inlier_mask, const double* h_Rt_in, double huber_a, int max_iter,
+                   double* h_Rt_out, double* h_cov, double* rmse, int* iterations);
+
 /* The hypotheses of the minimal solver alone: h_Rt_out receives 4 S x 12 doubles (NaN = no solution). */
 int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                 const int32_t* h_samples, int S, double* h_Rt_out);
