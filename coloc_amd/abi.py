@@ -44,7 +44,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine",
+    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -120,6 +120,8 @@ def load_library():
     lib.clc_detect_and_describe.argtypes = [vp, vp, u32, u32, vp, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     lib.clc_pnp_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_uint64, C.c_double, vp, vp, C.POINTER(ci), C.POINTER(C.c_double)]
     lib.clc_pnp_p3p.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp]
+    lib.clc_pnp_localize.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, C.POINTER(ci),
+                                     C.POINTER(C.c_double)]
     lib.clc_pnp_refine.argtypes = [vp, vp, vp, ci, vp, vp, vp, C.c_double, ci, vp, vp, C.POINTER(C.c_double), C.POINTER(ci)]
     lib.clc_profile_enable.argtypes = [vp, ci]
     lib.clc_profile_reset.argtypes = [vp]
@@ -325,6 +327,21 @@ class Context:
         self._chk(self.lib.clc_pnp_ransac(self.h, _p(X), _p(x), X.shape[0], _p(K), _p(samples), int(n_samples), int(seed),
                                           float(thr2), _p(Rt), _p(mask), C.byref(n), C.byref(cost)))
         return (Rt.reshape(3, 4) if n.value > 0 else None), mask.astype(bool), cost.value
+
+    def pnp_localize(self, X, x, K, samples=None, n_samples=256, seed=1, thr2=16.0, huber_a=16.0):
+        """ransac + refine in one submission: (Rt (3,4) or None, cov (6,6), inlier mask, rmse)."""
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        if samples is not None:
+            samples = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, 3)
+            n_samples = samples.shape[0]
+        Rt = np.zeros(12); cov = np.zeros(36)
+        mask = np.zeros(X.shape[0], dtype=np.uint8)
+        n, rmse = C.c_int(), C.c_double()
+        self._chk(self.lib.clc_pnp_localize(self.h, _p(X), _p(x), X.shape[0], _p(K), _p(samples), int(n_samples), int(seed),
+                                            float(thr2), float(huber_a), _p(Rt), _p(cov), _p(mask), C.byref(n), C.byref(rmse)))
+        return (Rt.reshape(3, 4) if n.value > 0 else None), cov.reshape(6, 6), mask.astype(bool), rmse.value
 
     def pnp_refine(self, X, x, K, Rt0, mask=None, huber_a=16.0, max_iter=50):
         """LM refinement of one pose: returns (Rt (3,4), cov (6,6), rmse, iterations)."""

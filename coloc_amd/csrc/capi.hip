@@ -797,7 +797,8 @@ static int ensure_pinned(clc_ctx* ctx, size_t bytes)
 
 static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                            const int32_t* h_samples, int S, uint64_t seed, double thr2, double* h_Rt, uint8_t* h_mask,
-                           int* n_inliers, double* cost, double* h_all_Rt)
+                           int* n_inliers, double* cost, double* h_all_Rt, double refine_huber = -1.0, double* h_cov = nullptr,
+                           double* rmse = nullptr)
 {
     if (!ctx || N < 0 || S < 0 || !h_K || (N > 0 && (!h_X || !h_x))) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_ransac: bad argument");
     if (n_inliers) *n_inliers = 0;
@@ -811,7 +812,9 @@ static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, i
     //                               [ result record | mask N bytes ]             <- one D2H copy
     const size_t in_d = (size_t)5 * N + 16 + ((size_t)3 * S + 1) / 2;
     const size_t scr_d = (size_t)48 * S + (size_t)4 * S + ((size_t)4 * S + 1) / 2;
-    const size_t res_d = (pnp_result_bytes() + 7) / 8;
+    const bool refine = refine_huber > 0.0;
+    const size_t ref_d = refine ? (pnp_refine_out_bytes() + 7) / 8 : 0;      // refine record rides in front of the mask
+    const size_t res_d = (pnp_result_bytes() + 7) / 8 + ref_d;
     const size_t out_d = res_d + ((size_t)N + 7) / 8;
     int rc = ensure_pnp(ctx, in_d + scr_d + out_d + 8);
     if (rc != CLC_OK) return rc;
@@ -834,6 +837,10 @@ static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, i
     memcpy(hp + (size_t)5 * N + 16, h_samples, sizeof(int32_t) * 3 * S);
     CLC_HIP(ctx, hipMemcpyAsync(dX, hp, in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     CLC_HIP(ctx, launch_pnp_ransac(dX, dx, N, dK, dSamples, S, thr2, dRt, dCount, dCost, dMask, dRes, ctx->stream, &ctx->prof));
+    double* dRef = dRes + (pnp_result_bytes() + 7) / 8;
+    if (refine)
+        CLC_HIP(ctx, launch_pnp_refine(dRes /* PnpResult.Rt */, dX, dx, dMask, N, dK, refine_huber, 50, dRef, ctx->stream, &ctx->prof,
+                                       (const int32_t*)((const uint8_t*)dRes + pnp_result_valid_offset())));
     CLC_HIP(ctx, hipMemcpyAsync(hp, dRes, out_d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (h_all_Rt) CLC_HIP(ctx, hipMemcpyAsync(h_all_Rt, dRt, sizeof(double) * 48 * S, hipMemcpyDeviceToHost, ctx->stream));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -843,6 +850,13 @@ static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, i
     if (h_mask) memcpy(h_mask, (const uint8_t*)(hp + res_d), (size_t)N);
     if (n_inliers) *n_inliers = r.h >= 0 ? r.count : 0;
     if (cost) *cost = r.cost;
+    if (refine) {
+        struct { double Rt[12]; double cov[36]; double cost; double rmse; int32_t iterations; int32_t n_used; } f;
+        memcpy(&f, hp + (pnp_result_bytes() + 7) / 8, sizeof f);
+        if (h_Rt) memcpy(h_Rt, f.Rt, sizeof f.Rt);
+        if (h_cov) memcpy(h_cov, f.cov, sizeof f.cov);
+        if (rmse) *rmse = f.rmse;
+    }
     return CLC_OK;
 }
 
@@ -891,6 +905,17 @@ int clc_pnp_refine(clc_ctx* ctx, const double* h_X, const double* h_x, int N, co
     if (rmse) *rmse = r.rmse;
     if (iterations) *iterations = r.iterations;
     return CLC_OK;
+}
+
+int clc_pnp_localize(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const int32_t* h_samples,
+                     int S, uint64_t seed, double thr2, double huber_a, double* h_Rt, double* h_cov, uint8_t* h_inlier_mask,
+                     int* n_inliers, double* rmse)
+{
+    if (h_Rt) memset(h_Rt, 0, sizeof(double) * 12);
+    if (h_cov) memset(h_cov, 0, sizeof(double) * 36);
+    if (rmse) *rmse = 0.0;
+    return pnp_ransac_impl(ctx, h_X, h_x, N, h_K, h_samples, S, seed, thr2, h_Rt, h_inlier_mask, n_inliers, nullptr, nullptr,
+                           huber_a > 0.0 ? huber_a : 16.0, h_cov, rmse);
 }
 
 int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const int32_t* h_samples, int S,

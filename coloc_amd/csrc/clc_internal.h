@@ -100,7 +100,8 @@ size_t pnp_result_bytes();
 // d_out: {double Rt[12]; double cov[36]; double cost; double rmse; int32 iterations; int32 n_used}
 hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,
                              const double* d_K, double huber_a, int max_iter, void* d_out, hipStream_t stream,
-                             Profiler* prof = nullptr);
+                             Profiler* prof = nullptr, const int32_t* d_valid = nullptr);
+size_t pnp_result_valid_offset();   // byte offset of the int32 "winning hypothesis" (< 0: none) in the ransac result record
 size_t pnp_refine_out_bytes();
 
 } // namespace clc

@@ -235,41 +235,69 @@ __device__ __forceinline__ void d_rodrigues(const double* w, const double* R, do
 // Cholesky solve of the damped 6x6 system (A + lambda diag(A)) d = g; returns false if not SPD
 __device__ __forceinline__ bool solve6(const double* A, const double* g, double lambda, double* d)
 {
+    // fully unrolled (compile-time indices) so that L, y stay in registers instead of scratch
     double L[36];
+    bool spd = true;
+#pragma unroll
     for (int i = 0; i < 6; ++i) {
+#pragma unroll
         for (int j = 0; j <= i; ++j) {
             double sum = A[6 * i + j] + (i == j ? lambda * (A[6 * i + i] > 1e-12 ? A[6 * i + i] : 1e-12) : 0.0);
+#pragma unroll
             for (int k = 0; k < j; ++k) sum -= L[6 * i + k] * L[6 * j + k];
-            if (i == j) { if (!(sum > 0.0)) return false; L[6 * i + i] = sqrt(sum); }
+            if (i == j) { spd = spd && (sum > 0.0); L[6 * i + i] = sqrt(sum > 0.0 ? sum : 1.0); }
             else L[6 * i + j] = sum / L[6 * j + j];
         }
     }
+    if (!spd) return false;
     double y[6];
-    for (int i = 0; i < 6; ++i) { double sum = g[i]; for (int k = 0; k < i; ++k) sum -= L[6 * i + k] * y[k]; y[i] = sum / L[6 * i + i]; }
-    for (int i = 5; i >= 0; --i) { double sum = y[i]; for (int k = i + 1; k < 6; ++k) sum -= L[6 * k + i] * d[k]; d[i] = sum / L[6 * i + i]; }
-    return true;
-}
-
-__device__ __forceinline__ bool invert6(const double* A, double* inv)
-{
-    for (int c = 0; c < 6; ++c) {
-        double e[6] = { 0, 0, 0, 0, 0, 0 }, col[6];
-        e[c] = 1.0;
-        if (!solve6(A, e, 0.0, col)) return false;
-        for (int r = 0; r < 6; ++r) inv[6 * r + c] = col[r];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double sum = g[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) sum -= L[6 * i + k] * y[k];
+        y[i] = sum / L[6 * i + i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double sum = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) sum -= L[6 * k + i] * d[k];
+        d[i] = sum / L[6 * i + i];
     }
     return true;
 }
 
-static constexpr int kRefineSums = 28;   // 21 (upper JtWJ) + 6 (JtWr) + 1 (cost)
-
-__global__ __launch_bounds__(256) void pnp_refine_kernel(const double* __restrict__ Rt_in, const double* __restrict__ X,
-                                                         const double* __restrict__ x, const uint8_t* __restrict__ mask,
-                                                         const int N, const double* __restrict__ K, const double huber_a,
-                                                         const int max_iter, RefineOut* __restrict__ out)
+// column c of A^-1 (A SPD): called by six lanes in parallel, one column each
+__device__ __forceinline__ bool invert6_column(const double* A, int c, double* inv)
 {
-    __shared__ double s_par[6], s_R[9], s_dR[3][9], s_sum[4][kRefineSums], s_tot[kRefineSums], s_try[6];
-    __shared__ double s_A[kRefineSums];   // sums (JtWJ, JtWr, cost) at the CURRENT parameters s_par
+    double e[6], col[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) e[r] = r == c ? 1.0 : 0.0;
+    if (!solve6(A, e, 0.0, col)) return false;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) inv[6 * r + c] = col[r];
+    return true;
+}
+
+static constexpr int kRefineSums = 29;   // 21 (upper JtWJ) + 6 (JtWr) + 1 (cost) + 1 (points used)
+static constexpr int kRefineThreads = 512;
+static constexpr int kRefineWaves = kRefineThreads / 64;
+
+__global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double* __restrict__ Rt_in, const double* __restrict__ X,
+                                                                    const double* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                                    const int N, const double* __restrict__ K, const double huber_a,
+                                                                    const int max_iter, const int32_t* __restrict__ valid,
+                                                                    RefineOut* __restrict__ out)
+{
+    if (valid && *valid < 0) {          // chained after clc_pnp_ransac that found no pose: nothing to refine
+        if (threadIdx.x < 12) out->Rt[threadIdx.x] = 0.0;
+        if (threadIdx.x < 36) out->cov[threadIdx.x] = 0.0;
+        if (threadIdx.x == 0) { out->cost = 0.0; out->rmse = 0.0; out->iterations = 0; out->n_used = 0; }
+        return;
+    }
+    __shared__ double s_par[6], s_try[6], s_R[9], s_dR[3][9], s_sum[kRefineWaves][kRefineSums], s_tot[kRefineSums];
+    __shared__ double s_A[kRefineSums];   // sums (JtWJ, JtWr, cost, count) at the CURRENT parameters s_par
     __shared__ int s_flag;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
@@ -282,14 +310,15 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const double* __restric
     }
     __syncthreads();
 
-    // one pass: sums of JtWJ / JtWr / cost at parameters `par` (jac = false: cost only)
-    auto pass = [&](const double* par, bool jac) {
-        if (tid == 0) { rodrigues(par, s_R); if (jac) d_rodrigues(par, s_R, s_dR); }
+    // One pass over the points at parameters `par`: cost AND the normal-equation sums, so that an
+    // accepted trial step needs no second pass (rejections are rare and only waste the Jacobian part).
+    auto pass = [&](const double* par) {
+        if (tid == 0) { rodrigues(par, s_R); d_rodrigues(par, s_R, s_dR); }
         __syncthreads();
         double acc[kRefineSums];
 #pragma unroll
         for (int i = 0; i < kRefineSums; ++i) acc[i] = 0.0;
-        for (int i = tid; i < N; i += 256) {
+        for (int i = tid; i < N; i += kRefineThreads) {
             if (mask && !mask[i]) continue;
             const double X0 = X[3 * i], X1 = X[3 * i + 1], X2 = X[3 * i + 2];
             const double xc = s_R[0] * X0 + s_R[1] * X1 + s_R[2] * X2 + par[3];
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const double* __restric
             const double rho = sq <= b2 ? sq : 2.0 * huber_a * sqrt(sq) - b2;
             const double wgt = sq <= b2 ? 1.0 : huber_a / sqrt(sq);          // rho'(s)
             acc[27] += 0.5 * rho;
-            if (!jac) continue;
+            acc[28] += 1.0;
             // d(proj)/d(xc,yc,zc)
             const double pu0 = fx * iz, pu1 = sk * iz, pu2 = -(fx * xn + sk * yn) * iz;
             const double pv1 = fy * iz, pv2 = -fy * yn * iz;
@@ -332,13 +361,17 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const double* __restric
             if (lane == 0) s_sum[wv][i] = v;
         }
         __syncthreads();
-        if (tid < kRefineSums) s_tot[tid] = (s_sum[0][tid] + s_sum[1][tid]) + (s_sum[2][tid] + s_sum[3][tid]);
+        if (tid < kRefineSums) {
+            double v = 0.0;
+            for (int w_ = 0; w_ < kRefineWaves; ++w_) v += s_sum[w_][tid];
+            s_tot[tid] = v;
+        }
         __syncthreads();
     };
 
     double lambda = 1e-4;
     int it = 0;
-    pass(s_par, true);
+    pass(s_par);
     if (tid < kRefineSums) s_A[tid] = s_tot[tid];
     __syncthreads();
     double cost = s_A[27];
@@ -359,49 +392,49 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const double* __restric
         const int flag = s_flag;
         if (flag == 1) break;
         if (flag == 2) { lambda *= 10.0; if (lambda > 1e10) break; __syncthreads(); continue; }
-        pass(s_try, false);
+        pass(s_try);
         const double new_cost = s_tot[27];
-        __syncthreads();
         if (new_cost < cost) {
-            if (tid < 6) s_par[tid] = s_try[tid];
             const double rel = (cost - new_cost) / fmax(cost, 1e-300);
+            if (tid < 6) s_par[tid] = s_try[tid];
+            if (tid < kRefineSums) s_A[tid] = s_tot[tid];
             cost = new_cost;
             lambda = fmax(lambda * 0.1, 1e-12);
-            __syncthreads();
-            pass(s_par, true);
-            if (tid < kRefineSums) s_A[tid] = s_tot[tid];
             __syncthreads();
             if (rel < 1e-8) { ++it; break; }                  // function tolerance 1e-8 (Refiner.hpp:169)
         } else {
             lambda *= 10.0;
+            __syncthreads();
             if (lambda > 1e10) break;
         }
     }
-    // s_A holds the sums at s_par (last Jacobian pass)
-    if (tid == 0) {
+    // s_A holds the sums at s_par
+    if (tid < 6) {
         double A[36];
         int idx = 0;
         for (int a_ = 0; a_ < 6; ++a_) for (int b_ = a_; b_ < 6; ++b_) { A[6 * a_ + b_] = s_A[idx]; A[6 * b_ + a_] = s_A[idx]; ++idx; }
+        if (!invert6_column(A, tid, out->cov)) for (int r = 0; r < 6; ++r) out->cov[6 * r + tid] = 0.0;
+    }
+    if (tid == 0) {
         double R[9];
         rodrigues(s_par, R);
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) out->Rt[4 * i + j] = R[3 * i + j]; out->Rt[4 * i + 3] = s_par[3 + i]; }
-        if (!invert6(A, out->cov)) for (int i = 0; i < 36; ++i) out->cov[i] = 0.0;
-        int n_used = 0;
-        for (int i = 0; i < N; ++i) n_used += (!mask || mask[i]) ? 1 : 0;
+        const double n_used = s_A[28];
         out->cost = s_A[27];
-        out->rmse = n_used ? sqrt(s_A[27] / (2.0 * n_used)) : 0.0;
+        out->rmse = n_used > 0.0 ? sqrt(s_A[27] / (2.0 * n_used)) : 0.0;
         out->iterations = it;
-        out->n_used = n_used;
+        out->n_used = (int32_t)n_used;
     }
 }
 
 hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,
-                             const double* d_K, double huber_a, int max_iter, void* d_out, hipStream_t stream, Profiler* prof)
+                             const double* d_K, double huber_a, int max_iter, void* d_out, hipStream_t stream, Profiler* prof,
+                             const int32_t* d_valid)
 {
     if (N <= 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
-    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, stream, d_Rt_in, d_X, d_x, d_mask, N, d_K, huber_a, max_iter,
-                       (RefineOut*)d_out);
+    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kRefineThreads), 0, stream, d_Rt_in, d_X, d_x, d_mask, N, d_K, huber_a, max_iter,
+                       d_valid, (RefineOut*)d_out);
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
     return hipGetLastError();
 }
@@ -422,6 +455,7 @@ hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const 
 }
 
 size_t pnp_result_bytes() { return sizeof(PnpResult); }
+size_t pnp_result_valid_offset() { return offsetof(PnpResult, h); }
 
 hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,
                                 const double* d_K, double* d_err, hipStream_t stream, Profiler* prof)

@@ -230,6 +230,13 @@ int clc_pnp_refine(clc_ctx* ctx, const double* h_X, const double* h_x, int N, co
                    const uint8_t* h_inlier_mask, const double* h_Rt_in, double huber_a, int max_iter,
                    double* h_Rt_out, double* h_cov, double* rmse, int* iterations);
 
+/* clc_pnp_ransac followed by clc_pnp_refine on its inliers as ONE submission (one upload, chained
+ * kernels, one download): what Localizer::localizeImage does end to end (Localizer.hpp:77-108).
+ * Outputs nullable; *n_inliers == 0 means no pose (h_Rt / h_cov are zero then). */
+int clc_pnp_localize(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
+                     const int32_t* h_samples, int S, uint64_t seed, double thr2, double huber_a,
+                     double* h_Rt, double* h_cov, uint8_t* h_inlier_mask, int* n_inliers, double* rmse);
+
 /* The hypotheses of the minimal solver alone: h_Rt_out receives 4 S x 12 doubles (NaN = no solution). */
 int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                 const int32_t* h_samples, int S, double* h_Rt_out);

@@ -204,3 +204,16 @@ def test_refine_with_huber_tail_and_without_mask(gpu_ctx):
                   for e in np.eye(6) * 1e-6])
     assert np.abs(g).max() < 1e-5 * c                                          # stationary point of the robust cost
     assert np.all(np.linalg.eigvalsh(cov) > 0)
+
+
+def test_localize_equals_ransac_then_refine(gpu_ctx):
+    sc = synth.pnp_scene(1200, seed=4400)
+    rng = np.random.default_rng(2)
+    samples = np.stack([rng.choice(1200, 3, replace=False) for _ in range(256)]).astype(np.int32)
+    Rt0, mask0, _ = gpu_ctx.pnp_ransac(sc["X"], sc["x"], sc["K"], samples=samples, thr2=16.0)
+    Rt1, cov1, rmse1, _ = gpu_ctx.pnp_refine(sc["X"], sc["x"], sc["K"], Rt0, mask=mask0)
+    Rt2, cov2, mask2, rmse2 = gpu_ctx.pnp_localize(sc["X"], sc["x"], sc["K"], samples=samples, thr2=16.0)
+    assert np.array_equal(mask0, mask2) and np.array_equal(Rt1, Rt2) and np.array_equal(cov1, cov2) and rmse1 == rmse2
+    # no pose -> zeros, no crash
+    Rt, cov, mask, rmse = gpu_ctx.pnp_localize(sc["X"][:2], sc["x"][:2], sc["K"])
+    assert Rt is None and not mask.any() and not cov.any()
