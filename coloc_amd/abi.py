@@ -44,7 +44,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize",
+    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -120,6 +120,8 @@ def load_library():
     lib.clc_detect_and_describe.argtypes = [vp, vp, u32, u32, vp, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     lib.clc_pnp_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_uint64, C.c_double, vp, vp, C.POINTER(ci), C.POINTER(C.c_double)]
     lib.clc_pnp_p3p.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp]
+    lib.clc_epipolar_residuals.argtypes = [vp, vp, ci, vp, vp, ci, vp]
+    lib.clc_epipolar_score.argtypes = [vp, vp, ci, vp, vp, ci, C.c_double, vp, vp]
     lib.clc_pnp_localize.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, C.POINTER(ci),
                                      C.POINTER(C.c_double)]
     lib.clc_pnp_refine.argtypes = [vp, vp, vp, ci, vp, vp, vp, C.c_double, ci, vp, vp, C.POINTER(C.c_double), C.POINTER(ci)]
@@ -327,6 +329,22 @@ class Context:
         self._chk(self.lib.clc_pnp_ransac(self.h, _p(X), _p(x), X.shape[0], _p(K), _p(samples), int(n_samples), int(seed),
                                           float(thr2), _p(Rt), _p(mask), C.byref(n), C.byref(cost)))
         return (Rt.reshape(3, 4) if n.value > 0 else None), mask.astype(bool), cost.value
+
+    def epipolar_residuals(self, F, x1, x2):
+        F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, 9)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        err = np.zeros((F.shape[0], x1.shape[0]), dtype=np.float64)
+        self._chk(self.lib.clc_epipolar_residuals(self.h, _p(F), F.shape[0], _p(x1), _p(x2), x1.shape[0], _p(err)))
+        return err
+
+    def epipolar_score(self, F, x1, x2, thr2):
+        F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, 9)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        cnt = np.zeros(F.shape[0], dtype=np.int32); cost = np.zeros(F.shape[0], dtype=np.float64)
+        self._chk(self.lib.clc_epipolar_score(self.h, _p(F), F.shape[0], _p(x1), _p(x2), x1.shape[0], float(thr2), _p(cnt), _p(cost)))
+        return cnt, cost
 
     def pnp_localize(self, X, x, K, samples=None, n_samples=256, seed=1, thr2=16.0, huber_a=16.0):
         """ransac + refine in one submission: (Rt (3,4) or None, cov (6,6), inlier mask, rmse)."""

@@ -770,6 +770,38 @@ int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, co
     return CLC_OK;
 }
 
+static int epipolar_impl(clc_ctx* ctx, const double* h_F, int H, const double* h_x1, const double* h_x2, int N, double thr2,
+                         double* h_err, int32_t* h_count, double* h_cost)
+{
+    if (!ctx || H < 0 || N < 0 || (H > 0 && !h_F) || (N > 0 && (!h_x1 || !h_x2))) return fail(ctx, CLC_ERR_BAD_ARG, "epipolar: bad argument");
+    if (H == 0 || (N == 0 && h_err)) return CLC_OK;
+    if (H > 65535) return fail(ctx, CLC_ERR_CAPACITY, "epipolar: more than 65535 hypotheses per call");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t out = h_err ? (size_t)H * N : (size_t)2 * H;
+    const int rc = ensure_pnp(ctx, (size_t)9 * H + (size_t)4 * N + out + 8);
+    if (rc != CLC_OK) return rc;
+    double* dF = ctx->d_pnp;
+    double* d1 = dF + (size_t)9 * H;
+    double* d2 = d1 + (size_t)2 * N;
+    double* dO = d2 + (size_t)2 * N;
+    CLC_HIP(ctx, hipMemcpyAsync(dF, h_F, sizeof(double) * 9 * H, hipMemcpyHostToDevice, ctx->stream));
+    if (N > 0) {
+        CLC_HIP(ctx, hipMemcpyAsync(d1, h_x1, sizeof(double) * 2 * N, hipMemcpyHostToDevice, ctx->stream));
+        CLC_HIP(ctx, hipMemcpyAsync(d2, h_x2, sizeof(double) * 2 * N, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (h_err) {
+        CLC_HIP(ctx, launch_epipolar(dF, H, d1, d2, N, thr2, dO, nullptr, nullptr, ctx->stream, &ctx->prof));
+        CLC_HIP(ctx, hipMemcpyAsync(h_err, dO, sizeof(double) * (size_t)H * N, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        int32_t* dC = (int32_t*)(dO + H);
+        CLC_HIP(ctx, launch_epipolar(dF, H, d1, d2, N, thr2, nullptr, dC, dO, ctx->stream, &ctx->prof));
+        if (h_cost) CLC_HIP(ctx, hipMemcpyAsync(h_cost, dO, sizeof(double) * H, hipMemcpyDeviceToHost, ctx->stream));
+        if (h_count) CLC_HIP(ctx, hipMemcpyAsync(h_count, dC, sizeof(int32_t) * H, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
 static void draw_samples(uint64_t seed, int S, int N, std::vector<int32_t>& out)
 {
     out.resize((size_t)3 * S);
@@ -858,6 +890,18 @@ static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, i
         if (rmse) *rmse = f.rmse;
     }
     return CLC_OK;
+}
+
+int clc_epipolar_residuals(clc_ctx* ctx, const double* h_F, int H, const double* h_x1, const double* h_x2, int N, double* h_err)
+{
+    if (H > 0 && N > 0 && !h_err) return fail(ctx, CLC_ERR_BAD_ARG, "epipolar_residuals: null output");
+    return epipolar_impl(ctx, h_F, H, h_x1, h_x2, N, 0.0, h_err, nullptr, nullptr);
+}
+
+int clc_epipolar_score(clc_ctx* ctx, const double* h_F, int H, const double* h_x1, const double* h_x2, int N, double thr2,
+                       int32_t* h_count, double* h_cost)
+{
+    return epipolar_impl(ctx, h_F, H, h_x1, h_x2, N, thr2, nullptr, h_count, h_cost);
 }
 
 int clc_pnp_ransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const int32_t* h_samples,

@@ -96,6 +96,9 @@ hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const 
                              int S, double thr2, double* d_Rt, int32_t* d_count, double* d_cost, uint8_t* d_mask,
                              void* d_result, hipStream_t stream, Profiler* prof = nullptr);
 size_t pnp_result_bytes();
+// symmetric epipolar distance of H fundamental matrices: d_err != null -> H x N residuals, else counts / costs
+hipError_t launch_epipolar(const double* d_F, int H, const double* d_x1, const double* d_x2, int N, double thr2, double* d_err,
+                           int32_t* d_count, double* d_cost, hipStream_t stream, Profiler* prof = nullptr);
 // Levenberg-Marquardt refinement of one pose over the (masked) correspondences + 6x6 covariance.
 // d_out: {double Rt[12]; double cov[36]; double cost; double rmse; int32 iterations; int32 n_used}
 hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,

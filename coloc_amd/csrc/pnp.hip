@@ -457,6 +457,64 @@ hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const 
 size_t pnp_result_bytes() { return sizeof(PnpResult); }
 size_t pnp_result_valid_offset() { return offsetof(PnpResult, h); }
 
+// ---- two-view scoring: symmetric epipolar distance of H fundamental matrices ----------
+// The error model RobustMatcher::filterEssential gives AC-RANSAC (reference include/coloc/RobustMatcher.hpp:161-168,
+// openMVG SymmetricEpipolarDistanceError on pixel coordinates with F = K2^-T E K1^-1).  Same batched shape as
+// the PnP scoring: all hypotheses x all correspondences in one launch; operation order = oracle's (exact).
+__device__ __forceinline__ double epipolar_err(const double* __restrict__ f, double u1, double v1, double u2, double v2)
+{
+    const double a0 = (f[0] * u1 + f[1] * v1) + f[2];
+    const double a1 = (f[3] * u1 + f[4] * v1) + f[5];
+    const double a2 = (f[6] * u1 + f[7] * v1) + f[8];
+    const double b0 = (f[0] * u2 + f[3] * v2) + f[6];
+    const double b1 = (f[1] * u2 + f[4] * v2) + f[7];
+    const double d = (u2 * a0 + v2 * a1) + a2;
+    return (d * d) * (1.0 / (a0 * a0 + a1 * a1) + 1.0 / (b0 * b0 + b1 * b1)) / 4.0;
+}
+
+__global__ __launch_bounds__(256) void epipolar_residual_kernel(const double* __restrict__ F, const double* __restrict__ x1,
+                                                                const double* __restrict__ x2, const int N, double* __restrict__ err)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    err[(size_t)blockIdx.y * N + i] = epipolar_err(F + (size_t)9 * blockIdx.y, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]);
+}
+
+__global__ __launch_bounds__(256) void epipolar_score_kernel(const double* __restrict__ F, const double* __restrict__ x1,
+                                                             const double* __restrict__ x2, const int N, const double thr2,
+                                                             int32_t* __restrict__ count, double* __restrict__ cost)
+{
+    __shared__ double s_cost[256];
+    __shared__ int s_cnt[256];
+    const double* f = F + (size_t)9 * blockIdx.x;
+    int cnt = 0;
+    double c = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double e = epipolar_err(f, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]);
+        if (e < thr2) { ++cnt; c += e; }
+        else c += thr2;
+    }
+    s_cost[threadIdx.x] = c;
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { s_cost[threadIdx.x] += s_cost[threadIdx.x + st]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (count) count[blockIdx.x] = s_cnt[0]; if (cost) cost[blockIdx.x] = s_cost[0]; }
+}
+
+hipError_t launch_epipolar(const double* d_F, int H, const double* d_x1, const double* d_x2, int N, double thr2, double* d_err,
+                           int32_t* d_count, double* d_cost, hipStream_t stream, Profiler* prof)
+{
+    if (H <= 0 || N <= 0) return hipSuccess;
+    prof_mark(prof, CLC_KERNEL_PNP_RESIDUALS, true, stream);
+    if (d_err) hipLaunchKernelGGL(epipolar_residual_kernel, dim3((N + 255) / 256, H), dim3(256), 0, stream, d_F, d_x1, d_x2, N, d_err);
+    else hipLaunchKernelGGL(epipolar_score_kernel, dim3(H), dim3(256), 0, stream, d_F, d_x1, d_x2, N, thr2, d_count, d_cost);
+    prof_mark(prof, CLC_KERNEL_PNP_RESIDUALS, false, stream);
+    return hipGetLastError();
+}
+
 hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x, int N,
                                 const double* d_K, double* d_err, hipStream_t stream, Profiler* prof)
 {

@@ -208,6 +208,16 @@ int clc_pnp_residuals(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X
 int clc_pnp_score(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, const double* h_x,
                   int N, const double* h_K, double thr2, int32_t* h_count, double* h_cost);
 
+/* ---- two-view scoring: the data-parallel core of RobustMatcher::filterEssential -------------------
+ * (RobustMatcher.hpp:153-186: AC-RANSAC over FivePointSolver + SymmetricEpipolarDistanceError.)
+ * h_F: H x 9 row-major FUNDAMENTAL matrices (F = K2^-T E K1^-1); h_x1 / h_x2: N x 2 pixel points of the
+ * two views.  err[h*N+i] = (x2^T F x1)^2 (1/|(F x1)_xy|^2 + 1/|(F^T x2)_xy|^2) / 4, fp64.  The minimal
+ * solver stays with the caller (OpenMVG's, when linked in): generate all hypotheses, score once. */
+int clc_epipolar_residuals(clc_ctx* ctx, const double* h_F, int H, const double* h_x1, const double* h_x2,
+                           int N, double* h_err);
+int clc_epipolar_score(clc_ctx* ctx, const double* h_F, int H, const double* h_x1, const double* h_x2, int N,
+                       double thr2, int32_t* h_count, double* h_cost);
+
 /* Whole robust pose solve on the GPU -- the role of SfM_Localizer::Localize(P3P, max_iteration = 256)
  * at Localizer.hpp:82-93: S minimal samples -> one P3P problem per lane (<= 4 poses each) -> all
  * 4 S hypotheses scored over all N correspondences in one launch -> best = most inliers (err < thr2),

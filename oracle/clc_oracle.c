@@ -445,3 +445,24 @@ void orc_pnp_score(const double* err, int H, int N, double thr2, int32_t* count_
         if (cost_out) cost_out[h] = cost;
     }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* two-view scoring                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+void orc_epipolar_residuals(const double* F, int H, const double* x1, const double* x2, int N, double* err_out)
+{
+    for (int h = 0; h < H; ++h) {
+        const double* f = F + (size_t)9 * h;
+        for (int i = 0; i < N; ++i) {
+            const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+            const double a0 = (f[0] * u1 + f[1] * v1) + f[2];      /* F x1 */
+            const double a1 = (f[3] * u1 + f[4] * v1) + f[5];
+            const double a2 = (f[6] * u1 + f[7] * v1) + f[8];
+            const double b0 = (f[0] * u2 + f[3] * v2) + f[6];      /* F^T x2 */
+            const double b1 = (f[1] * u2 + f[4] * v2) + f[7];
+            const double d = (u2 * a0 + v2 * a1) + a2;             /* x2^T F x1 */
+            err_out[(size_t)h * N + i] = (d * d) * (1.0 / (a0 * a0 + a1 * a1) + 1.0 / (b0 * b0 + b1 * b1)) / 4.0;
+        }
+    }
+}

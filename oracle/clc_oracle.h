@@ -122,6 +122,14 @@ void orc_pnp_residuals(const double* Rt, int H, const double* X, const double* x
 void orc_pnp_score(const double* err, int H, int N, double thr2, int32_t* count_out,
                    double* cost_out);
 
+/* ---- two-view scoring (include/coloc/RobustMatcher.hpp:153-186) ---------- */
+
+/* Symmetric epipolar distance of H fundamental matrices (row-major 9) over N pixel correspondences,
+ * the error model RobustMatcher::filterEssential hands to AC-RANSAC
+ * (openMVG::fundamental::kernel::SymmetricEpipolarDistanceError; OpenMVG is absent, formula restated
+ * from its published definition): e = (x2^T F x1)^2 (1/|(F x1)_xy|^2 + 1/|(F^T x2)_xy|^2) / 4. */
+void orc_epipolar_residuals(const double* F, int H, const double* x1, const double* x2, int N, double* err_out);
+
 #ifdef __cplusplus
 }
 #endif

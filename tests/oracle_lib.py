@@ -141,6 +141,14 @@ class Oracle:
         self.lib.orc_pnp_residuals(_ptr(Rt), C.c_int(H), _ptr(X), _ptr(x), C.c_int(N), _ptr(K), _ptr(err))
         return err
 
+    def epipolar_residuals(self, F, x1, x2):
+        F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, 9)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        err = np.zeros((F.shape[0], x1.shape[0]), dtype=np.float64)
+        self.lib.orc_epipolar_residuals(_ptr(F), C.c_int(F.shape[0]), _ptr(x1), _ptr(x2), C.c_int(x1.shape[0]), _ptr(err))
+        return err
+
     def pnp_score(self, err, thr2):
         err = np.ascontiguousarray(err, dtype=np.float64)
         H, N = err.shape
