@@ -65,6 +65,8 @@ void orc_k2nn_split(const uint8_t* q, int nq, const uint8_t* t, int nt, int thre
  * Returns the number of threads used. */
 int orc_k2nn_omp(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule, int threshold,
                  float ratio, int32_t* match_out);
+/* which inner loop the baseline uses on this CPU: "avx512-vpopcntdq" or "scalar popcnt64" */
+const char* orc_k2nn_omp_kernel(void);
 
 /* ---- pyramid (include/coloc/GPUDetector.hpp:109-114,249-254; src/CUDALERP.cu:157-178) --- */
 

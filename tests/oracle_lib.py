@@ -32,6 +32,7 @@ class Oracle:
             build_oracle()
         self.lib = C.CDLL(path)
         self.lib.orc_k2nn_omp.restype = C.c_int
+        self.lib.orc_k2nn_omp_kernel.restype = C.c_char_p
         self.lib.orc_fast9.restype = C.c_int
         self.lib.orc_feature_angle.restype = C.c_float
         self.lib.orc_latch_pattern.restype = C.POINTER(C.c_uint8)
@@ -54,6 +55,9 @@ class Oracle:
         self.lib.orc_k2nn_split(_ptr(Q), C.c_int(Q.shape[0]), _ptr(T), C.c_int(T.shape[0]),
                                 C.c_int(int(threshold)), C.c_int(int(nsplit)), _ptr(m))
         return m
+
+    def k2nn_omp_kernel(self):
+        return self.lib.orc_k2nn_omp_kernel().decode()
 
     def k2nn_omp(self, Q, T, rule=0, threshold=40, ratio=0.8):
         Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
