@@ -33,24 +33,34 @@ HBM_PEAK_GBS = 8000.0
 
 
 def cpu_baseline(desc_q, desc_t):
-    """The oracle's OpenMP brute-force matcher (restated OpenMVG BRUTE_FORCE_HAMMING top-2) on the same
-    10k x 10k pair, all host cores; the CHECKER timed as a baseline, never the product path."""
-    import numpy as np
+    """The oracle's OpenMP brute-force matcher on the same 10k x 10k pair, all host cores; the CHECKER timed as a
+    baseline, never the product path.  `value` is the loop BASELINE.md section 2 specifies (restated OpenMVG
+    BRUTE_FORCE_HAMMING: 8 x __builtin_popcountll per pair, running top-2, OpenMP over queries); the best-effort
+    AVX-512 VPOPCNTDQ variant of the same matcher is reported beside it."""
     import oracle_lib
     orc = oracle_lib.Oracle()
-    best = None
-    nthr = 1
-    reps = 5
-    for _ in range(reps):
-        t0 = time.perf_counter()
-        _, nthr = orc.k2nn_omp(desc_q, desc_t, rule=0, threshold=THR)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    cmp_per_s = desc_q.shape[0] * desc_t.shape[0] / best
-    return {"value": cmp_per_s / 1e6, "unit": "Mmatches/s", "cores": int(nthr), "kind": "port",
-            "sample": "full %d x %d pair, K2NN acceptance rule, best of %d (%.3f s each), inner loop: %s"
-                      % (desc_q.shape[0], desc_t.shape[0], reps, best, orc.k2nn_omp_kernel()),
-            "cpu_count": os.cpu_count()}
+    reps = 7
+
+    def best_of(kernel):
+        best, nthr = None, 1
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            _, nthr = orc.k2nn_omp(desc_q, desc_t, rule=0, threshold=THR, kernel=kernel)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, nthr
+
+    n_cmp = desc_q.shape[0] * desc_t.shape[0]
+    t_scalar, nthr = best_of(0)
+    out = {"value": n_cmp / t_scalar / 1e6, "unit": "Mmatches/s", "cores": int(nthr), "kind": "port",
+           "sample": "full %d x %d pair, K2NN acceptance rule, best of %d (%.4f s each), 8 x popcount64 per pair (BASELINE.md plan)"
+                     % (desc_q.shape[0], desc_t.shape[0], reps, t_scalar),
+           "cpu_count": os.cpu_count()}
+    if orc.avx512_available():
+        t_simd, _ = best_of(1)
+        out["best_effort_simd"] = {"value": n_cmp / t_simd / 1e6, "unit": "Mmatches/s",
+                                   "what": "same matcher, AVX-512 VPOPCNTDQ transposing inner loop (%.4f s)" % t_simd}
+    return out
 
 
 def main():
@@ -269,6 +279,8 @@ def main():
             dt_ = arena[1].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(dq, dt_)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if "best_effort_simd" in out["cpu_baseline"]:
+                out["gpu_over_cpu_best_effort_simd"] = out["value"] / out["cpu_baseline"]["best_effort_simd"]["value"]
         print(json.dumps(out))
     ctx.close()
     if world > 1:

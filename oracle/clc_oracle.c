@@ -228,9 +228,26 @@ const char* orc_k2nn_omp_kernel(void) { return k2nn_pick_kernel() ? "avx512-vpop
 int orc_k2nn_omp(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule, int threshold,
                  float ratio, int32_t* match_out)
 {
+    return orc_k2nn_omp_ex(q, nq, t, nt, rule, threshold, ratio, -1, match_out);
+}
+
+int orc_k2nn_avx512_available(void)
+{
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vpopcntdq");
+#else
+    return 0;
+#endif
+}
+
+/* kernel: 0 = the 8 x __builtin_popcountll loop BASELINE.md section 2 specifies ("OpenMVG-equivalent
+ * (restated)"), 1 = AVX-512 VPOPCNTDQ (falls back to 0 when the CPU lacks it), -1 = whichever is faster here. */
+int orc_k2nn_omp_ex(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule, int threshold,
+                    float ratio, int kernel, int32_t* match_out)
+{
     const int thr = (int)(uint8_t)threshold;
     const float r2 = ratio * ratio;
-    const int wide = k2nn_pick_kernel();
+    const int wide = kernel < 0 ? k2nn_pick_kernel() : (kernel == 1 && orc_k2nn_avx512_available());
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();

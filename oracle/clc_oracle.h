@@ -65,8 +65,13 @@ void orc_k2nn_split(const uint8_t* q, int nq, const uint8_t* t, int nt, int thre
  * Returns the number of threads used. */
 int orc_k2nn_omp(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule, int threshold,
                  float ratio, int32_t* match_out);
-/* which inner loop the baseline uses on this CPU: "avx512-vpopcntdq" or "scalar popcnt64" */
+/* which inner loop the auto-selection uses on this CPU */
 const char* orc_k2nn_omp_kernel(void);
+/* explicit inner loop: 0 = 8 x __builtin_popcountll per pair ("OpenMVG-equivalent
+ * (restated)"), 1 = AVX-512 VPOPCNTDQ best effort (falls back to 0 if absent), -1 = auto */
+int orc_k2nn_omp_ex(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule, int threshold,
+                    float ratio, int kernel, int32_t* match_out);
+int orc_k2nn_avx512_available(void);
 
 /* ---- pyramid (include/coloc/GPUDetector.hpp:109-114,249-254; src/CUDALERP.cu:157-178) --- */
 

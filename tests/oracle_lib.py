@@ -59,13 +59,18 @@ class Oracle:
     def k2nn_omp_kernel(self):
         return self.lib.orc_k2nn_omp_kernel().decode()
 
-    def k2nn_omp(self, Q, T, rule=0, threshold=40, ratio=0.8):
+    def k2nn_omp(self, Q, T, rule=0, threshold=40, ratio=0.8, kernel=-1):
+        """kernel: 0 = 8 x popcount64 per pair, 1 = AVX-512 VPOPCNTDQ, -1 = auto."""
         Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
         T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 64)
         m = np.empty(Q.shape[0], dtype=np.int32)
-        nthr = self.lib.orc_k2nn_omp(_ptr(Q), C.c_int(Q.shape[0]), _ptr(T), C.c_int(T.shape[0]),
-                                     C.c_int(rule), C.c_int(int(threshold)), C.c_float(ratio), _ptr(m))
+        self.lib.orc_k2nn_omp_ex.restype = C.c_int
+        nthr = self.lib.orc_k2nn_omp_ex(_ptr(Q), C.c_int(Q.shape[0]), _ptr(T), C.c_int(T.shape[0]), C.c_int(rule),
+                                        C.c_int(int(threshold)), C.c_float(ratio), C.c_int(kernel), _ptr(m))
         return m, nthr
+
+    def avx512_available(self):
+        return bool(self.lib.orc_k2nn_avx512_available())
 
     # -- pyramid
     def pyramid_dims(self, W, H, scale_factor=1.2, levels=8):

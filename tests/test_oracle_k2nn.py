@@ -96,6 +96,17 @@ def test_split_merge_is_exact(oracle, nsplit):
         assert np.array_equal(oracle.k2nn_split(Q, T, thr, nsplit), oracle.k2nn(Q, T, thr))
 
 
+def test_omp_baseline_kernels_agree(oracle):
+    """The scalar-popcount loop (BASELINE.md plan), the AVX-512 VPOPCNTDQ loop (if this CPU has it) and the
+    auto-selected one all equal the sequential oracle, including tails that are not multiples of 8."""
+    for nt in (1, 7, 8, 9, 250, 1001):
+        Q, T = synth.planted_descriptors(333, nt, seed=100 + nt)
+        want = oracle.k2nn(Q, T, 40)
+        for kernel in (0, 1, -1):
+            m, _ = oracle.k2nn_omp(Q, T, rule=0, threshold=40, kernel=kernel)
+            assert np.array_equal(m, want), (nt, kernel)
+
+
 def test_omp_baseline_matches_k2nn_rule(oracle):
     Q, T = synth.planted_descriptors(500, 800, seed=5)
     m, nthr = oracle.k2nn_omp(Q, T, rule=0, threshold=40)

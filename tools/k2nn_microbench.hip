@@ -52,6 +52,33 @@ __device__ __forceinline__ void sweep_one_paired(const uint32_t (&q)[R][16], con
     }
 }
 
+// paired asm, the R chains interleaved word by word (ILP inside one wave), optional second accumulator
+template <int R, int NACC>
+__device__ __forceinline__ void sweep_one_paired_il(const uint32_t (&q)[R][16], const u32x4 a, const u32x4 b, const u32x4 c, const u32x4 d,
+                                                    const uint32_t t_rel, uint32_t (&best)[R], uint32_t (&second)[R])
+{
+    const uint32_t tw[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+    uint32_t acc[R][NACC], tmp;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) acc[r][n] = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            asm volatile("v_xor_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[r][k % NACC]), "=&v"(tmp) : "v"(q[r][k]), "v"(tw[k]));
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t d0 = acc[r][0];
+#pragma unroll
+        for (int n = 1; n < NACC; ++n) d0 += acc[r][n];
+        const uint32_t key = (d0 << 22) + t_rel;
+        second[r] = umed3(best[r], second[r], key);
+        best[r] = min(best[r], key);
+    }
+}
+
 // MODE 0: plain loop (s_load, wait, compute).  MODE 1: no loads in the loop (VALU ceiling).
 // MODE 2: explicit double buffer: wait, issue next s_load, compute current.
 template <int R, int WAVES, int MODE>
@@ -169,6 +196,61 @@ __global__ __launch_bounds__(64 * WAVES) void sweep_lds(const u32x4* __restrict_
 
 static unsigned long long g_checksum = 0;
 static constexpr int kMaxSplits = 1024;   // capacity of the partial buffer, in split rows
+// MODE 6/7: WAVE-PRIVATE LDS staging (no workgroup barrier): each wave pulls 16 train vectors with one coalesced
+// global_load_dwordx4, parks them in its own 2 x 1 KiB LDS ring and broadcast-reads them into VGPRs, so v_xor_b32
+// runs in its 2-cycle VGPR form directly followed by the dependent v_bcnt (paired asm).
+template <int R, int WAVES, int VAR = 0>
+__global__ __launch_bounds__(64 * WAVES) void sweep_wlds(const u32x4* __restrict__ Q, int nq, const u32x4* __restrict__ T, int nt,
+                                                        int splits, int t_per_split, u32x2* __restrict__ partial, int nq_pad)
+{
+    __shared__ u32x4 ring[WAVES][2][64];
+    const uint32_t qblock = blockIdx.x / splits;
+    const uint32_t split = blockIdx.x - qblock * splits;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t qbase = qblock * (64u * R * WAVES) + wave * (64u * R) + lane;
+    uint32_t q[R][16];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t qi = qbase + 64u * r; if (qi >= (uint32_t)nq) qi = nq - 1;
+        const global_cu4_ptr qp = (global_cu4_ptr)(uintptr_t)Q + (size_t)qi * 4u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const u32x4 v = qp[k]; q[r][4*k] = v.x; q[r][4*k+1] = v.y; q[r][4*k+2] = v.z; q[r][4*k+3] = v.w; }
+    }
+    uint32_t best[R], second[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best[r] = 0xFFFFFFFFu; second[r] = 0xFFFFFFFFu; }
+    const uint32_t t0 = split * t_per_split;
+    uint32_t t1 = t0 + t_per_split; if (t1 > (uint32_t)nt) t1 = nt;
+    const global_cu4_ptr tg = (global_cu4_ptr)(uintptr_t)T;
+    const uint32_t ntile = (t1 - t0 + 15u) / 16u;
+    auto gload = [&](uint32_t ti) {
+        uint32_t row = t0 + ti * 16u + (lane >> 2);
+        if (row >= t1) row = t1 - 1u;
+        return tg[(size_t)row * 4u + (lane & 3u)];
+    };
+    u32x4 stage = gload(0);
+    for (uint32_t ti = 0; ti < ntile; ++ti) {
+        u32x4* buf = ring[wave][ti & 1u];
+        buf[lane] = stage;                                       // ds_write_b128, wave-private: no barrier needed
+        if (ti + 1 < ntile) stage = gload(ti + 1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t base = t0 + ti * 16u;
+        const uint32_t cnt = min(16u, t1 - base);
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const u32x4 a = buf[j * 4], b = buf[j * 4 + 1], c = buf[j * 4 + 2], d = buf[j * 4 + 3];
+            if (VAR == 0) sweep_one_paired<R>(q, a, b, c, d, base + j - t0, best, second);
+            else if (VAR == 1) sweep_one_paired_il<R, 1>(q, a, b, c, d, base + j - t0, best, second);
+            else sweep_one_paired_il<R, 2>(q, a, b, c, d, base + j - t0, best, second);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    u32x2 __attribute__((address_space(1)))* prow = (u32x2 __attribute__((address_space(1)))*)(uintptr_t)partial + (size_t)split * nq_pad;
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const uint32_t qi = qbase + 64u * r; if (qi < (uint32_t)nq) prow[qi] = u32x2{ best[r], second[r] }; }
+}
+
 template <int R, int WAVES, int MODE>
 float run(const u32x4* dQ, int nq, const u32x4* dT, int nt, int target_blocks, u32x2* dP, int reps, int* out_splits)
 {
@@ -183,6 +265,9 @@ float run(const u32x4* dQ, int nq, const u32x4* dT, int nt, int target_blocks, u
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     auto launch = [&]() {
         if (MODE == 3) hipLaunchKernelGGL((sweep_lds<R, WAVES, 64>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+        else if (MODE == 7) hipLaunchKernelGGL((sweep_wlds<R, WAVES, 1>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+        else if (MODE == 8) hipLaunchKernelGGL((sweep_wlds<R, WAVES, 2>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+        else if (MODE == 6) hipLaunchKernelGGL((sweep_wlds<R, WAVES>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
         else if (MODE == 5) hipLaunchKernelGGL((sweep_lds<R, WAVES, 64, true>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
         else if (MODE == 4) hipLaunchKernelGGL((sweep_lds<R, WAVES, 32>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
         else hipLaunchKernelGGL((sweep<R, WAVES, (MODE > 2 ? 0 : MODE)>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
@@ -221,16 +306,18 @@ int main(int argc, char** argv)
     CHECK(hipMemcpy(dQ, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dT, ht.data(), ht.size() * 4, hipMemcpyHostToDevice));
     const double cmp = (double)nq * nt;
-    const int targets[] = { 2048, 4096, 8192 };
+    const int targets[] = { 2048, 4096 };
     printf("%-28s %8s %7s %9s %9s\n", "variant", "target", "splits", "us", "Gcmp/s");
 #define RUN(R, WV, MODE, name) for (int tb : targets) { int sp; float ms = run<R, WV, MODE>(dQ, nq, dT, nt, tb, dP, 15, &sp); \
         printf("%-28s %8d %7d %9.1f %9.1f  cs %016llx\n", name, tb, sp, ms * 1e3, cmp / (ms * 1e-3) / 1e9, g_checksum); }
-    RUN(2, 4, 0, "R2 W4 plain (sgpr)");
     RUN(2, 4, 2, "R2 W4 prefetch (sgpr)");
-    RUN(2, 4, 3, "R2 W4 lds TT64");
-    RUN(2, 4, 5, "R2 W4 lds paired-asm");
-    RUN(1, 4, 5, "R1 W4 lds paired-asm");
-    RUN(4, 4, 5, "R4 W4 lds paired-asm");
-    RUN(3, 4, 5, "R3 W4 lds paired-asm");
+    RUN(2, 4, 6, "R2 W4 wave-lds paired");
+    RUN(2, 4, 7, "R2 W4 wave-lds paired interleaved");
+    RUN(2, 4, 8, "R2 W4 wave-lds paired il 2acc");
+    RUN(4, 4, 7, "R4 W4 wave-lds paired interleaved");
+    RUN(4, 4, 8, "R4 W4 wave-lds paired il 2acc");
+    RUN(3, 4, 7, "R3 W4 wave-lds paired interleaved");
+    RUN(2, 8, 7, "R2 W8 wave-lds paired interleaved");
+    RUN(1, 4, 8, "R1 W4 wave-lds paired il 2acc");
     return 0;
 }
