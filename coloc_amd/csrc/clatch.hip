@@ -56,23 +56,24 @@ static constexpr uint16_t patch_lds_addr(int row, int col)
     return (uint16_t)(kCopyBase[p & 3] + (p & ~3));
 }
 struct SlotTable {
-    uint16_t addr[512][4];   // per slot: LDS addresses of patches a, b, c (+ pad)
-    uint16_t src[512];       // per OUTPUT bit n: (source lane * 4) | (source round << 8)
+    // rec[round*64 + lane] = {a, b, c, src}: LDS addresses of the slot's patches a, b, c, and -- for the OUTPUT
+    // bit n = round*64 + lane -- where that bit was computed: (source lane * 4) | (source round << 8).
+    // 8 bytes per record: one global_load_dwordx2 per round and lane.
+    uint16_t rec[512][4];
 };
 static constexpr SlotTable make_slot_table()
 {
     SlotTable t{};
     for (int slot = 0; slot < 512; ++slot) {
         const int n = k_slot_triplet[slot];
-        t.addr[slot][0] = patch_lds_addr(k_pattern[n].v[0], k_pattern[n].v[1]);
-        t.addr[slot][1] = patch_lds_addr(k_pattern[n].v[2], k_pattern[n].v[3]);
-        t.addr[slot][2] = patch_lds_addr(k_pattern[n].v[4], k_pattern[n].v[5]);
-        t.addr[slot][3] = 0;
-        t.src[n] = (uint16_t)(((slot & 63) << 2) | ((slot >> 6) << 8));
+        t.rec[slot][0] = patch_lds_addr(k_pattern[n].v[0], k_pattern[n].v[1]);
+        t.rec[slot][1] = patch_lds_addr(k_pattern[n].v[2], k_pattern[n].v[3]);
+        t.rec[slot][2] = patch_lds_addr(k_pattern[n].v[4], k_pattern[n].v[5]);
+        t.rec[n][3] = (uint16_t)(((slot & 63) << 2) | ((slot >> 6) << 8));
     }
     return t;
 }
-__device__ const SlotTable k_slots = make_slot_table();
+__device__ __attribute__((aligned(16))) const SlotTable k_slots = make_slot_table();
 
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     uint32_t pa[8], pb[8], pc[8], src[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint16_t* e = k_slots.addr[j * 64 + lane];
-        pa[j] = e[0]; pb[j] = e[1]; pc[j] = e[2];
-        src[j] = k_slots.src[j * 64 + lane];
+        const uint2 e = *reinterpret_cast<const uint2*>(k_slots.rec[j * 64 + lane]);
+        pa[j] = e.x & 0xFFFFu; pb[j] = e.x >> 16; pc[j] = e.y & 0xFFFFu;
+        src[j] = e.y >> 16;
     }
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
 
