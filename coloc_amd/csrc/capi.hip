@@ -278,10 +278,11 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         CREATE_HIP(hipMalloc((void**)&ctx->d_best, cap * sizeof(uint16_t)));
         CREATE_HIP(hipMalloc((void**)&ctx->d_second, cap * sizeof(uint16_t)));
     }
-    // partial workspace: enough for one maxkp x maxkp pair at the target split count
+    // K2NN workspace: one armed {best, second} row per query suffices in atomic mode (a few pairs' worth
+    // here); the slab fallback for train sets > 2^22 and larger job lists grow it on demand
     {
         const size_t cap = dopts || mopts ? (size_t)(mopts ? mopts->maxkp : dopts->maxkp) : 16384;
-        const size_t elems = ((cap + 63) & ~(size_t)63) * 128 + 4096;
+        const size_t elems = ((cap + 63) & ~(size_t)63) * 8 + 4096;
         CREATE_HIP(hipMalloc((void**)&ctx->d_partial, elems * sizeof(uint2)));
         CREATE_HIP(hipMemsetAsync(ctx->d_partial, 0xFF, elems * sizeof(uint2), ctx->stream));   // armed top-2 rows
         ctx->partial_cap = elems;
