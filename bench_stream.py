@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench_stream.py -- BASELINE config[4] shaped run: cameras streaming synthetic video through the whole
+loop describe -> match against the map -> robust pose + covariance -> covariance-intersection fusion.
+
+NOT the driver's benchmark (that is bench.py); this is the scenario harness for the streaming
+configuration.  One camera per rank (python -m torch.distributed.run --nproc-per-node N bench_stream.py
+--gpus N); with N = 1 it runs `--cams` cameras round-robin on the one GPU.
+
+Per frame and camera (reference include/coloc/coloc.hpp:201-272 intraPoseEstimator + :362-389 fusion):
+  1. front end on the frame image, device-resident: pyramid -> FAST-9/NMS/orientation -> CLATCH
+     (timing realism: the synthetic frames carry no geometry, so these descriptors are not matched);
+  2. map tracking: the frame's observed descriptors (map descriptors with bit noise + distractors) against the
+     map on the GPU, threshold MatcherOptions.thresh = 60 -> 2D-3D correspondences (GPUMatcher.hpp:174-178,252-271);
+  3. clc_pnp_localize: 256 P3P samples -> scored hypotheses -> LM refinement + 6x6 covariance;
+  4. fusion: each camera's position is fused with its neighbour's estimate of it (here: the neighbour's own
+     error-free relative offset, so the fused value can be checked) by covariance intersection.
+Reports frames/s per camera, per-stage p50 latencies and the position error against ground truth.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def rot_y(a):
+    import numpy as np
+    return np.array([[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--cams", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=90)      # 3 s at 30 fps
+    ap.add_argument("--map-points", type=int, default=4000)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import synth
+    from coloc_amd import Context, cov_intersection
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    my_cams = list(range(args.cams)) if world == 1 else [rank]
+    n_cams = args.cams if world == 1 else world
+
+    W, H, M = 1280, 720, args.map_points
+    ctx = Context(device=local_rank, width=W, height=H, maxkp=20000, match_thresh=60)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    sptr = stream.cuda_stream
+
+    rng = np.random.default_rng(7)
+    Xw = np.stack([rng.uniform(-6, 6, M), rng.uniform(-4, 4, M), rng.uniform(6, 22, M)], 1)     # map landmarks
+    map_desc = rng.integers(0, 256, size=(M, 64), dtype=np.uint8)
+    ctx.set_map(map_desc)                                                                        # GPUMatcher::setMapData
+    K = np.array([[1000.0, 0, W / 2], [0, 1000.0, H / 2], [0, 0, 1]])
+    frames = [torch.from_numpy(synth.rect_image(W, H, seed=1000 + c, noise_sigma=2.0)).to(dev) for c in my_cams]
+
+    def pose_of(cam, f):
+        """smooth known trajectory: cameras on an arc, slowly orbiting"""
+        a = (cam - (n_cams - 1) / 2) * 0.12 + 0.2 * math.sin(2 * math.pi * f / 300.0)
+        C = np.array([2.5 * math.sin(a), 0.15 * cam, 2.5 - 2.5 * math.cos(a)])
+        R = rot_y(-0.5 * a)
+        return R, -R @ C, C
+
+    lat = {"front_end": [], "match": [], "pose": [], "fuse": [], "frame": []}
+    pos_err, pos_err_fused, n_inl = [], [], []
+    est = {}
+    t_start = time.perf_counter()
+    for f in range(args.frames):
+        for k, cam in enumerate(my_cams):
+            t0 = time.perf_counter()
+            # 1. front end (device-resident)
+            ctx.pyramid_build_dev(frames[k].data_ptr(), W, H, W, sptr)
+            ctx.detect_dev(sptr)
+            ctx.describe_detected_dev(None, sptr)
+            ctx.sync(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            # 2. observed descriptors of this frame: visible landmarks with bit noise + 30 % distractors
+            R, t, C = pose_of(cam, f)
+            Xc = Xw @ R.T + t
+            uv = (Xc @ K.T); uv = uv[:, :2] / uv[:, 2:3]
+            vis = np.nonzero((Xc[:, 2] > 0.5) & (uv[:, 0] >= 0) & (uv[:, 0] < W) & (uv[:, 1] >= 0) & (uv[:, 1] < H))[0]
+            frng = np.random.default_rng(100000 * cam + f)
+            # bit noise: each of the 512 bits flips with probability p_i, p_i ~ U(0, 30/512) per keypoint
+            p_flip = frng.uniform(0, 30.0 / 512.0, (len(vis), 1))
+            noise = np.packbits(frng.random((len(vis), 512)) < p_flip, axis=1)
+            obs = map_desc[vis] ^ noise
+            n_dis = int(0.3 * len(vis))
+            q = np.concatenate([obs, frng.integers(0, 256, size=(n_dis, 64), dtype=np.uint8)])
+            xy = np.concatenate([uv[vis] + frng.normal(0, 0.5, (len(vis), 2)),
+                                 np.stack([frng.uniform(0, W, n_dis), frng.uniform(0, H, n_dis)], 1)])
+            t1b = time.perf_counter()
+            m = ctx.match_map(q, 60)                     # train = map: m[i] = map index or -1  (IndMatch(map, query))
+            t2 = time.perf_counter()
+            sel = np.nonzero(m >= 0)[0]
+            # 3. robust pose + refinement + covariance
+            Rt, cov, mask, rmse = ctx.pnp_localize(Xw[m[sel]], xy[sel], K, n_samples=256, seed=f + 1, thr2=16.0)
+            t3 = time.perf_counter()
+            if Rt is None:
+                continue
+            Ce = -Rt[:, :3].T @ Rt[:, 3]
+            # covariance of the centre: J = -R^T on the translation block (rotation part neglected, like the
+            # reference, which fuses the translation block only: colocUtils.hpp:38-43)
+            Cc = Rt[:, :3].T @ cov[3:, 3:] @ Rt[:, :3]
+            est[cam] = (Ce, Cc, C)
+            lat["front_end"].append(t1 - t0); lat["match"].append(t2 - t1b); lat["pose"].append(t3 - t2)
+            lat["frame"].append((t1 - t0) + (t3 - t1b))
+            pos_err.append(np.linalg.norm(Ce - C)); n_inl.append(int(mask.sum()))
+        # 4. fusion across cameras (positions + 3x3 covariances are tiny: gathered on the host side here)
+        if world > 1:
+            mine = est.get(rank)
+            buf = torch.zeros(15, dtype=torch.float64, device=dev)
+            if mine is not None:
+                buf[:3] = torch.from_numpy(mine[0]); buf[3:12] = torch.from_numpy(mine[1].reshape(9)); buf[12:15] = torch.from_numpy(mine[2])
+            allb = torch.zeros((world, 15), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(allb.view(-1), buf)
+            allb = allb.cpu().numpy()
+            est = {c: (allb[c, :3], allb[c, 3:12].reshape(3, 3), allb[c, 12:15]) for c in range(world) if allb[c, 3:12].any()}
+        for cam in my_cams:
+            nb = (cam + 1) % n_cams
+            if cam not in est or nb not in est or nb == cam:
+                continue
+            t4 = time.perf_counter()
+            Ce, Cc, Cgt = est[cam]
+            Cn, Ccn, Cngt = est[nb]
+            rel = Cgt - Cngt                                   # the neighbour's (here: exact) relative measurement
+            om, Cf, pf = cov_intersection(Cc, Ccn + 1e-6 * np.eye(3), Ce, Cn + rel)
+            lat["fuse"].append(time.perf_counter() - t4)
+            pos_err_fused.append(np.linalg.norm(pf - Cgt))
+    wall = time.perf_counter() - t_start
+    if rank == 0:
+        p50 = lambda v: float(np.median(v) * 1e3) if len(v) else None
+        out = {"scenario": "config[4]-shaped streaming loop, %d camera(s) on this rank, %d ranks" % (len(my_cams), world),
+               "frames_per_camera": args.frames, "map_points": M,
+               "camera_frames_per_s_per_gpu_timed_stages": (1000.0 / p50(lat["frame"])) if lat["frame"] else None,
+               "cameras_at_30fps_per_gpu": (1000.0 / p50(lat["frame"]) / 30.0) if lat["frame"] else None,
+               "wall_s_including_host_side_synthesis": wall,
+               "required": "30 fps per camera (config[4]: 8 cameras on 8 GPUs)",
+               "p50_ms": {k: p50(v) for k, v in lat.items()},
+               "inliers_p50": float(np.median(n_inl)) if n_inl else None,
+               "position_error_p50": float(np.median(pos_err)) if pos_err else None,
+               "position_error_fused_p50": float(np.median(pos_err_fused)) if pos_err_fused else None,
+               "note": "host-side synthesis of the observed descriptors is outside the timed stages"}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

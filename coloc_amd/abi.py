@@ -44,7 +44,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score",
+    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -135,6 +135,19 @@ def load_library():
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def cov_intersection(CA, CB, ca, cb):
+    """Host-side covariance intersection: returns (omega, fused 3x3 covariance, fused position)."""
+    lib = load_library()
+    CA = np.ascontiguousarray(CA, dtype=np.float64).reshape(9); CB = np.ascontiguousarray(CB, dtype=np.float64).reshape(9)
+    ca = np.ascontiguousarray(ca, dtype=np.float64).reshape(3); cb = np.ascontiguousarray(cb, dtype=np.float64).reshape(3)
+    om = C.c_double(); cov = np.zeros(9); pos = np.zeros(3)
+    lib.clc_cov_intersection.argtypes = [C.c_void_p] * 4 + [C.POINTER(C.c_double), C.c_void_p, C.c_void_p]
+    rc = lib.clc_cov_intersection(_p(CA), _p(CB), _p(ca), _p(cb), C.byref(om), _p(cov), _p(pos))
+    if rc != CLC_OK:
+        raise CLCError(rc, lib.clc_status_string(rc).decode())
+    return om.value, cov.reshape(3, 3), pos
 
 
 def keypoints_to_features(kps):

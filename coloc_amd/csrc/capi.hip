@@ -7,6 +7,7 @@
 // texture object per frame / per match call, GPUDetector.hpp:240,244, GPUMatcher.hpp:198-201), one
 // stream per context, every HIP status checked and mapped to an int code.
 #include "clc_internal.h"
+#include "../host/HIPCovIntersection.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -968,6 +969,24 @@ int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const
 {
     if (!h_samples || !h_Rt_out) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_p3p: bad argument");
     return pnp_ransac_impl(ctx, h_X, h_x, N, h_K, h_samples, S, 0, 1.0, nullptr, nullptr, nullptr, nullptr, h_Rt_out);
+}
+
+int clc_cov_intersection(const double* CA, const double* CB, const double* ca, const double* cb, double* omega,
+                         double* cov_fused, double* pos_fused)
+{
+    if (!CA || !CB || !ca || !cb) return CLC_ERR_BAD_ARG;
+    coloc::Mat3d A, B;
+    coloc::Vec3d a, b;
+    for (int i = 0; i < 9; ++i) { A[i] = CA[i]; B[i] = CB[i]; }
+    for (int i = 0; i < 3; ++i) { a[i] = ca[i]; b[i] = cb[i]; }
+    coloc::HIPCovIntersection ci;
+    ci.loadData(A, B, a, b);
+    ci.optimize();
+    ci.computeFusedValues();
+    if (omega) *omega = ci.minX;
+    if (cov_fused) for (int i = 0; i < 9; ++i) cov_fused[i] = ci.covFused[i];
+    if (pos_fused) for (int i = 0; i < 3; ++i) pos_fused[i] = ci.poseFused[i];
+    return CLC_OK;
 }
 
 } // extern "C"

@@ -251,6 +251,15 @@ int clc_pnp_localize(clc_ctx* ctx, const double* h_X, const double* h_x, int N, 
 int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                 const int32_t* h_samples, int S, double* h_Rt_out);
 
+/* ---- fusion (host arithmetic; no GPU work) ---------------------------------------------------------
+ * Covariance intersection of two 3-D position estimates as CoLoC fuses intra- and inter-camera poses
+ * (include/coloc/CovIntersection.hpp:24-49, called at include/coloc/coloc.hpp:362-389): omega in [0,1]
+ * minimising trace(inv(inv(CA) + inv(CB) - inv(omega CA + (1-omega) CB))) to 1e-3, then the fused
+ * covariance (9, row-major) and position (3).  Same code as coloc_amd/host/HIPCovIntersection.hpp, exported
+ * for hosts that bind the C ABI only.  ctx may be NULL. */
+int clc_cov_intersection(const double* CA, const double* CB, const double* ca, const double* cb,
+                         double* omega, double* cov_fused, double* pos_fused);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,3 +46,17 @@ def test_cov_intersection_matches_restatement(tmp_path):
         Kg = C @ (np.linalg.inv(CA) - x * M); Lg = C @ (np.linalg.inv(CB) - (1 - x) * M)
         assert np.allclose(p, Kg @ ca + Lg @ cb, rtol=1e-8, atol=1e-12)
         assert np.all(np.linalg.eigvalsh((C + C.T) / 2) > 0)
+
+
+def test_c_abi_export_matches_header():
+    """clc_cov_intersection (host-only entry point of the .so; works without a GPU) == the same formulas."""
+    from coloc_amd import cov_intersection
+    rng = np.random.default_rng(5)
+    for _ in range(10):
+        CA, CB = _spd(rng, 0.05), _spd(rng, 0.02)
+        ca, cb = rng.normal(size=3), rng.normal(size=3)
+        om, C, p = cov_intersection(CA, CB, ca, cb)
+        assert np.allclose(C, _fused(CA, CB, om), rtol=1e-8)
+        f = lambda w: np.trace(_fused(CA, CB, w))
+        best = min(minimize_scalar(f, bounds=(0, 1), method="bounded").fun, f(0.0), f(1.0))
+        assert np.trace(C) <= best * (1 + 1e-4)

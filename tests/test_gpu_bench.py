@@ -47,3 +47,14 @@ def test_two_rank_rehearsal_runs():
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["pairs"] == 1 and d["value"] > 0 and "REHEARSAL" in d["collective"]
+
+
+def test_streaming_scenario_runs_and_localizes():
+    """BASELINE config[4] shape on one GPU: front end -> map match -> localize -> fuse, every frame; the pose
+    must land within a millimetre-scale error of the synthetic ground truth at 0.5 px noise."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_stream.py"), "--cams", "2", "--frames", "6", "--map-points", "2000"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["position_error_p50"] < 0.01 and d["inliers_p50"] > 500
+    assert d["cameras_at_30fps_per_gpu"] > 8
