@@ -13,6 +13,7 @@
 //     vector-memory instructions in the inner loop; the load of vector t+1 is issued before the
 //     VALU work on vector t (explicit double buffer in SGPRs).  Per (query, train) pair the VALU executes
 //     16 x (v_xor_b32 + v_bcnt_u32_b32 with accumulate) = 32 lane-ops.
+//   * every v_xor is directly followed by the v_bcnt that consumes it (one asm statement per word).
 //   * top-2 without branches or an index register: key = (distance << 22) | train_index_in_split.
 //     Unsigned order on keys is (distance, index) lexicographic, so best' = min(best, key) keeps
 //     the lowest index among equal distances, and second' = med3(best, second, key) is the second
@@ -50,17 +51,15 @@ typedef u32x2 __attribute__((address_space(1)))* global_u2_ptr;
 
 int k2nn_queries_per_block() { return kQPerBlock; }
 
-__device__ __forceinline__ uint32_t bcnt_first(uint32_t x)
+// One 32-bit word of the distance: xor with the (scalar) train word, immediately consumed by the
+// popcount-accumulate.  Emitted as ONE asm statement on purpose: when the v_bcnt directly follows the v_xor
+// that feeds it, the pair issues in ~6.3 cycles; scheduled apart (as the compiler does to "hide latency")
+// the same two instructions cost ~8 (profiles/r01_valu_issue_rates.txt) -- worth 8 % of the sweep.
+__device__ __forceinline__ uint32_t xor_bcnt_acc(uint32_t q, uint32_t t_scalar, uint32_t acc)
 {
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
-    return r;
-}
-__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
-{
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
+    uint32_t tmp;
+    asm volatile("v_xor_b32 %1, %3, %2\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(acc), "=&v"(tmp) : "v"(q), "s"(t_scalar));
+    return acc;
 }
 __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
 {
@@ -79,9 +78,9 @@ __device__ __forceinline__ void sweep_one(const uint32_t (&q)[R][16], const u32x
                               c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        uint32_t acc = bcnt_first(q[r][0] ^ tw[0]);
+        uint32_t acc = 0;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) acc = bcnt_acc(q[r][k] ^ tw[k], acc);
+        for (int k = 0; k < 16; ++k) acc = xor_bcnt_acc(q[r][k], tw[k], acc);
         const uint32_t key = (acc << kKeyShift) + t_rel;
         second[r] = umed3(best[r], second[r], key);
         best[r] = min(best[r], key);

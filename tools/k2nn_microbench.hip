@@ -79,6 +79,36 @@ __device__ __forceinline__ void sweep_one_paired_il(const uint32_t (&q)[R][16], 
     }
 }
 
+// paired asm with the train word as SGPR operand: v_xor_b32 v, s, v directly followed by its v_bcnt
+template <int R, int IL>
+__device__ __forceinline__ void sweep_one_paired_sgpr(const uint32_t (&q)[R][16], const u32x4 a, const u32x4 b, const u32x4 c, const u32x4 d,
+                                                      const uint32_t t_rel, uint32_t (&best)[R], uint32_t (&second)[R])
+{
+    const uint32_t tw[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+    uint32_t acc[R], tmp;
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0;
+    if (IL) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                asm volatile("v_xor_b32 %1, %3, %2\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[r]), "=&v"(tmp) : "v"(q[r][k]), "s"(tw[k]));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                asm volatile("v_xor_b32 %1, %3, %2\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[r]), "=&v"(tmp) : "v"(q[r][k]), "s"(tw[k]));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint32_t key = (acc[r] << 22) + t_rel;
+        second[r] = umed3(best[r], second[r], key);
+        best[r] = min(best[r], key);
+    }
+}
+
 // MODE 0: plain loop (s_load, wait, compute).  MODE 1: no loads in the loop (VALU ceiling).
 // MODE 2: explicit double buffer: wait, issue next s_load, compute current.
 template <int R, int WAVES, int MODE>
@@ -123,7 +153,9 @@ __global__ __launch_bounds__(64 * WAVES) void sweep(const u32x4* __restrict__ Q,
             const_u4_ptr np = (t + 1 < t1) ? tp : tp - 4;   // never read past the split
             const u32x4 na = np[0], nb = np[1], nc = np[2], nd = np[3];
             __builtin_amdgcn_sched_barrier(0);
-            sweep_one<R>(q, a, b, c, d, t - t0, best, second);
+            if (MODE == 9) sweep_one_paired_sgpr<R, 0>(q, a, b, c, d, t - t0, best, second);
+            else if (MODE == 10) sweep_one_paired_sgpr<R, 1>(q, a, b, c, d, t - t0, best, second);
+            else sweep_one<R>(q, a, b, c, d, t - t0, best, second);
             __builtin_amdgcn_sched_barrier(0);
             a = na; b = nb; c = nc; d = nd;
         }
@@ -270,7 +302,7 @@ float run(const u32x4* dQ, int nq, const u32x4* dT, int nt, int target_blocks, u
         else if (MODE == 6) hipLaunchKernelGGL((sweep_wlds<R, WAVES>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
         else if (MODE == 5) hipLaunchKernelGGL((sweep_lds<R, WAVES, 64, true>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
         else if (MODE == 4) hipLaunchKernelGGL((sweep_lds<R, WAVES, 32>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
-        else hipLaunchKernelGGL((sweep<R, WAVES, (MODE > 2 ? 0 : MODE)>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
+        else hipLaunchKernelGGL((sweep<R, WAVES, (MODE == 9 || MODE == 10) ? MODE : (MODE > 2 ? 0 : MODE)>), dim3(qblocks * splits), dim3(64 * WAVES), 0, 0, dQ, nq, dT, nt, splits, per, dP, nq_pad);
     };
     for (int i = 0; i < 3; ++i) launch();
     CHECK(hipDeviceSynchronize());
@@ -311,13 +343,13 @@ int main(int argc, char** argv)
 #define RUN(R, WV, MODE, name) for (int tb : targets) { int sp; float ms = run<R, WV, MODE>(dQ, nq, dT, nt, tb, dP, 15, &sp); \
         printf("%-28s %8d %7d %9.1f %9.1f  cs %016llx\n", name, tb, sp, ms * 1e3, cmp / (ms * 1e-3) / 1e9, g_checksum); }
     RUN(2, 4, 2, "R2 W4 prefetch (sgpr)");
-    RUN(2, 4, 6, "R2 W4 wave-lds paired");
+    RUN(2, 4, 9, "R2 W4 prefetch sgpr paired-asm");
+    RUN(2, 4, 10, "R2 W4 prefetch sgpr paired interleaved");
+    RUN(1, 4, 9, "R1 W4 prefetch sgpr paired-asm");
+    RUN(3, 4, 9, "R3 W4 prefetch sgpr paired-asm");
+    RUN(4, 4, 9, "R4 W4 prefetch sgpr paired-asm");
+    RUN(4, 4, 10, "R4 W4 prefetch sgpr paired interleaved");
+    RUN(2, 8, 9, "R2 W8 prefetch sgpr paired-asm");
     RUN(2, 4, 7, "R2 W4 wave-lds paired interleaved");
-    RUN(2, 4, 8, "R2 W4 wave-lds paired il 2acc");
-    RUN(4, 4, 7, "R4 W4 wave-lds paired interleaved");
-    RUN(4, 4, 8, "R4 W4 wave-lds paired il 2acc");
-    RUN(3, 4, 7, "R3 W4 wave-lds paired interleaved");
-    RUN(2, 8, 7, "R2 W8 wave-lds paired interleaved");
-    RUN(1, 4, 8, "R1 W4 wave-lds paired il 2acc");
     return 0;
 }
