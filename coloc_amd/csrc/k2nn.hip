@@ -81,9 +81,11 @@ __device__ __forceinline__ void sweep_one(const uint32_t (&q)[R][16], const u32x
         uint32_t acc = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc = xor_bcnt_acc(q[r][k], tw[k], acc);
-        const uint32_t key = (acc << kKeyShift) + t_rel;
-        second[r] = umed3(best[r], second[r], key);
-        best[r] = min(best[r], key);
+        // key = (distance << 22) + index; second = med3(best, second, key); best = min(best, key) -- again as
+        // one dependent run (each instruction consumes the previous result)
+        uint32_t key;
+        asm volatile("v_lshl_add_u32 %2, %3, 22, %4\n\tv_med3_u32 %1, %0, %1, %2\n\tv_min_u32 %0, %0, %2"
+                     : "+v"(best[r]), "+v"(second[r]), "=&v"(key) : "v"(acc), "s"(t_rel));
     }
 }
 
