@@ -67,6 +67,10 @@ __global__ __launch_bounds__(256) void rate_kernel(uint32_t* out, int iters, uns
         else if (OP == 44) { uint32_t tmp; asm volatile("v_xor_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(r[14 + ((I) & 1)]), "=&v"(tmp) : "v"(r[(I) % 7]), "v"(r[7 + (I) % 7])); } \
         else if (OP == 45) { uint32_t tmp; asm volatile("v_xor_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(r[12 + ((I) & 3)]), "=&v"(tmp) : "v"(r[(I) % 6]), "v"(r[6 + (I) % 6])); } \
         else if (OP == 46) { uint32_t tmp; asm volatile("v_xor_b32 %1, %2, %3\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(r[14 + ((I) & 1)]), "=&v"(tmp) : "s"(s), "v"(r[(I) % 7])); } \
+        else if (OP == 47) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(r[15]) : "v"(r[(I) % 7]), "v"(r[7 + (I) % 7])); \
+        else if (OP == 48) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(r[12 + ((I) & 3)]) : "v"(r[(I) % 6]), "v"(r[6 + (I) % 6])); \
+        else if (OP == 49) asm volatile("v_dot4_u32_u8 %0, %1, %1, %0" : "+v"(r[12 + ((I) & 3)]) : "v"(r[(I) % 12])); \
+        else if (OP == 50) asm volatile("v_add_f32 %0, %1, %0\n\tv_cvt_i32_f32 %0, %0\n\tv_med3_i32 %0, %0, 0, %2" : "+v"(r[(I)]) : "v"(r[(I + 1) & 15]), "v"(r[(I + 2) & 15])); \
         else if (OP == 39) { if (((I) & 3) == 3) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(r[I]) : "v"(r[(I + 1) & 15])); else asm volatile("v_xor_b32 %0, %1, %0" : "+v"(r[I]) : "v"(r[(I + 1) & 15])); }
         OPS(0) OPS(1) OPS(2) OPS(3) OPS(4) OPS(5) OPS(6) OPS(7) OPS(8) OPS(9) OPS(10) OPS(11) OPS(12) OPS(13) OPS(14) OPS(15)
         OPS(0) OPS(1) OPS(2) OPS(3) OPS(4) OPS(5) OPS(6) OPS(7) OPS(8) OPS(9) OPS(10) OPS(11) OPS(12) OPS(13) OPS(14) OPS(15)
@@ -133,9 +137,10 @@ int main()
                             "v_bitop3_b32", "v_sad_u8", "v_mul_u32_u24", "v_min_i32", "v_subrev_u32", "v_mad_i32_i24",
                             "alt xor(vv)/bcnt indep", "alt xor(vv)->bcnt dep", "alt xor(sv)/bcnt", "3 xor(vv) : 1 bcnt",
                             "v_xor_b32_dpp newbcast", "alt xor_dpp->bcnt dep", "v_mov_b32(s)", "v_mov_b32_dpp newbcast",
-                            "k2nn pairs vv, 2 chains", "k2nn pairs vv, 4 chains", "k2nn pairs sv, 2 chains" };
+                            "k2nn pairs vv, 2 chains", "k2nn pairs vv, 4 chains", "k2nn pairs sv, 2 chains",
+                            "dot4 one acc chain", "dot4 four acc chains", "dot4 a*a four chains", "add_f32->cvt->med3 run (x3)" };
 #define B(OP) bench(names[OP], [&]() { hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(256), 0, 0, dout, iters, dclk); }, blocks, iters, dclk);
-    B(0) B(1) B(2) B(3) B(4) B(5) B(6) B(7) B(8) B(9) B(10) B(11) B(12) B(13) B(14) B(15) B(16) B(17) B(18) B(19) B(20) B(21) B(22) B(23) B(24) B(25) B(26) B(27) B(28) B(29) B(30) B(31) B(32) B(33) B(34) B(35) B(36) B(37) B(38) B(39) B(40) B(41) B(42) B(43) B(44) B(45) B(46)
+    B(0) B(1) B(2) B(3) B(4) B(5) B(6) B(7) B(8) B(9) B(10) B(11) B(12) B(13) B(14) B(15) B(16) B(17) B(18) B(19) B(20) B(21) B(22) B(23) B(24) B(25) B(26) B(27) B(28) B(29) B(30) B(31) B(32) B(33) B(34) B(35) B(36) B(37) B(38) B(39) B(40) B(41) B(42) B(43) B(44) B(45) B(46) B(47) B(48) B(49) B(50)
     bench("v_pk_fma_f32", [&]() { hipLaunchKernelGGL(rate_pk, dim3(blocks), dim3(256), 0, 0, (float2*)dout, iters, dclk); }, blocks, iters, dclk);
     return 0;
 }
