@@ -105,7 +105,7 @@ struct clc_ctx {
     uint2* d_partial = nullptr;
     size_t partial_cap = 0;
     bool partial_dirty = false;      // armed (all-ones) state of the atomic top-2 rows was lost
-    int target_blocks = 4096;
+    int target_blocks = 6144;
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
     size_t pairs_cap = 0;
