@@ -44,7 +44,8 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection",
+    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_essential_fivepoint",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -120,6 +121,8 @@ def load_library():
     lib.clc_detect_and_describe.argtypes = [vp, vp, u32, u32, vp, vp, ci, C.POINTER(ci), C.POINTER(ci)]
     lib.clc_pnp_ransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_uint64, C.c_double, vp, vp, C.POINTER(ci), C.POINTER(C.c_double)]
     lib.clc_pnp_p3p.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp]
+    lib.clc_essential_ransac.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, C.c_uint64, C.c_double, vp, vp, vp, C.POINTER(ci)]
+    lib.clc_essential_fivepoint.argtypes = [vp, vp, vp, ci, vp, vp, vp, ci, vp]
     lib.clc_epipolar_residuals.argtypes = [vp, vp, ci, vp, vp, ci, vp]
     lib.clc_epipolar_score.argtypes = [vp, vp, ci, vp, vp, ci, C.c_double, vp, vp]
     lib.clc_pnp_localize.argtypes = [vp, vp, vp, ci, vp, vp, ci, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, C.POINTER(ci),
@@ -342,6 +345,31 @@ class Context:
         self._chk(self.lib.clc_pnp_ransac(self.h, _p(X), _p(x), X.shape[0], _p(K), _p(samples), int(n_samples), int(seed),
                                           float(thr2), _p(Rt), _p(mask), C.byref(n), C.byref(cost)))
         return (Rt.reshape(3, 4) if n.value > 0 else None), mask.astype(bool), cost.value
+
+    def essential_ransac(self, x1, x2, K1, K2, samples=None, n_samples=256, seed=1, thr2=4.0):
+        """Five-point RANSAC: (E (3,3) or None, F (3,3), inlier mask)."""
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        K1 = np.ascontiguousarray(K1, dtype=np.float64).reshape(9); K2 = np.ascontiguousarray(K2, dtype=np.float64).reshape(9)
+        if samples is not None:
+            samples = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, 5)
+            n_samples = samples.shape[0]
+        E = np.zeros(9); F = np.zeros(9)
+        mask = np.zeros(x1.shape[0], dtype=np.uint8)
+        n = C.c_int()
+        self._chk(self.lib.clc_essential_ransac(self.h, _p(x1), _p(x2), x1.shape[0], _p(K1), _p(K2), _p(samples), int(n_samples),
+                                                int(seed), float(thr2), _p(E), _p(F), _p(mask), C.byref(n)))
+        return (E.reshape(3, 3) if n.value > 0 else None), F.reshape(3, 3), mask.astype(bool)
+
+    def essential_fivepoint(self, x1, x2, K1, K2, samples):
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        K1 = np.ascontiguousarray(K1, dtype=np.float64).reshape(9); K2 = np.ascontiguousarray(K2, dtype=np.float64).reshape(9)
+        samples = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, 5)
+        out = np.zeros((samples.shape[0], 10, 9), dtype=np.float64)
+        self._chk(self.lib.clc_essential_fivepoint(self.h, _p(x1), _p(x2), x1.shape[0], _p(K1), _p(K2), _p(samples),
+                                                   samples.shape[0], _p(out)))
+        return out
 
     def epipolar_residuals(self, F, x1, x2):
         F = np.ascontiguousarray(F, dtype=np.float64).reshape(-1, 9)

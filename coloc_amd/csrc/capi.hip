@@ -804,16 +804,23 @@ static int epipolar_impl(clc_ctx* ctx, const double* h_F, int H, const double* h
     return CLC_OK;
 }
 
-static void draw_samples(uint64_t seed, int S, int N, std::vector<int32_t>& out)
+// S minimal samples of `k` distinct indices in [0, N) from a xorshift64* stream
+static void draw_samples(uint64_t seed, int S, int N, std::vector<int32_t>& out, int k = 3)
 {
-    out.resize((size_t)3 * S);
+    out.resize((size_t)k * S);
     uint64_t st = seed ? seed : 0x9E3779B97F4A7C15ull;
     auto next = [&]() { st ^= st >> 12; st ^= st << 25; st ^= st >> 27; return st * 0x2545F4914F6CDD1Dull; };   // xorshift64*
     for (int s = 0; s < S; ++s) {
-        int32_t a = (int32_t)(next() % (uint64_t)N), b, c;
-        do { b = (int32_t)(next() % (uint64_t)N); } while (N > 1 && b == a);
-        do { c = (int32_t)(next() % (uint64_t)N); } while (N > 2 && (c == a || c == b));
-        out[3 * s] = a; out[3 * s + 1] = b; out[3 * s + 2] = c;
+        for (int j = 0; j < k; ++j) {
+            int32_t v;
+            bool again;
+            do {
+                v = (int32_t)(next() % (uint64_t)N);
+                again = false;
+                for (int m = 0; m < j && N > j; ++m) again = again || out[(size_t)k * s + m] == v;
+            } while (again);
+            out[(size_t)k * s + j] = v;
+        }
     }
 }
 
@@ -904,6 +911,74 @@ int clc_epipolar_score(clc_ctx* ctx, const double* h_F, int H, const double* h_x
                        int32_t* h_count, double* h_cost)
 {
     return epipolar_impl(ctx, h_F, H, h_x1, h_x2, N, thr2, nullptr, h_count, h_cost);
+}
+
+static int essential_impl(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1, const double* h_K2,
+                          const int32_t* h_samples, int S, uint64_t seed, double thr2, double* h_E, double* h_F, uint8_t* h_mask,
+                          int* n_inliers, double* h_all_E)
+{
+    if (!ctx || N < 0 || S < 0 || !h_K1 || !h_K2 || (N > 0 && (!h_x1 || !h_x2))) return fail(ctx, CLC_ERR_BAD_ARG, "essential_ransac: bad argument");
+    if (n_inliers) *n_inliers = 0;
+    if (N < 5 || S == 0) { if (h_mask && N > 0) memset(h_mask, 0, (size_t)N); return CLC_OK; }
+    if (S > 6000) return fail(ctx, CLC_ERR_CAPACITY, "essential_ransac: more than 6000 samples per call");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> drawn;
+    if (!h_samples) { draw_samples(seed, S, N, drawn, 5); h_samples = drawn.data(); }
+    // device workspace in doubles: [ x1 2N | x2 2N | K1 16 | K2 16 | samples (5S int32) ] in,
+    //                              [ FE 180 S | cost 10 S | count (10 S int32) ] scratch, [ result | mask ] out
+    const size_t in_d = (size_t)4 * N + 32 + ((size_t)5 * S + 1) / 2;
+    const size_t scr_d = (size_t)180 * S + (size_t)10 * S + ((size_t)10 * S + 1) / 2;
+    const size_t res_d = (epi_result_bytes() + 7) / 8;
+    const size_t out_d = res_d + ((size_t)N + 7) / 8;
+    int rc = ensure_pnp(ctx, in_d + scr_d + out_d + 8);
+    if (rc != CLC_OK) return rc;
+    rc = ensure_pinned(ctx, (in_d > out_d ? in_d : out_d) * sizeof(double) + 64);
+    if (rc != CLC_OK) return rc;
+    double* d1 = ctx->d_pnp;
+    double* d2 = d1 + (size_t)2 * N;
+    double* dK1 = d2 + (size_t)2 * N;
+    double* dK2 = dK1 + 16;
+    int32_t* dSamples = (int32_t*)(dK2 + 16);
+    double* dFE = ctx->d_pnp + in_d;
+    double* dCost = dFE + (size_t)180 * S;
+    int32_t* dCount = (int32_t*)(dCost + (size_t)10 * S);
+    double* dRes = ctx->d_pnp + in_d + scr_d;
+    uint8_t* dMask = (uint8_t*)(dRes + res_d);
+    double* hp = (double*)ctx->h_pin;
+    memcpy(hp, h_x1, sizeof(double) * 2 * N);
+    memcpy(hp + (size_t)2 * N, h_x2, sizeof(double) * 2 * N);
+    memcpy(hp + (size_t)4 * N, h_K1, sizeof(double) * 9);
+    memcpy(hp + (size_t)4 * N + 16, h_K2, sizeof(double) * 9);
+    memcpy(hp + (size_t)4 * N + 32, h_samples, sizeof(int32_t) * 5 * S);
+    CLC_HIP(ctx, hipMemcpyAsync(d1, hp, in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_essential_ransac(d1, d2, N, dK1, dK2, dSamples, S, thr2, dFE, dCount, dCost, dMask, dRes, ctx->stream, &ctx->prof));
+    CLC_HIP(ctx, hipMemcpyAsync(hp, dRes, out_d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<double> fe;
+    if (h_all_E) { fe.resize((size_t)180 * S); CLC_HIP(ctx, hipMemcpyAsync(fe.data(), dFE, sizeof(double) * 180 * S, hipMemcpyDeviceToHost, ctx->stream)); }
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    struct { double E[9]; double F[9]; double cost; int32_t h; int32_t count; } r;
+    memcpy(&r, hp, sizeof r);
+    if (h_E) memcpy(h_E, r.E, sizeof r.E);
+    if (h_F) memcpy(h_F, r.F, sizeof r.F);
+    if (h_mask) memcpy(h_mask, (const uint8_t*)(hp + res_d), (size_t)N);
+    if (n_inliers) *n_inliers = r.h >= 0 ? r.count : 0;
+    if (h_all_E)
+        for (size_t k = 0; k < (size_t)10 * S; ++k) memcpy(h_all_E + 9 * k, fe.data() + 18 * k + 9, sizeof(double) * 9);
+    return CLC_OK;
+}
+
+int clc_essential_ransac(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1, const double* h_K2,
+                         const int32_t* h_samples, int S, uint64_t seed, double thr2, double* h_E, double* h_F,
+                         uint8_t* h_inlier_mask, int* n_inliers)
+{
+    return essential_impl(ctx, h_x1, h_x2, N, h_K1, h_K2, h_samples, S, seed, thr2, h_E, h_F, h_inlier_mask, n_inliers, nullptr);
+}
+
+int clc_essential_fivepoint(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1, const double* h_K2,
+                            const int32_t* h_samples, int S, double* h_E_out)
+{
+    if (!h_samples || !h_E_out) return fail(ctx, CLC_ERR_BAD_ARG, "essential_fivepoint: bad argument");
+    return essential_impl(ctx, h_x1, h_x2, N, h_K1, h_K2, h_samples, S, 0, 1.0, nullptr, nullptr, nullptr, nullptr, h_E_out);
 }
 
 int clc_pnp_ransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const int32_t* h_samples,

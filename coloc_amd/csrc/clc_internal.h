@@ -96,6 +96,12 @@ hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const 
                              int S, double thr2, double* d_Rt, int32_t* d_count, double* d_cost, uint8_t* d_mask,
                              void* d_result, hipStream_t stream, Profiler* prof = nullptr);
 size_t pnp_result_bytes();
+// five-point problems for S minimal samples (10 slots of {F(9), E(9)} each) -> symmetric-epipolar score -> select + mask.
+// d_result: {double E[9]; double F[9]; double cost; int32 h; int32 count} (epi_result_bytes()).
+hipError_t launch_essential_ransac(const double* d_x1, const double* d_x2, int N, const double* d_K1, const double* d_K2,
+                                   const int32_t* d_samples, int S, double thr2, double* d_FE, int32_t* d_count, double* d_cost,
+                                   uint8_t* d_mask, void* d_result, hipStream_t stream, Profiler* prof = nullptr);
+size_t epi_result_bytes();
 // symmetric epipolar distance of H fundamental matrices: d_err != null -> H x N residuals, else counts / costs
 hipError_t launch_epipolar(const double* d_F, int H, const double* d_x1, const double* d_x2, int N, double thr2, double* d_err,
                            int32_t* d_count, double* d_cost, hipStream_t stream, Profiler* prof = nullptr);

@@ -1,0 +1,419 @@
+// fivept.h -- calibrated five-point relative pose: up to 10 essential matrices from 5 correspondences, one
+// problem per lane (host + device inline).
+//
+// Role: hypothesis generator for the batched essential-matrix RANSAC (clc_essential_ransac), the GPU form of
+// RobustMatcher::filterEssential (reference include/coloc/RobustMatcher.hpp:153-186), which asks OpenMVG for
+// essential::kernel::FivePointSolver inside AC-RANSAC.  OpenMVG is an empty, unpinned submodule in the
+// reference snapshot, so this follows the published method (Nister 2004 / Stewenius et al. 2006), derived
+// from scratch and built by polynomial arithmetic rather than by a transcribed coefficient table:
+//   1. the 5 epipolar constraints q2^T E q1 = 0 leave a 4-D null space {E1..E4}: E = x E1 + y E2 + z E3 + E4;
+//   2. det(E) = 0 and 2 E E^T E - trace(E E^T) E = 0 are 10 cubic polynomials in (x, y, z) over 20 monomials,
+//      ordered [x3 x2y x2z xy2 xyz xz2 y3 y2z yz2 z3 | x2 xy xz y2 yz z2 x y z 1];
+//   3. Gauss-Jordan on the 10 cubic monomials gives [I | B]; with basis b = [x2 xy xz y2 yz z2 x y z 1]^T the
+//      action matrix of "multiply by x" has rows -B[x3], -B[x2y], -B[x2z], -B[xy2], -B[xyz], -B[xz2] and the
+//      unit rows x*x = x2, x*y = xy, x*z = xz, x*1 = x;  A b = x b at every solution;
+//   4. eigenvalues by Hessenberg reduction + complex single-shift QR; each real one is refined together with its
+//      eigenvector by inverse iteration on A itself;  (x, y, z) = b[6..8] / b[9].
+//      (A characteristic-polynomial route -- Faddeev-LeVerrier + Durand-Kerner -- lost 15 % of the true solutions
+//      to cancellation in the coefficients and was dropped.)
+// fp64 throughout.  Inputs are NORMALISED image coordinates (K^-1 applied).
+#ifndef CLC_FIVEPT_H
+#define CLC_FIVEPT_H
+
+#include <math.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define FPT_HD __host__ __device__ inline
+#else
+#define FPT_HD static inline
+#endif
+
+// exponents of the 20 monomials in the order above
+FPT_HD int fpt_mono_index(int i, int j, int k)
+{
+    // i, j, k = exponents of x, y, z; total degree <= 3
+    const int d = i + j + k;
+    if (d == 3) {
+        if (i == 3) return 0;
+        if (i == 2) return j == 1 ? 1 : 2;
+        if (i == 1) return j == 2 ? 3 : (j == 1 ? 4 : 5);
+        return j == 3 ? 6 : (j == 2 ? 7 : (j == 1 ? 8 : 9));
+    }
+    if (d == 2) {
+        if (i == 2) return 10;
+        if (i == 1) return j == 1 ? 11 : 12;
+        return j == 2 ? 13 : (j == 1 ? 14 : 15);
+    }
+    if (d == 1) return i == 1 ? 16 : (j == 1 ? 17 : 18);
+    return 19;
+}
+FPT_HD void fpt_mono_exp(int m, int* i, int* j, int* k)
+{
+    const signed char E[20][3] = { {3,0,0},{2,1,0},{2,0,1},{1,2,0},{1,1,1},{1,0,2},{0,3,0},{0,2,1},{0,1,2},{0,0,3},
+                                   {2,0,0},{1,1,0},{1,0,1},{0,2,0},{0,1,1},{0,0,2},{1,0,0},{0,1,0},{0,0,1},{0,0,0} };
+    *i = E[m][0]; *j = E[m][1]; *k = E[m][2];
+}
+
+// c += a * b for polynomials stored over the 20 monomials (caller guarantees deg(a) + deg(b) <= 3)
+FPT_HD void fpt_poly_mul_add(const double* a, const double* b, double scale, double* c)
+{
+    for (int m = 0; m < 20; ++m) {
+        if (a[m] == 0.0) continue;
+        int ai, aj, ak;
+        fpt_mono_exp(m, &ai, &aj, &ak);
+        for (int n = 0; n < 20; ++n) {
+            if (b[n] == 0.0) continue;
+            int bi, bj, bk;
+            fpt_mono_exp(n, &bi, &bj, &bk);
+            if (ai + aj + ak + bi + bj + bk > 3) continue;
+            c[fpt_mono_index(ai + bi, aj + bj, ak + bk)] += scale * a[m] * b[n];
+        }
+    }
+}
+
+// solve (A - lambda I) y = rhs for a 10 x 10 A by LU with partial pivoting; returns false if singular to working precision
+FPT_HD bool fpt_solve_shifted(const double* A, double lambda, const double* rhs, double* y)
+{
+    double M[10][11];
+    for (int r = 0; r < 10; ++r) {
+        for (int c = 0; c < 10; ++c) M[r][c] = A[10 * r + c] - (r == c ? lambda : 0.0);
+        M[r][10] = rhs[r];
+    }
+    for (int c = 0; c < 10; ++c) {
+        int p = c;
+        double best = fabs(M[c][c]);
+        for (int r = c + 1; r < 10; ++r) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
+        if (!(best > 0.0)) { M[c][c] = 1e-300; best = 1e-300; p = c; }
+        if (p != c) for (int k = 0; k < 11; ++k) { const double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; }
+        const double inv = 1.0 / M[c][c];
+        for (int r = c + 1; r < 10; ++r) {
+            const double f = M[r][c] * inv;
+            if (f == 0.0) continue;
+            for (int k = c; k < 11; ++k) M[r][k] -= f * M[c][k];
+        }
+    }
+    for (int r = 9; r >= 0; --r) {
+        double s = M[r][10];
+        for (int k = r + 1; k < 10; ++k) s -= M[r][k] * y[k];
+        y[r] = s / M[r][r];
+    }
+    for (int r = 0; r < 10; ++r) if (!(y[r] == y[r])) return false;
+    return true;
+}
+
+// All eigenvalues of a real 10 x 10 matrix (copied; A is not modified).
+FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi)
+{
+    const int n = 10;
+    double hr[10][10], hi[10][10];
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) { hr[r][c] = A[10 * r + c]; hi[r][c] = 0.0; }
+    // Hessenberg by elimination with row/column interchanges (similarity transforms)
+    for (int m = 1; m < n - 1; ++m) {
+        int p = m;
+        double x = 0.0;
+        for (int j = m; j < n; ++j) if (fabs(hr[j][m - 1]) > fabs(x)) { x = hr[j][m - 1]; p = j; }
+        if (p != m) {
+            for (int j = m - 1; j < n; ++j) { const double t = hr[p][j]; hr[p][j] = hr[m][j]; hr[m][j] = t; }
+            for (int j = 0; j < n; ++j) { const double t = hr[j][p]; hr[j][p] = hr[j][m]; hr[j][m] = t; }
+        }
+        if (x != 0.0) {
+            for (int i = m + 1; i < n; ++i) {
+                double y = hr[i][m - 1];
+                if (y == 0.0) continue;
+                y /= x;
+                hr[i][m - 1] = 0.0;
+                for (int j = m; j < n; ++j) hr[i][j] -= y * hr[m][j];
+                for (int j = 0; j < n; ++j) hr[j][m] += y * hr[j][i];
+            }
+        }
+    }
+    for (int r = 2; r < n; ++r) for (int c = 0; c < r - 1; ++c) hr[r][c] = 0.0;
+    double norm = 0.0;
+    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) norm = fabs(hr[r][c]) > norm ? fabs(hr[r][c]) : norm;
+    if (!(norm > 0.0)) { for (int i = 0; i < n; ++i) { wr[i] = 0.0; wi[i] = 0.0; } return; }
+    int m = n - 1, iter = 0;
+    while (m >= 0) {
+        // look for a negligible subdiagonal element
+        int l = m;
+        while (l > 0) {
+            const double sd = fabs(hr[l][l - 1]) + fabs(hi[l][l - 1]);
+            const double dg = fabs(hr[l][l]) + fabs(hi[l][l]) + fabs(hr[l - 1][l - 1]) + fabs(hi[l - 1][l - 1]);
+            if (sd <= 1e-15 * (dg > 0.0 ? dg : norm)) { hr[l][l - 1] = 0.0; hi[l][l - 1] = 0.0; break; }
+            --l;
+        }
+        if (l == m) { wr[m] = hr[m][m]; wi[m] = hi[m][m]; --m; iter = 0; continue; }
+        if (++iter > 300) {                       // give up on this block: report the diagonal
+            for (int i = l; i <= m; ++i) { wr[i] = hr[i][i]; wi[i] = hi[i][i]; }
+            m = l - 1; iter = 0; continue;
+        }
+        // Wilkinson shift: eigenvalue of the trailing 2 x 2 closer to h[m][m]  (exceptional shifts now and then)
+        double sr, si;
+        {
+            const double ar = hr[m - 1][m - 1], ai = hi[m - 1][m - 1], br = hr[m - 1][m], bi = hi[m - 1][m];
+            const double cr = hr[m][m - 1], ci = hi[m][m - 1], dr = hr[m][m], di = hi[m][m];
+            // roots of t^2 - (a + d) t + (a d - b c): t = (a + d)/2 +- sqrt(((a - d)/2)^2 + b c)
+            const double hr_ = 0.5 * (ar - dr), hi_ = 0.5 * (ai - di);
+            const double qr_ = hr_ * hr_ - hi_ * hi_ + (br * cr - bi * ci), qi_ = 2.0 * hr_ * hi_ + (br * ci + bi * cr);
+            const double mag = sqrt(sqrt(qr_ * qr_ + qi_ * qi_));
+            const double ang = 0.5 * atan2(qi_, qr_);
+            const double rr = mag * cos(ang), ri = mag * sin(ang);
+            const double mr = 0.5 * (ar + dr), mi = 0.5 * (ai + di);
+            const double t1r = mr + rr, t1i = mi + ri, t2r = mr - rr, t2i = mi - ri;
+            const double d1 = fabs(t1r - dr) + fabs(t1i - di), d2 = fabs(t2r - dr) + fabs(t2i - di);
+            sr = d1 < d2 ? t1r : t2r; si = d1 < d2 ? t1i : t2i;
+            if (iter % 11 == 10) { sr += 0.7 * (fabs(cr) + fabs(ci)); si += 0.3 * (fabs(cr) + fabs(ci)); }
+        }
+        for (int i = l; i <= m; ++i) { hr[i][i] -= sr; hi[i][i] -= si; }
+        // QR step on the active block [l, m]: H = Q R by Givens rotations, then H <- R Q
+        double gc[10], gsr[10], gsi[10];
+        for (int k = l; k < m; ++k) {
+            // rotation G = [c, s; -conj(s), c] with c real that zeroes H[k+1][k]
+            const double ar = hr[k][k], ai = hi[k][k], br = hr[k + 1][k], bi = hi[k + 1][k];
+            const double na = sqrt(ar * ar + ai * ai), nb = sqrt(br * br + bi * bi);
+            const double nrm = sqrt(na * na + nb * nb);
+            double c, s_r, s_i;
+            if (nrm == 0.0) { c = 1.0; s_r = 0.0; s_i = 0.0; }
+            else if (na == 0.0) { c = 0.0; s_r = br / nb; s_i = -bi / nb; }    // s = conj(b)/|b|
+            else {
+                c = na / nrm;
+                // s = (a/|a|) conj(b) / nrm
+                const double ur = ar / na, ui = ai / na;
+                s_r = (ur * br + ui * bi) / nrm; s_i = (ui * br - ur * bi) / nrm;
+            }
+            gc[k] = c; gsr[k] = s_r; gsi[k] = s_i;
+            // rows k, k+1, columns k..m:  [x; y] <- [c x + s y; -conj(s) x + c y]
+            for (int j = k; j <= m; ++j) {
+                const double xr = hr[k][j], xi = hi[k][j], yr = hr[k + 1][j], yi = hi[k + 1][j];
+                hr[k][j] = c * xr + (s_r * yr - s_i * yi);
+                hi[k][j] = c * xi + (s_r * yi + s_i * yr);
+                hr[k + 1][j] = -(s_r * xr + s_i * xi) + c * yr;       // -conj(s) x = -(s_r - i s_i)(x)
+                hi[k + 1][j] = -(s_r * xi - s_i * xr) + c * yi;
+            }
+            hr[k + 1][k] = 0.0; hi[k + 1][k] = 0.0;
+        }
+        for (int k = l; k < m; ++k) {
+            // columns k, k+1, rows l..min(k+2, m): [x, y] <- [x c + y conj(s), -x s + y c]   (multiplication by G^H)
+            const double c = gc[k], s_r = gsr[k], s_i = gsi[k];
+            const int rmax = k + 2 < m ? k + 2 : m;
+            for (int i = l; i <= rmax; ++i) {
+                const double xr = hr[i][k], xi = hi[i][k], yr = hr[i][k + 1], yi = hi[i][k + 1];
+                hr[i][k] = c * xr + (yr * s_r + yi * s_i);
+                hi[i][k] = c * xi + (yi * s_r - yr * s_i);
+                hr[i][k + 1] = -(xr * s_r - xi * s_i) + c * yr;
+                hi[i][k + 1] = -(xr * s_i + xi * s_r) + c * yi;
+            }
+        }
+        for (int i = l; i <= m; ++i) { hr[i][i] += sr; hi[i][i] += si; }
+    }
+}
+
+// relative residual of the essential-matrix constraints 2 E E^T E - tr(E E^T) E = 0 (which imply det E = 0)
+FPT_HD double fpt_constraint_residual(const double* E)
+{
+    double G[9], n2 = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) G[3 * a + b] = E[3 * a] * E[3 * b] + E[3 * a + 1] * E[3 * b + 1] + E[3 * a + 2] * E[3 * b + 2];
+    for (int i = 0; i < 9; ++i) n2 += E[i] * E[i];
+    const double tr = G[0] + G[4] + G[8];
+    double worst = 0.0;
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+            const double c = 2.0 * (G[3 * a] * E[b] + G[3 * a + 1] * E[3 + b] + G[3 * a + 2] * E[6 + b]) - tr * E[3 * a + b];
+            worst = fabs(c) > worst ? fabs(c) : worst;
+        }
+    return n2 > 0.0 ? worst / (n2 * sqrt(n2)) : 1.0;
+}
+
+// q1, q2: 5 x 2 normalised coordinates in view 1 / view 2 (q2^T E q1 = 0).  E_out: up to 10 x 9 (row-major 3x3).
+FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_out)
+{
+    // ---- 1. null space of the 5 x 9 constraint matrix by reduced row echelon form
+    double A[5][9];
+    for (int i = 0; i < 5; ++i) {
+        const double a[3] = { q2[i][0], q2[i][1], 1.0 }, b[3] = { q1[i][0], q1[i][1], 1.0 };
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[i][3 * r + c] = a[r] * b[c];
+    }
+    int piv[5];
+    bool is_piv[9] = { false, false, false, false, false, false, false, false, false };
+    int row = 0;
+    for (int col = 0; col < 9 && row < 5; ++col) {
+        int p = row;
+        double best = fabs(A[row][col]);
+        for (int r = row + 1; r < 5; ++r) if (fabs(A[r][col]) > best) { best = fabs(A[r][col]); p = r; }
+        if (best < 1e-12) continue;
+        if (p != row) for (int k = 0; k < 9; ++k) { const double t = A[row][k]; A[row][k] = A[p][k]; A[p][k] = t; }
+        const double inv = 1.0 / A[row][col];
+        for (int k = 0; k < 9; ++k) A[row][k] *= inv;
+        for (int r = 0; r < 5; ++r) {
+            if (r == row) continue;
+            const double f = A[r][col];
+            if (f == 0.0) continue;
+            for (int k = 0; k < 9; ++k) A[r][k] -= f * A[row][k];
+        }
+        piv[row] = col;
+        is_piv[col] = true;
+        ++row;
+    }
+    if (row < 5) return 0;                      // degenerate sample
+    double EE[4][9];
+    {
+        int nb = 0;
+        for (int f = 0; f < 9; ++f) {
+            if (is_piv[f]) continue;
+            for (int k = 0; k < 9; ++k) EE[nb][k] = 0.0;
+            EE[nb][f] = 1.0;
+            for (int r = 0; r < 5; ++r) EE[nb][piv[r]] = -A[r][f];
+            ++nb;
+        }
+    }
+    // ---- 2. the ten cubic constraints.  e[a][b] = linear polynomial x EE0 + y EE1 + z EE2 + EE3
+    double e[9][20];
+    for (int k = 0; k < 9; ++k) {
+        for (int m = 0; m < 20; ++m) e[k][m] = 0.0;
+        e[k][16] = EE[0][k]; e[k][17] = EE[1][k]; e[k][18] = EE[2][k]; e[k][19] = EE[3][k];
+    }
+    double M[10][20];
+    for (int r = 0; r < 10; ++r) for (int m = 0; m < 20; ++m) M[r][m] = 0.0;
+    {
+        // det(E): e0 (e4 e8 - e5 e7) - e1 (e3 e8 - e5 e6) + e2 (e3 e7 - e4 e6)
+        double t[20];
+        const int tri[3][5] = { { 0, 4, 8, 5, 7 }, { 1, 3, 8, 5, 6 }, { 2, 3, 7, 4, 6 } };
+        for (int s = 0; s < 3; ++s) {
+            for (int m = 0; m < 20; ++m) t[m] = 0.0;
+            fpt_poly_mul_add(e[tri[s][1]], e[tri[s][2]], 1.0, t);
+            fpt_poly_mul_add(e[tri[s][3]], e[tri[s][4]], -1.0, t);
+            fpt_poly_mul_add(e[tri[s][0]], t, s == 1 ? -1.0 : 1.0, M[0]);
+        }
+        // G = E E^T (quadratic), tr = trace(G);  C = 2 G E - tr E
+        double G[9][20], tr[20];
+        for (int m = 0; m < 20; ++m) tr[m] = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                for (int m = 0; m < 20; ++m) G[3 * a + b][m] = 0.0;
+                for (int c = 0; c < 3; ++c) fpt_poly_mul_add(e[3 * a + c], e[3 * b + c], 1.0, G[3 * a + b]);
+            }
+        for (int m = 0; m < 20; ++m) tr[m] = G[0][m] + G[4][m] + G[8][m];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) {
+                double* row_ = M[1 + 3 * a + b];
+                for (int c = 0; c < 3; ++c) fpt_poly_mul_add(G[3 * a + c], e[3 * c + b], 2.0, row_);
+                fpt_poly_mul_add(tr, e[3 * a + b], -1.0, row_);
+            }
+    }
+    double M0[10][20];                       // the constraints before elimination: used to polish the roots
+    for (int r = 0; r < 10; ++r) {
+        double nr = 0.0;
+        for (int m = 0; m < 20; ++m) nr = fabs(M[r][m]) > nr ? fabs(M[r][m]) : nr;
+        nr = nr > 0.0 ? 1.0 / nr : 1.0;
+        for (int m = 0; m < 20; ++m) M0[r][m] = M[r][m] * nr;
+    }
+    // ---- 3. Gauss-Jordan on the 10 cubic monomials
+    for (int c = 0; c < 10; ++c) {
+        int p = c;
+        double best = fabs(M[c][c]);
+        for (int r = c + 1; r < 10; ++r) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
+        if (best < 1e-14) return 0;
+        if (p != c) for (int k = 0; k < 20; ++k) { const double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; }
+        const double inv = 1.0 / M[c][c];
+        for (int k = 0; k < 20; ++k) M[c][k] *= inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == c) continue;
+            const double f = M[r][c];
+            if (f == 0.0) continue;
+            for (int k = 0; k < 20; ++k) M[r][k] -= f * M[c][k];
+        }
+    }
+    // action matrix of multiplication by x on b = [x2 xy xz y2 yz z2 x y z 1]
+    double Ax[100];
+    for (int i = 0; i < 100; ++i) Ax[i] = 0.0;
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 10; ++c) Ax[10 * r + c] = -M[r][10 + c];   // x3, x2y, x2z, xy2, xyz, xz2
+    Ax[10 * 6 + 0] = 1.0; Ax[10 * 7 + 1] = 1.0; Ax[10 * 8 + 2] = 1.0; Ax[10 * 9 + 6] = 1.0;
+    // ---- 4. eigenvalues of Ax: Hessenberg form by stabilised elimination, then single-shift QR in complex
+    //         arithmetic (Wilkinson shift, Givens rotations, deflation) -- no characteristic polynomial
+    double zr[10], zi[10];
+    fpt_eigenvalues10(Ax, zr, zi);
+    // ---- real roots -> eigenvectors by inverse iteration on Ax, refined eigenvalue by the eigen-equation
+    int ns = 0;
+    double anorm = 0.0;
+    for (int i = 0; i < 100; ++i) anorm = fabs(Ax[i]) > anorm ? fabs(Ax[i]) : anorm;
+    for (int k = 0; k < 10 && ns < 10; ++k) {
+        if (fabs(zi[k]) > 1e-6 * (1.0 + fabs(zr[k]))) continue;
+        double lam = zr[k];
+        double v[10], y[10];
+        for (int i = 0; i < 10; ++i) v[i] = 1.0 / (1.0 + i);
+        bool ok = true;
+        for (int it = 0; it < 4 && ok; ++it) {
+            ok = fpt_solve_shifted(Ax, lam + 1e-11 * (anorm + 1.0), v, y);
+            if (!ok) break;
+            double nrm = 0.0;
+            for (int i = 0; i < 10; ++i) nrm = fabs(y[i]) > nrm ? fabs(y[i]) : nrm;
+            if (!(nrm > 0.0)) { ok = false; break; }
+            for (int i = 0; i < 10; ++i) v[i] = y[i] / nrm;
+            // eigenvalue from the component of largest magnitude: (A v)_m / v_m
+            int mi = 0;
+            for (int i = 1; i < 10; ++i) if (fabs(v[i]) > fabs(v[mi])) mi = i;
+            double av = 0.0;
+            for (int j = 0; j < 10; ++j) av += Ax[10 * mi + j] * v[j];
+            lam = av / v[mi];
+        }
+        if (!ok || fabs(v[9]) < 1e-12) continue;
+        double x = v[6] / v[9], yv = v[7] / v[9], z = v[8] / v[9];
+        // polish (x, y, z) on the ten cubic constraints themselves (Gauss-Newton, 3 unknowns): the eigen-solution
+        // of a nearly defective action matrix is only good to ~1e-5, the constraints pin it to rounding
+        for (int it = 0; it < 4; ++it) {
+            double mono[20], dmx[20], dmy[20], dmz[20];
+            for (int m = 0; m < 20; ++m) {
+                int ei, ej, ek;
+                fpt_mono_exp(m, &ei, &ej, &ek);
+                const double px[4] = { 1.0, x, x * x, x * x * x }, py[4] = { 1.0, yv, yv * yv, yv * yv * yv }, pz[4] = { 1.0, z, z * z, z * z * z };
+                mono[m] = px[ei] * py[ej] * pz[ek];
+                dmx[m] = ei ? ei * px[ei - 1] * py[ej] * pz[ek] : 0.0;
+                dmy[m] = ej ? ej * px[ei] * py[ej - 1] * pz[ek] : 0.0;
+                dmz[m] = ek ? ek * px[ei] * py[ej] * pz[ek - 1] : 0.0;
+            }
+            double JtJ[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, Jtr[3] = { 0, 0, 0 };
+            for (int r = 0; r < 10; ++r) {
+                double rr = 0.0, jx = 0.0, jy = 0.0, jz = 0.0;
+                for (int m = 0; m < 20; ++m) { rr += M0[r][m] * mono[m]; jx += M0[r][m] * dmx[m]; jy += M0[r][m] * dmy[m]; jz += M0[r][m] * dmz[m]; }
+                JtJ[0] += jx * jx; JtJ[1] += jx * jy; JtJ[2] += jx * jz; JtJ[4] += jy * jy; JtJ[5] += jy * jz; JtJ[8] += jz * jz;
+                Jtr[0] += jx * rr; Jtr[1] += jy * rr; Jtr[2] += jz * rr;
+            }
+            JtJ[3] = JtJ[1]; JtJ[6] = JtJ[2]; JtJ[7] = JtJ[5];
+            const double det = JtJ[0] * (JtJ[4] * JtJ[8] - JtJ[5] * JtJ[7]) - JtJ[1] * (JtJ[3] * JtJ[8] - JtJ[5] * JtJ[6])
+                             + JtJ[2] * (JtJ[3] * JtJ[7] - JtJ[4] * JtJ[6]);
+            if (!(fabs(det) > 1e-300)) break;
+            const double dx_ = (Jtr[0] * (JtJ[4] * JtJ[8] - JtJ[5] * JtJ[7]) - JtJ[1] * (Jtr[1] * JtJ[8] - JtJ[5] * Jtr[2])
+                              + JtJ[2] * (Jtr[1] * JtJ[7] - JtJ[4] * Jtr[2])) / det;
+            const double dy_ = (JtJ[0] * (Jtr[1] * JtJ[8] - JtJ[5] * Jtr[2]) - Jtr[0] * (JtJ[3] * JtJ[8] - JtJ[5] * JtJ[6])
+                              + JtJ[2] * (JtJ[3] * Jtr[2] - Jtr[1] * JtJ[6])) / det;
+            const double dz_ = (JtJ[0] * (JtJ[4] * Jtr[2] - Jtr[1] * JtJ[7]) - JtJ[1] * (JtJ[3] * Jtr[2] - Jtr[1] * JtJ[6])
+                              + Jtr[0] * (JtJ[3] * JtJ[7] - JtJ[4] * JtJ[6])) / det;
+            if (!(dx_ == dx_) || !(dy_ == dy_) || !(dz_ == dz_)) break;
+            x -= dx_; yv -= dy_; z -= dz_;
+            if (fabs(dx_) + fabs(dy_) + fabs(dz_) < 1e-15 * (1.0 + fabs(x) + fabs(yv) + fabs(z))) break;
+        }
+        // skip duplicates of an already accepted root
+        bool dup = false;
+        for (int s = 0; s < ns; ++s) {
+            double d = 0.0;
+            for (int c = 0; c < 9; ++c) {
+                const double ev = x * EE[0][c] + yv * EE[1][c] + z * EE[2][c] + EE[3][c];
+                d = fmax(d, fabs(ev - E_out[9 * s + c]));
+            }
+            if (d < 1e-9 * (1.0 + fabs(x) + fabs(yv) + fabs(z))) dup = true;
+        }
+        if (dup) continue;
+        bool finite = true;
+        for (int c = 0; c < 9; ++c) {
+            const double ev = x * EE[0][c] + yv * EE[1][c] + z * EE[2][c] + EE[3][c];
+            E_out[9 * ns + c] = ev;
+            finite = finite && (ev == ev) && fabs(ev) < 1e300;
+        }
+        // an eigenvalue that was not a true real root (or an eigenvector that did not settle) yields a matrix that
+        // is not essential: keep only candidates that satisfy the cubic constraints
+        if (finite && fpt_constraint_residual(E_out + 9 * ns) < 1e-9) ++ns;
+    }
+    return ns;
+}
+
+#endif

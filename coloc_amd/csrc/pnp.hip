@@ -16,6 +16,7 @@
 // relative tolerance on `cost` in the tests.
 #include "clc_internal.h"
 #include "p3p.h"
+#include "fivept.h"
 
 namespace clc {
 
@@ -503,6 +504,142 @@ __global__ __launch_bounds__(256) void epipolar_score_kernel(const double* __res
     }
     if (threadIdx.x == 0) { if (count) count[blockIdx.x] = s_cnt[0]; if (cost) cost[blockIdx.x] = s_cost[0]; }
 }
+
+// ---- essential-matrix RANSAC: five-point problems, one per lane ---------------------------
+// samples: S x 5 correspondence indices.  Each lane normalises its 5 point pairs with K1^-1 / K2^-1, solves the
+// five-point problem (csrc/fivept.h, <= 10 real solutions) and writes 10 slots of {F = K2^-T E K1^-1 (9), E (9)};
+// unused slots are NaN so that they score worst.  The arrays of the solver live in scratch memory: this kernel is
+// latency-bound by design (256 lanes), the scoring that follows is the data-parallel part.
+struct EpiResult {      // one packed record so the host needs a single D2H copy
+    double E[9];
+    double F[9];
+    double cost;
+    int32_t h;
+    int32_t count;
+};
+
+__device__ __forceinline__ void normalise_px(const double* __restrict__ K, double u, double v, double* out)
+{
+    const double yn = (v - K[5]) / K[4];
+    out[0] = (u - K[2] - K[1] * yn) / K[0];
+    out[1] = yn;
+}
+
+__global__ __launch_bounds__(64) void fivept_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
+                                                    const double* __restrict__ K1, const double* __restrict__ K2,
+                                                    const int32_t* __restrict__ samples, const int S, const int N,
+                                                    double* __restrict__ FE /* S x 10 x 18 */)
+{
+    const int sidx = blockIdx.x * 64 + threadIdx.x;
+    if (sidx >= S) return;
+    double q1[5][2], q2[5][2];
+    bool ok = true;
+    for (int p = 0; p < 5; ++p) {
+        int i = samples[5 * sidx + p];
+        if (i < 0 || i >= N) { ok = false; i = 0; }
+        normalise_px(K1, x1[2 * i], x1[2 * i + 1], q1[p]);
+        normalise_px(K2, x2[2 * i], x2[2 * i + 1], q2[p]);
+    }
+    double E[90];
+    const int n = ok ? fivept_solve(q1, q2, E) : 0;
+    // F = K2^-T E K1^-1 for upper-triangular K = [fx s cx; 0 fy cy; 0 0 1]: K^-1 = [1/fx, -s/(fx fy), (s cy - cx fy)/(fx fy); 0, 1/fy, -cy/fy; 0 0 1]
+    double A1[9], A2[9];
+    {
+        const double* Ks[2] = { K1, K2 };
+        double* As[2] = { A1, A2 };
+        for (int w = 0; w < 2; ++w) {
+            const double fx = Ks[w][0], sk = Ks[w][1], cx = Ks[w][2], fy = Ks[w][4], cy = Ks[w][5];
+            double* A = As[w];
+            A[0] = 1.0 / fx; A[1] = -sk / (fx * fy); A[2] = (sk * cy - cx * fy) / (fx * fy);
+            A[3] = 0.0; A[4] = 1.0 / fy; A[5] = -cy / fy;
+            A[6] = 0.0; A[7] = 0.0; A[8] = 1.0;
+        }
+    }
+    double* out = FE + (size_t)180 * sidx;
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    for (int k = 0; k < 10; ++k) {
+        if (k >= n) { for (int e = 0; e < 18; ++e) out[18 * k + e] = qnan; continue; }
+        const double* Ek = E + 9 * k;
+        double T[9];                                   // T = E K1^-1
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) T[3 * r + c] = Ek[3 * r] * A1[c] + Ek[3 * r + 1] * A1[3 + c] + Ek[3 * r + 2] * A1[6 + c];
+        for (int r = 0; r < 3; ++r)                    // F = K2^-T T : F[r][c] = sum_m A2[m][r] T[m][c]
+            for (int c = 0; c < 3; ++c) out[18 * k + 3 * r + c] = A2[r] * T[c] + A2[3 + r] * T[3 + c] + A2[6 + r] * T[6 + c];
+        for (int e = 0; e < 9; ++e) out[18 * k + 9 + e] = Ek[e];
+    }
+}
+
+// score the F part of every slot (stride 18 doubles)
+__global__ __launch_bounds__(256) void epipolar_score_strided_kernel(const double* __restrict__ FE, const double* __restrict__ x1,
+                                                                     const double* __restrict__ x2, const int N, const double thr2,
+                                                                     int32_t* __restrict__ count, double* __restrict__ cost)
+{
+    __shared__ double s_cost[256];
+    __shared__ int s_cnt[256];
+    const double* f = FE + (size_t)18 * blockIdx.x;
+    int cnt = 0;
+    double c = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        const double e = epipolar_err(f, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]);
+        if (e < thr2) { ++cnt; c += e; }
+        else c += thr2;
+    }
+    s_cost[threadIdx.x] = c;
+    s_cnt[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { s_cost[threadIdx.x] += s_cost[threadIdx.x + st]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { count[blockIdx.x] = s_cnt[0]; cost[blockIdx.x] = s_cost[0]; }
+}
+
+__global__ __launch_bounds__(256) void epipolar_select_mask_kernel(const double* __restrict__ FE, const int32_t* __restrict__ count,
+                                                                   const double* __restrict__ cost, const int H,
+                                                                   const double* __restrict__ x1, const double* __restrict__ x2,
+                                                                   const int N, const double thr2, uint8_t* __restrict__ mask,
+                                                                   EpiResult* __restrict__ res)
+{
+    __shared__ int s_h[256];
+    int bh = -1;
+    for (int h = threadIdx.x; h < H; h += 256)
+        if (bh < 0 || hyp_better(count, cost, h, bh)) bh = h;
+    s_h[threadIdx.x] = bh;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const int a = s_h[threadIdx.x], b = s_h[threadIdx.x + st];
+            s_h[threadIdx.x] = a < 0 ? b : ((b >= 0 && hyp_better(count, cost, b, a)) ? b : a);
+        }
+        __syncthreads();
+    }
+    const int h = s_h[0];
+    const bool ok = h >= 0 && count[h] > 0;
+    const double* f = FE + (size_t)18 * (ok ? h : 0);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 9) { res->F[threadIdx.x] = ok ? f[threadIdx.x] : 0.0; res->E[threadIdx.x] = ok ? f[9 + threadIdx.x] : 0.0; }
+        if (threadIdx.x == 9) { res->h = ok ? h : -1; res->count = ok ? count[h] : 0; res->cost = ok ? cost[h] : 0.0; }
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    mask[i] = (ok && epipolar_err(f, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1]) < thr2) ? 1 : 0;
+}
+
+hipError_t launch_essential_ransac(const double* d_x1, const double* d_x2, int N, const double* d_K1, const double* d_K2,
+                                   const int32_t* d_samples, int S, double thr2, double* d_FE, int32_t* d_count, double* d_cost,
+                                   uint8_t* d_mask, void* d_result, hipStream_t stream, Profiler* prof)
+{
+    if (S <= 0 || N <= 0) return hipSuccess;
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
+    hipLaunchKernelGGL(fivept_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, d_x1, d_x2, d_K1, d_K2, d_samples, S, N, d_FE);
+    hipLaunchKernelGGL(epipolar_score_strided_kernel, dim3(10 * S), dim3(256), 0, stream, (const double*)d_FE, d_x1, d_x2, N, thr2,
+                       d_count, d_cost);
+    hipLaunchKernelGGL(epipolar_select_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_FE,
+                       (const int32_t*)d_count, (const double*)d_cost, 10 * S, d_x1, d_x2, N, thr2, d_mask, (EpiResult*)d_result);
+    prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
+    return hipGetLastError();
+}
+size_t epi_result_bytes() { return sizeof(EpiResult); }
 
 hipError_t launch_epipolar(const double* d_F, int H, const double* d_x1, const double* d_x2, int N, double thr2, double* d_err,
                            int32_t* d_count, double* d_cost, hipStream_t stream, Profiler* prof)

@@ -218,6 +218,21 @@ int clc_epipolar_residuals(clc_ctx* ctx, const double* h_F, int H, const double*
 int clc_epipolar_score(clc_ctx* ctx, const double* h_F, int H, const double* h_x1, const double* h_x2, int N,
                        double thr2, int32_t* h_count, double* h_cost);
 
+/* Essential-matrix RANSAC on the GPU -- the role of RobustMatcher::filterEssential (RobustMatcher.hpp:153-186:
+ * ACRANSAC over essential::kernel::FivePointSolver + SymmetricEpipolarDistanceError): S minimal samples of 5
+ * correspondences -> one five-point problem per lane (<= 10 essential matrices each, csrc/fivept.h) -> all
+ * 10 S hypotheses scored over all N pixel correspondences (F = K2^-T E K1^-1) -> best = most inliers
+ * (err < thr2), then lowest truncated cost, then lowest index -> inlier mask.  h_samples: S x 5 indices
+ * (NULL = drawn from a xorshift64* stream seeded with `seed`).  Outputs (nullable): h_E, h_F 9 doubles
+ * row-major, h_inlier_mask N bytes, *n_inliers (0 = no model).  OpenMVG's a-contrario threshold selection and
+ * its solver's root order are unpinned (absent submodule). */
+int clc_essential_ransac(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1,
+                         const double* h_K2, const int32_t* h_samples, int S, uint64_t seed, double thr2,
+                         double* h_E, double* h_F, uint8_t* h_inlier_mask, int* n_inliers);
+/* The five-point hypotheses alone: h_E_out receives S x 10 x 9 doubles (NaN = no solution). */
+int clc_essential_fivepoint(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1,
+                            const double* h_K2, const int32_t* h_samples, int S, double* h_E_out);
+
 /* Whole robust pose solve on the GPU -- the role of SfM_Localizer::Localize(P3P, max_iteration = 256)
  * at Localizer.hpp:82-93: S minimal samples -> one P3P problem per lane (<= 4 poses each) -> all
  * 4 S hypotheses scored over all N correspondences in one launch -> best = most inliers (err < thr2),

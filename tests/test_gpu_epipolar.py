@@ -54,3 +54,69 @@ def test_true_fundamental_matrix_wins(gpu_ctx):
     cnt, cost = gpu_ctx.epipolar_score(Fs, x1, x2, 4.0)
     assert cnt.argmax() == 123 and cost.argmin() == 123
     assert cnt[123] >= 0.9 * (3000 - len(out))
+
+
+def _true_E(seed):
+    a = synth.pnp_scene(5, seed=seed, cam=0)
+    b = synth.pnp_scene(5, seed=seed + 3, cam=3)
+    R = b["R"] @ a["R"].T
+    t = b["t"] - R @ a["t"]
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    return tx @ R
+
+
+def _numpy_fivepoint_check(E, q1, q2):
+    """Necessary and sufficient conditions of a five-point solution: the 5 epipolar constraints, det E = 0 and
+    2 E E^T E - tr(E E^T) E = 0 (two equal singular values, one zero)."""
+    En = E / np.linalg.norm(E)
+    r = np.abs(np.einsum("ni,ij,nj->n", np.c_[q2, np.ones(5)], En, np.c_[q1, np.ones(5)])).max()
+    s = np.linalg.svd(En, compute_uv=False)
+    return r, abs(s[0] - s[1]) / s[0], s[2] / s[0]
+
+
+def test_fivepoint_hypotheses_are_valid_and_contain_the_truth(gpu_ctx):
+    N = 400
+    x1, x2, F, _ = _two_view(N, seed=91, noise=0.0, outliers=0.0)
+    K = synth.pnp_scene(5, seed=1)["K"]
+    Kinv = np.linalg.inv(K)
+    rng = np.random.default_rng(4)
+    samples = np.stack([rng.choice(N, 5, replace=False) for _ in range(200)]).astype(np.int32)
+    Es = gpu_ctx.essential_fivepoint(x1, x2, K, K, samples)
+    Et = _true_E(91)
+    Et /= np.linalg.norm(Et)
+    hits, nsol = 0, 0
+    for s in range(len(samples)):
+        q1 = (np.c_[x1[samples[s]], np.ones(5)] @ Kinv.T)[:, :2]
+        q2 = (np.c_[x2[samples[s]], np.ones(5)] @ Kinv.T)[:, :2]
+        best = 1.0
+        for E in Es[s]:
+            if np.isnan(E).any():
+                continue
+            nsol += 1
+            E = E.reshape(3, 3)
+            r, ds, s3 = _numpy_fivepoint_check(E, q1, q2)
+            # a genuine essential matrix through the 5 points; 1e-4 on the singular values: roots of the cubic
+            # constraints that are close together are only resolved to ~1e-5 (observed worst 4.4e-6)
+            assert r < 1e-9 and ds < 1e-4 and s3 < 1e-4
+            En = E / np.linalg.norm(E)
+            best = min(best, np.abs(En - Et).max(), np.abs(En + Et).max())
+        hits += best < 1e-5
+    assert hits >= 0.95 * len(samples) and 2.0 < nsol / len(samples) <= 10.0
+
+
+def test_essential_ransac_finds_the_model(gpu_ctx):
+    for N in (300, 3000):
+        x1, x2, F, out = _two_view(N, seed=60 + N, noise=0.5, outliers=0.3)
+        K = synth.pnp_scene(5, seed=1)["K"]
+        E, Fh, mask = gpu_ctx.essential_ransac(x1, x2, K, K, n_samples=256, seed=5, thr2=4.0)
+        assert E is not None
+        inl = np.ones(N, bool); inl[out] = False
+        assert (mask & inl).sum() >= 0.85 * inl.sum() and (mask & ~inl).sum() <= 0.06 * N
+        s = np.linalg.svd(E, compute_uv=False)
+        assert abs(s[0] - s[1]) / s[0] < 1e-4 and s[2] / s[0] < 1e-4
+        # same epipolar geometry as the ground truth: the true F's inliers are (almost all) ours
+        Ft = F / np.linalg.norm(F)
+        e_true = gpu_ctx.epipolar_residuals(Ft.reshape(1, 9), x1, x2)[0]
+        assert ((e_true < 4.0) & mask).sum() >= 0.9 * (e_true < 4.0).sum()
+    E, Fh, mask = gpu_ctx.essential_ransac(x1[:4], x2[:4], K, K)
+    assert E is None and not mask.any()
