@@ -63,6 +63,7 @@ struct K2nnJobDev {
     uint32_t     partial_off; // first uint2 of this job's partial slab (slab mode) / of its top-2 row (atomic mode)
     uint32_t     nq_pad;      // row length of the slab
     uint32_t     atomic_merge;// 1: splits are folded with two atomicMin per query into a top-2 row, no slab
+    uint32_t     cnt_off;     // atomic mode: first arrival counter (one per query block) of this job, in uint32 units
 };
 static constexpr int kK2nnJobsPerLaunch = 16;
 // Passed BY VALUE as the kernel argument (1.2 KB of kernarg): no job upload, no staging hazard.
@@ -76,8 +77,8 @@ struct K2nnPlan {
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
 K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks);
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
-// In atomic mode d_partial must hold 0xFF bytes in every entry the jobs use; the finalize kernel
-// leaves it that way again (self re-arming workspace).
+// In atomic mode d_partial must hold 0xFF bytes in every entry the jobs use (top-2 rows and arrival counters);
+// the workgroup that completes a query block leaves it that way again (self re-arming workspace).
 hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream,
                        Profiler* prof = nullptr);
 int k2nn_queries_per_block();

@@ -22,8 +22,9 @@
 //     their split in four and fold their results through LDS, so that 10k x 10k fills 256 CUs x 8
 //     waves/SIMD with only one 8-byte result per (query, workgroup).  Splits are folded into one {best_key, second_key} row per query with two
 //     atomicMin (keys carry the global train index, so the fold is order-free and exact -- the
-//     merge rule of SURVEY.md 8(a) note N1 with "lowest index wins" built into the key order); a
-//     tiny finalize kernel applies the threshold, writes the int32 result and re-arms the row.
+//     merge rule of SURVEY.md 8(a) note N1 with "lowest index wins" built into the key order); the
+//     workgroup whose arrival completes a query block (a per-block arrival counter) applies the threshold,
+//     writes the int32 results and re-arms rows and counter -- no second launch, no spinning.
 //     Train sets beyond 2^22 vectors fall back to per-split slabs + an ordered merge kernel.
 //
 // Bound: integer VALU (32 of the 35 lane-ops per pair are the algorithmic xor+popcount); HBM
@@ -87,6 +88,20 @@ __device__ __forceinline__ void sweep_one(const uint32_t (&q)[R][16], const u32x
         asm volatile("v_lshl_add_u32 %2, %3, 22, %4\n\tv_med3_u32 %1, %0, %1, %2\n\tv_min_u32 %0, %0, %2"
                      : "+v"(best[r]), "+v"(second[r]), "=&v"(key) : "v"(acc), "s"(t_rel));
     }
+}
+
+// {best_key, second_key} of one query -> the reference's outputs (CUDAK2NN.cu:54 sentinels, :75 acceptance)
+__device__ __forceinline__ void emit_result(const K2nnJobDev& job, const uint32_t qi, const uint32_t bkey, const uint32_t skey)
+{
+    int best_v = 100000, second_v = 200000, best_i = -1;
+    if (bkey != kEmpty) {
+        best_v = (int)(bkey >> kKeyShift);
+        best_i = (int)(bkey & kIdxMask);
+        second_v = skey == kEmpty ? 100000 : (int)(skey >> kKeyShift);
+    }
+    job.out[qi] = (best_i >= 0 && second_v - best_v > (int)job.thr) ? best_i : -1;
+    if (job.best_out) job.best_out[qi] = (uint16_t)min(best_v, 65535);
+    if (job.second_out) job.second_out[qi] = (uint16_t)min(second_v, 65535);
 }
 
 template <int R>
@@ -183,6 +198,7 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
         // order (distance, index) and the fold is commutative: whichever value leaves the `best` slot
         // (because a smaller key arrived) is offered to `second` by the arrival that displaced it.
         unsigned int* top = reinterpret_cast<unsigned int*>(partial + job.partial_off);
+        uint32_t seen = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t qi = qbase + 64u * r;
@@ -191,7 +207,31 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
                 const uint32_t skey = second[r] == kEmpty ? kEmpty : second[r] + s0;
                 const uint32_t old = atomicMin(top + 2u * qi, bkey);
                 const uint32_t cand = bkey < old ? min(old, skey) : bkey;
-                if (cand != kEmpty) atomicMin(top + 2u * qi + 1u, cand);
+                seen |= old;
+                if (cand != kEmpty) seen |= atomicMin(top + 2u * qi + 1u, cand);
+            }
+        }
+        // Arrival counter of this query block (armed at all-ones like the rows, so the n-th arrival reads n - 2).
+        // Every atomic above RETURNS a value and the wave waits for all of them (vmcnt(0)), i.e. they have been
+        // performed at the memory side -- agent-scope atomics bypass the XCD-local L2 -- before lane 0 counts this
+        // workgroup in.  Whoever arrives last therefore knows every split has been folded and turns the rows into
+        // results; rows and counter are read AND re-armed by atomic exchange, so no cached copy is ever consulted.
+        // (A __threadfence() here would be the textbook release, but its L2 write-back + invalidate per workgroup
+        // evicts the train slices the other workgroups are streaming: measured +50 % on the whole sweep.)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) : : "memory");
+        unsigned int* cnt = reinterpret_cast<unsigned int*>(partial) + job.cnt_off + qblock;
+        uint32_t arrival = 0;
+        if (lane == 0) arrival = atomicAdd(cnt, 1u) + 1u;
+        arrival = __builtin_amdgcn_readfirstlane(arrival);
+        if (arrival != job.splits - 1u) return;
+        if (lane == 0) atomicExch(cnt, kEmpty);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t qi = qbase + 64u * r;
+            if (qi < job.nq) {
+                const uint32_t bkey = atomicExch(top + 2u * qi, kEmpty);
+                const uint32_t skey = atomicExch(top + 2u * qi + 1u, kEmpty);
+                emit_result(job, qi, bkey, skey);
             }
         }
         return;
@@ -204,25 +244,14 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
     }
 }
 
-// Atomic mode: one thread per query turns the folded {best_key, second_key} into the result and
-// re-arms the row (all ones) for the next call.
-__global__ __launch_bounds__(256) void k2nn_finalize_kernel(const K2nnJobList jobs, uint2* __restrict__ top2)
+// Atomic mode, jobs with an EMPTY train set only (no sweep workgroup exists that could finalize them):
+// the reference leaves best_i uninitialised there (CUDAK2NN.cu:54,75); defined here as "no match".
+__global__ __launch_bounds__(256) void k2nn_nomatch_kernel(const K2nnJobList jobs)
 {
     const K2nnJobDev& job = jobs.j[blockIdx.y];
     const uint32_t qi = blockIdx.x * 256u + threadIdx.x;
-    if (qi >= job.nq) return;
-    uint2* row = top2 + job.partial_off + qi;
-    const uint2 e = *row;
-    *row = make_uint2(kEmpty, kEmpty);
-    int best_v = 100000, second_v = 200000, best_i = -1;      // CUDAK2NN.cu:54 sentinels
-    if (e.x != kEmpty) {
-        best_v = (int)(e.x >> kKeyShift);
-        best_i = (int)(e.x & kIdxMask);
-        second_v = e.y == kEmpty ? 100000 : (int)(e.y >> kKeyShift);
-    }
-    job.out[qi] = (best_i >= 0 && second_v - best_v > (int)job.thr) ? best_i : -1;
-    if (job.best_out) job.best_out[qi] = (uint16_t)min(best_v, 65535);
-    if (job.second_out) job.second_out[qi] = (uint16_t)min(second_v, 65535);
+    if (job.nt != 0u || qi >= job.nq) return;
+    emit_result(job, qi, kEmpty, kEmpty);
 }
 
 // Fold the per-split partials of one query and threshold.
@@ -325,6 +354,10 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
         jb.partial_off = (uint32_t)off;
         jb.atomic_merge = plan.atomic_merge ? 1u : 0u;
         off += plan.atomic_merge ? (size_t)jb.nq_pad : (size_t)splits * jb.nq_pad;
+        if (plan.atomic_merge) {                                          // arrival counters: one uint32 per query block
+            jb.cnt_off = (uint32_t)(2u * off);
+            off += (jb.qblocks + 1u) / 2u;
+        }
     }
     plan.partial_elems = off;
     return plan;
@@ -335,12 +368,13 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
     for (int base = 0; base < njobs; base += kK2nnJobsPerLaunch) {
         const int cnt = njobs - base < kK2nnJobsPerLaunch ? njobs - base : kK2nnJobsPerLaunch;
         K2nnJobList list;
-        uint32_t grid_x = 0, max_nq = 0;
+        uint32_t grid_x = 0, max_nq = 0, max_nq_empty = 0;
         for (int j = 0; j < cnt; ++j) {
             list.j[j] = jobs[base + j];
             const uint32_t gx = list.j[j].nt ? list.j[j].qblocks * list.j[j].splits : 0u;
             if (gx > grid_x) grid_x = gx;
             if (list.j[j].nq > max_nq) max_nq = list.j[j].nq;
+            if (list.j[j].nt == 0u && list.j[j].nq > max_nq_empty) max_nq_empty = list.j[j].nq;
         }
         for (int j = cnt; j < kK2nnJobsPerLaunch; ++j) list.j[j] = K2nnJobDev{};
         if (max_nq == 0) continue;
@@ -349,13 +383,15 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, false, stream);
         }
-        prof_mark(prof, CLC_KERNEL_K2NN_MERGE, true, stream);
-        if (list.j[0].atomic_merge)
-            hipLaunchKernelGGL(k2nn_finalize_kernel, dim3((max_nq + 255) / 256, cnt), dim3(256), 0, stream, list, d_partial);
-        else
+        if (list.j[0].atomic_merge) {
+            if (max_nq_empty)
+                hipLaunchKernelGGL(k2nn_nomatch_kernel, dim3((max_nq_empty + 255) / 256, cnt), dim3(256), 0, stream, list);
+        } else {
+            prof_mark(prof, CLC_KERNEL_K2NN_MERGE, true, stream);
             hipLaunchKernelGGL(k2nn_merge_kernel, dim3((max_nq + kMergeQ - 1) / kMergeQ, cnt), dim3(kMergeQ * kMergeGroups),
                                0, stream, list, (const uint2*)d_partial);
-        prof_mark(prof, CLC_KERNEL_K2NN_MERGE, false, stream);
+            prof_mark(prof, CLC_KERNEL_K2NN_MERGE, false, stream);
+        }
     }
     return hipGetLastError();
 }

@@ -118,3 +118,26 @@ def test_train_set_beyond_22_bit_index_uses_slab_merge(oracle):
     # and the atomic path still works on the same context afterwards (workspace re-armed)
     assert np.array_equal(ctx.match_2nn(Q, T[:5000], 40), oracle.k2nn(Q, T[:5000], 40))
     ctx.close()
+
+
+def test_workspace_rearms_across_changing_shapes(gpu_ctx, oracle):
+    """The top-2 rows and the per-query-block arrival counters live in one self re-arming workspace whose layout
+    changes with every call's job list: alternate shapes (different query blocks, split counts, single-split and
+    multi-job calls) on ONE context and require oracle-identical results every time."""
+    rng = np.random.default_rng(77)
+    shapes = [(130, 9000), (4000, 70), (1, 20000), (129, 129), (2500, 2500), (64, 64), (9000, 130), (300, 5000)]
+    for rep in range(3):
+        for nq, nt in shapes:
+            Q, T = synth.planted_descriptors(nq, nt, seed=int(rng.integers(1 << 30)))
+            thr = int(rng.integers(0, 80))
+            m, b, s = gpu_ctx.match_2nn(Q, T, thr, want_dist=True)
+            mo, bo, so = oracle.k2nn(Q, T, thr, want_dist=True)
+            assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so), (rep, nq, nt)
+        # a multi-job call in between: three cameras, one of them without descriptors
+        descs = [synth.random_descriptors(700, seed=rep), np.zeros((0, 64), np.uint8), synth.random_descriptors(1500, seed=50 + rep)]
+        descs[2][:200] = descs[0][:200]
+        descs[2][:200, 3] ^= 0x21
+        outs = gpu_ctx.match_pairs(descs, [(0, 1), (0, 2), (2, 0), (1, 2)], 40)
+        assert (outs[0] == -1).all() and outs[3].shape == (0,)
+        assert np.array_equal(outs[1], oracle.k2nn(descs[0], descs[2], 40))
+        assert np.array_equal(outs[2], oracle.k2nn(descs[2], descs[0], 40))
