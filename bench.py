@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real path). gloo = REHEARSAL of the N>1 code path on a box with fewer "
                          "GPUs than ranks: ranks share GPUs and the all-gather is staged through host memory")
+    ap.add_argument("--per-camera-launches", action="store_true",
+                    help="describe each camera with its own pyramid + CLATCH launch pair (the reference's call pattern) "
+                         "instead of the batched entry point")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events)")
     args = ap.parse_args()
 
@@ -117,10 +120,19 @@ def main():
     my_cmp = sum(j.nq * counts[j.pair[1]] for j in jobs)
     total_cmp = sum(counts[i] * counts[j] for i, j in multicam.exhaustive_pairs(n_cams))
 
+    # the frames of all cameras this rank owns go through ONE pyramid launch and ONE CLATCH launch
+    # (clc_describe_batch_dev; at N > 1 a rank owns one camera)
+    img_ptrs = [t.data_ptr() for t in imgs]
+    kp_ptrs = [t.data_ptr() for t in kps]
+    desc_ptrs = [(arena[c] if world == 1 else mine).data_ptr() for c in cams]
+
     def step():
-        for k, c in enumerate(cams):
-            ctx.pyramid_build_dev(imgs[k].data_ptr(), W, H, W, sptr)
-            ctx.describe_dev(kps[k].data_ptr(), NKP, (arena[c] if world == 1 else mine).data_ptr(), sptr)
+        if args.per_camera_launches:
+            for k, c in enumerate(cams):
+                ctx.pyramid_build_dev(img_ptrs[k], W, H, W, sptr)
+                ctx.describe_dev(kp_ptrs[k], NKP, desc_ptrs[k], sptr)
+        else:
+            ctx.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP] * len(cams), desc_ptrs, sptr)
         if world > 1:
             if args.backend == "nccl":
                 dist.all_gather_into_tensor(arena.view(-1), mine.view(-1))   # RCCL over xGMI, 640 KB per rank
@@ -226,7 +238,8 @@ def main():
                        "comparisons_per_step": total_cmp},
             "stages": {"clatch_us_per_launch": clatch_us, "pyramid_us_per_launch": avg_us("pyramid_kernel"),
                        "k2nn_sweep_us": sweep_us, "k2nn_merge_us": avg_us("k2nn_merge_kernel"),
-                       "Mdesc_per_s_kernel": (NKP / clatch_us) if clatch_us else None,
+                       "cameras_per_describe_launch": 1 if args.per_camera_launches else len(cams),
+                       "Mdesc_per_s_kernel": (NKP * (1 if args.per_camera_launches else len(cams)) / clatch_us) if clatch_us else None,
                        "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6},
             "roofline": roof,
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",

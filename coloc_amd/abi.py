@@ -45,7 +45,7 @@ EXPORTS = [
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
-    "clc_essential_fivepoint",
+    "clc_essential_fivepoint", "clc_describe_batch_dev",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -105,6 +105,7 @@ def load_library():
     lib.clc_pyramid_download.argtypes = [vp, ci, vp]
     lib.clc_describe.argtypes = [vp, vp, ci, vp]
     lib.clc_describe_dev.argtypes = [vp, vp, ci, vp, vp]
+    lib.clc_describe_batch_dev.argtypes = [vp, ci, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, vp]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
     lib.clc_match_2nn_dev.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
@@ -282,6 +283,15 @@ class Context:
 
     def describe_dev(self, d_kps, n, d_desc, stream=None):
         self._chk(self.lib.clc_describe_dev(self.h, d_kps, n, d_desc, stream))
+
+    def describe_batch_dev(self, d_imgs, width, height, pitch, d_kps, counts, d_desc, stream=None):
+        """Frames of several cameras (lists of device pointers / counts) in one pyramid + one CLATCH launch."""
+        n = len(d_imgs)
+        imgs = (C.c_void_p * n)(*d_imgs)
+        kps = (C.c_void_p * n)(*d_kps)
+        cnt = (C.c_int * n)(*counts)
+        out = (C.c_void_p * n)(*d_desc)
+        self._chk(self.lib.clc_describe_batch_dev(self.h, n, imgs, width, height, pitch, kps, cnt, out, stream))
 
     # -- match
     def match_2nn(self, Q, T, threshold=40, want_dist=False):

@@ -85,7 +85,8 @@ struct clc_ctx {
     // pyramid
     PyramidDesc pd{};
     uint8_t* d_arena = nullptr;
-    size_t arena_bytes = 0;
+    size_t arena_bytes = 0;      // one pyramid
+    int arena_slots = 1;         // pyramids the arena holds (grown by clc_describe_batch_dev)
     bool pyramid_valid = false;
     // detect + describe
     clc_keypoint* d_kps = nullptr;
@@ -508,6 +509,50 @@ int clc_describe_dev(clc_ctx* ctx, const clc_keypoint* d_kps, int n, void* d_des
     if (((uintptr_t)d_desc & 7u) || ((uintptr_t)d_kps & 3u)) return fail(ctx, CLC_ERR_BAD_ARG, "describe: misaligned device pointer");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     CLC_HIP(ctx, launch_clatch(ctx->pd, ctx->d_arena, d_kps, n, (uint64_t*)d_desc, pick(ctx, stream), &ctx->prof));
+    return CLC_OK;
+}
+
+int clc_describe_batch_dev(clc_ctx* ctx, int n_images, const void* const* d_imgs, uint32_t width, uint32_t height,
+                           size_t pitch, const clc_keypoint* const* d_kps, const int* counts, void* const* d_desc,
+                           void* stream)
+{
+    if (!ctx || n_images < 0 || (n_images > 0 && (!d_imgs || !d_kps || !counts || !d_desc)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "describe_batch: null argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "describe_batch: context created without detector options");
+    if (n_images > CLC_MAX_BATCH) return fail(ctx, CLC_ERR_CAPACITY, "describe_batch: more than CLC_MAX_BATCH images");
+    if (n_images == 0) return CLC_OK;
+    if (width != ctx->dopts.width || height != ctx->dopts.height || pitch < width || pitch > 0xFFFFFFFFull)
+        return fail(ctx, CLC_ERR_BAD_ARG, "describe_batch: image size differs from DetectorOptions width/height");
+    ClatchBatch batch{};
+    const uint8_t* srcs[CLC_MAX_BATCH] = {};
+    for (int b = 0; b < n_images; ++b) {
+        if (!d_imgs[b] || counts[b] < 0 || (counts[b] > 0 && (!d_kps[b] || !d_desc[b])))
+            return fail(ctx, CLC_ERR_BAD_ARG, "describe_batch: null image / keypoint / descriptor pointer");
+        if (((uintptr_t)d_desc[b] & 7u) || ((uintptr_t)d_kps[b] & 3u))
+            return fail(ctx, CLC_ERR_BAD_ARG, "describe_batch: misaligned device pointer");
+        srcs[b] = (const uint8_t*)d_imgs[b];
+        batch.kps[b] = d_kps[b];
+        batch.desc[b] = (uint64_t*)d_desc[b];
+        batch.n[b] = counts[b];
+    }
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    if (n_images > ctx->arena_slots) {
+        // grow the arena to n_images pyramids; slot 0 (the current single-image pyramid) is about to be overwritten anyway
+        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (st != ctx->stream) CLC_HIP(ctx, hipStreamSynchronize(st));
+        uint8_t* grown = nullptr;
+        CLC_HIP(ctx, hipMalloc((void**)&grown, ctx->arena_bytes * (size_t)n_images));
+        CLC_HIP(ctx, hipMemsetAsync(grown, 0, ctx->arena_bytes * (size_t)n_images, st));
+        CLC_HIP(ctx, hipStreamSynchronize(st));
+        CLC_HIP(ctx, hipFree(ctx->d_arena));
+        ctx->d_arena = grown;
+        ctx->arena_slots = n_images;
+    }
+    ctx->pyramid_valid = false;
+    CLC_HIP(ctx, launch_pyramid_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, srcs, n_images, (uint32_t)pitch, st, &ctx->prof));
+    ctx->pyramid_valid = true;
+    CLC_HIP(ctx, launch_clatch_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, n_images, st, &ctx->prof));
     return CLC_OK;
 }
 

@@ -86,6 +86,9 @@ __device__ __forceinline__ u32x2_a4 lds_read8(const uint8_t* p)
 
 struct ClatchArgs {
     PyramidDesc pd;
+    uint32_t slot_stride;                 // bytes between the pyramids of consecutive cameras (blockIdx.y = camera)
+    const uint32_t* n_dev;                // single-camera launches after the GPU detector: keypoint count in device memory
+    ClatchBatch cam;
 };
 
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
@@ -99,13 +102,16 @@ __device__ __forceinline__ int clamp_i32(int v, int hi)   // min(max(v, 0), hi) 
     return r;
 }
 
-__global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena,
-                                                    const clc_keypoint* __restrict__ kps, const int n_arg,
-                                                    const uint32_t* __restrict__ n_dev, uint64_t* __restrict__ desc)
+__global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
 {
+    const uint32_t cam = blockIdx.y;
+    const int n_arg = args.cam.n[cam];
     // keypoint count: a launch argument, or (after the GPU detector) read from device memory
-    const int n = n_dev ? min((int)*n_dev, n_arg) : n_arg;
+    const int n = args.n_dev ? min((int)*args.n_dev, n_arg) : n_arg;
     if ((int)blockIdx.x >= n) return;
+    const clc_keypoint* __restrict__ kps = args.cam.kps[cam];
+    uint64_t* __restrict__ desc = args.cam.desc[cam];
+    const uint8_t* __restrict__ arena = arena_base + (size_t)cam * args.slot_stride;
     __shared__ __attribute__((aligned(16))) uint8_t roi[kWaveLds];
     const uint32_t lane = threadIdx.x;
 
@@ -201,30 +207,50 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     }
 }
 
+static hipError_t launch_clatch_impl(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
+                                     int n_img, const uint32_t* d_count, hipStream_t stream, Profiler* prof)
+{
+    if (n_img <= 0) return hipSuccess;
+    if (n_img > kMaxBatch || slot_stride > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    ClatchArgs a;
+    a.pd = pd;
+    a.slot_stride = (uint32_t)slot_stride;
+    a.n_dev = d_count;
+    int max_n = 0;
+    for (int b = 0; b < kMaxBatch; ++b) {
+        a.cam.kps[b] = b < n_img ? batch.kps[b] : nullptr;
+        a.cam.desc[b] = b < n_img ? batch.desc[b] : nullptr;
+        a.cam.n[b] = b < n_img ? batch.n[b] : 0;
+        if (a.cam.n[b] > max_n) max_n = a.cam.n[b];
+    }
+    if (max_n <= 0) return hipSuccess;
+    const int blocks = max_n < 65536 ? max_n : 65536;   // one wave per keypoint; grid-stride beyond 64k
+    prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
+    hipLaunchKernelGGL(clatch_kernel, dim3(blocks, (uint32_t)n_img), dim3(64), 0, stream, a, arena);
+    prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_clatch_batch(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
+                               int n_img, hipStream_t stream, Profiler* prof)
+{
+    return launch_clatch_impl(pd, arena, slot_stride, batch, n_img, nullptr, stream, prof);
+}
+
 hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps, int n,
                          uint64_t* d_desc, hipStream_t stream, Profiler* prof)
 {
-    if (n <= 0) return hipSuccess;
-    ClatchArgs a;
-    a.pd = pd;
-    const int blocks = n < 65536 ? n : 65536;   // one wave per keypoint; grid-stride beyond 64k
-    prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
-    hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64), 0, stream, a, arena, d_kps, n, (const uint32_t*)nullptr, d_desc);
-    prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
-    return hipGetLastError();
+    ClatchBatch one{};
+    one.kps[0] = d_kps; one.desc[0] = d_desc; one.n[0] = n;
+    return launch_clatch_impl(pd, arena, 0, one, 1, nullptr, stream, prof);
 }
 
 hipError_t launch_clatch_counted(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
                                  const uint32_t* d_count, int max_n, uint64_t* d_desc, hipStream_t stream, Profiler* prof)
 {
-    if (max_n <= 0) return hipSuccess;
-    ClatchArgs a;
-    a.pd = pd;
-    const int blocks = max_n < 65536 ? max_n : 65536;
-    prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
-    hipLaunchKernelGGL(clatch_kernel, dim3(blocks), dim3(64), 0, stream, a, arena, d_kps, max_n, d_count, d_desc);
-    prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
-    return hipGetLastError();
+    ClatchBatch one{};
+    one.kps[0] = d_kps; one.desc[0] = d_desc; one.n[0] = max_n;
+    return launch_clatch_impl(pd, arena, 0, one, 1, d_count, stream, prof);
 }
 
 } // namespace clc

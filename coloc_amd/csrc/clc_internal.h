@@ -32,10 +32,22 @@ struct PyramidDesc {
 // arena and resample levels 1..L-1 from it.
 hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, const uint8_t* d_src, uint32_t src_pitch,
                           hipStream_t stream, Profiler* prof = nullptr);
+// The same for the frames of n_img cameras in ONE launch: image b goes to the pyramid at arena + b * slot_stride.
+static constexpr int kMaxBatch = CLC_MAX_BATCH;
+hipError_t launch_pyramid_batch(const PyramidDesc& pd, uint8_t* arena, size_t slot_stride, const uint8_t* const* d_src,
+                                int n_img, uint32_t src_pitch, hipStream_t stream, Profiler* prof = nullptr);
 
 // ---- CLATCH ----------------------------------------------------------------------------------
 hipError_t launch_clatch(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
                          int n, uint64_t* d_desc, hipStream_t stream, Profiler* prof = nullptr);
+// Keypoint lists of n_img cameras in ONE launch (blockIdx.y = camera; pyramid b at arena + b * slot_stride).
+struct ClatchBatch {
+    const clc_keypoint* kps[kMaxBatch];
+    uint64_t*           desc[kMaxBatch];
+    int                 n[kMaxBatch];
+};
+hipError_t launch_clatch_batch(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
+                               int n_img, hipStream_t stream, Profiler* prof = nullptr);
 
 // ---- detector (FAST-9 + NMS + orientation) ---------------------------------------------------
 // score: arena-shaped u8 scratch; d_count[0] = keypoints written (<= maxkp), d_count[1] = found.

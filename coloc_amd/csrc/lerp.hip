@@ -9,7 +9,7 @@
 // written in the source, no FMA contraction (the file is built with -ffp-contract=off).
 //
 // MI355X shape: the reference issues 7 launches on 7 streams (GPUDetector.hpp:250-255); here ALL
-// levels AND the level-0 copy into the pyramid arena are one launch.  Each lane produces 4 horizontally adjacent output pixels and stores one
+// levels AND the level-0 copy into the pyramid arena are one launch -- for the frames of up to CLC_MAX_BATCH cameras at once (blockIdx.y = camera).  Each lane produces 4 horizontally adjacent output pixels and stores one
 // dword, so a wave writes 256 contiguous bytes; the source taps are plain byte loads from the
 // L2-resident level-0 image (640x480 = 300 KB).  HBM-trivial: writes 2.09 x W x H bytes.
 #include "clc_internal.h"
@@ -20,6 +20,8 @@ struct LerpArgs {
     PyramidDesc pd;
     uint32_t src_pitch;      // bytes per row of the caller's level-0 image
     uint32_t copy_blocks;    // leading workgroups that copy level 0 into the arena (0 = already there)
+    uint32_t slot_stride;    // bytes between the pyramids of consecutive images (blockIdx.y = image)
+    const uint8_t* src[kMaxBatch];   // level-0 image of each camera
 };
 
 __device__ __forceinline__ float tap(const uint8_t* __restrict__ img, uint32_t pitch, int W, int H, int x, int y)
@@ -29,9 +31,10 @@ __device__ __forceinline__ float tap(const uint8_t* __restrict__ img, uint32_t p
     return (float)img[(size_t)y * pitch + (size_t)x] / 255.0f;
 }
 
-__global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t* __restrict__ arena,
-                                                      const uint8_t* __restrict__ src0)
+__global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t* __restrict__ arena_base)
 {
+    uint8_t* __restrict__ arena = arena_base + (size_t)blockIdx.y * a.slot_stride;
+    const uint8_t* __restrict__ src0 = a.src[blockIdx.y];
     const LevelDesc L0 = a.pd.lv[0];
     if (blockIdx.x < a.copy_blocks) {
         // level 0: copy the caller's image into the arena (dword stores; CLATCH samples it from there).
@@ -91,21 +94,31 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t*
     *reinterpret_cast<uint32_t*>(arena + L.offset + (size_t)y * L.pitch + x0) = packed;
 }
 
-hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, const uint8_t* d_src, uint32_t src_pitch,
-                          hipStream_t stream, Profiler* prof)
+hipError_t launch_pyramid_batch(const PyramidDesc& pd, uint8_t* arena, size_t slot_stride, const uint8_t* const* d_src,
+                                int n_img, uint32_t src_pitch, hipStream_t stream, Profiler* prof)
 {
+    if (n_img <= 0) return hipSuccess;
+    if (n_img > kMaxBatch || slot_stride > 0xFFFFFFFFull) return hipErrorInvalidValue;
     LerpArgs a;
     a.pd = pd;
-    // d_src == level 0 inside the arena: nothing to copy
-    const bool in_place = d_src == arena + pd.lv[0].offset;
+    // d_src == level 0 inside the arena (single image only): nothing to copy
+    const bool in_place = n_img == 1 && d_src[0] == arena + pd.lv[0].offset;
     a.src_pitch = in_place ? pd.lv[0].pitch : src_pitch;
     a.copy_blocks = in_place ? 0u : (pd.lv[0].pitch / 4 * pd.lv[0].h + 255) / 256;
+    a.slot_stride = (uint32_t)slot_stride;
+    for (int b = 0; b < kMaxBatch; ++b) a.src[b] = b < n_img ? d_src[b] : nullptr;
     const uint32_t nblk = a.copy_blocks + (pd.levels > 1 ? pd.blk_begin[pd.levels] : 0u);
     if (nblk == 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_PYRAMID, true, stream);
-    hipLaunchKernelGGL(pyramid_kernel, dim3(nblk), dim3(256), 0, stream, a, arena, d_src);
+    hipLaunchKernelGGL(pyramid_kernel, dim3(nblk, (uint32_t)n_img), dim3(256), 0, stream, a, arena);
     prof_mark(prof, CLC_KERNEL_PYRAMID, false, stream);
     return hipGetLastError();
+}
+
+hipError_t launch_pyramid(const PyramidDesc& pd, uint8_t* arena, const uint8_t* d_src, uint32_t src_pitch,
+                          hipStream_t stream, Profiler* prof)
+{
+    return launch_pyramid_batch(pd, arena, 0, &d_src, 1, src_pitch, stream, prof);
 }
 
 } // namespace clc

@@ -36,6 +36,7 @@ extern "C" {
 #define CLC_ABI_VERSION 1
 #define CLC_DESC_BYTES 64
 #define CLC_MAX_LEVELS 8
+#define CLC_MAX_BATCH 8    /* cameras per clc_describe_batch_dev call */
 
 /* status codes */
 enum {
@@ -164,6 +165,15 @@ int clc_detect_and_describe(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, 
 /* n keypoints on the current pyramid -> n x 64 B descriptors. */
 int clc_describe(clc_ctx* ctx, const clc_keypoint* h_kps, int n, uint8_t* h_desc);
 int clc_describe_dev(clc_ctx* ctx, const clc_keypoint* d_kps, int n, void* d_desc, void* stream);
+/* A host that owns several cameras on one GPU (BASELINE configs 2-3: ColoC::processImages walks the drones one
+ * by one, coloc.hpp:150-163) hands over the frames of all n_images <= CLC_MAX_BATCH cameras at once: ONE pyramid
+ * launch and ONE CLATCH launch for all of them instead of one pair per camera -- same results as n_images times
+ * clc_pyramid_build_dev + clc_describe_dev.  d_imgs[b]: u8 width x height device image (pitch bytes per row, the
+ * DetectorOptions size); d_kps[b] / counts[b]: that camera's keypoints; d_desc[b]: counts[b] x 64 B out.  The
+ * pointer arrays themselves are host memory.  Afterwards camera 0's pyramid is the context's current one. */
+int clc_describe_batch_dev(clc_ctx* ctx, int n_images, const void* const* d_imgs, uint32_t width, uint32_t height,
+                           size_t pitch, const clc_keypoint* const* d_kps, const int* counts, void* const* d_desc,
+                           void* stream);
 /* {scale*x, scale*y, 7*scale, angle}, scale = pow(1.2f, level): GPUDetector.hpp:172-179. */
 int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4);
 

@@ -154,3 +154,43 @@ def test_more_than_65536_keypoints_grid_stride(oracle):
     assert np.array_equal(d[idx], oracle.clatch(pyr, kps[idx]))
     assert len({bytes(r) for r in d[::97]}) > 500
     ctx.close()
+
+
+def test_batched_cameras_equal_per_image_calls(oracle):
+    """clc_describe_batch_dev (one pyramid + one CLATCH launch for several cameras) == the per-image path, bit for
+    bit, including a camera without keypoints, ragged counts and a pitched source image; camera 0's pyramid is the
+    context's current one afterwards, and growing the batch on the same context works."""
+    import torch
+    W, H = 320, 240
+    pitch = 384
+    ctx, single = _ctx(W, H, 4096), _ctx(W, H, 4096)
+    for n_cam, counts in [(3, [1500, 0, 2500]), (5, [7, 64, 1, 3000, 129])]:
+        imgs = [synth.rect_image(W, H, seed=4000 + 10 * n_cam + c, noise_sigma=2.0) for c in range(n_cam)]
+        kps = [synth.random_keypoints(counts[c], W, H, seed=4100 + 10 * n_cam + c) for c in range(n_cam)]
+        d_imgs = []
+        for im in imgs:
+            t = torch.zeros((H, pitch), dtype=torch.uint8, device="cuda:0")
+            t[:, :W] = torch.from_numpy(im).cuda()
+            d_imgs.append(t)
+        d_kps = [torch.from_numpy(k.view(np.uint8).reshape(-1, 20).copy()).cuda() if len(k) else torch.zeros((1, 20), dtype=torch.uint8, device="cuda:0") for k in kps]
+        d_desc = [torch.full((max(c, 1), 64), 0xAB, dtype=torch.uint8, device="cuda:0") for c in counts]
+        torch.cuda.synchronize()
+        ctx.describe_batch_dev([t.data_ptr() for t in d_imgs], W, H, pitch, [t.data_ptr() for t in d_kps], counts,
+                               [t.data_ptr() for t in d_desc])
+        ctx.sync()
+        for c in range(n_cam):
+            single.pyramid_build(imgs[c])
+            want = single.describe(kps[c]) if counts[c] else np.zeros((0, 64), np.uint8)
+            got = d_desc[c].cpu().numpy()[:counts[c]]
+            assert np.array_equal(got, want), "camera %d of %d" % (c, n_cam)
+            if counts[c] == 0:
+                assert (d_desc[c].cpu().numpy() == 0xAB).all()          # nothing written for an empty camera
+        pyr0 = oracle.pyramid(imgs[0])
+        for lv in range(8):
+            assert np.array_equal(ctx.pyramid_download(lv), pyr0[lv])
+        # and the oracle itself on one camera of the batch
+        c = n_cam - 2
+        assert np.array_equal(d_desc[c].cpu().numpy()[:counts[c]], oracle.clatch(oracle.pyramid(imgs[c]), kps[c]))
+    with pytest.raises(Exception):
+        ctx.describe_batch_dev([0] * 9, W, H, pitch, [0] * 9, [0] * 9, [0] * 9)
+    ctx.close(); single.close()
