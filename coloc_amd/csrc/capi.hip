@@ -107,6 +107,7 @@ struct clc_ctx {
     size_t partial_cap = 0;
     bool partial_dirty = false;      // armed (all-ones) state of the atomic top-2 rows was lost
     int target_blocks = 6144;
+    bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
     size_t pairs_cap = 0;
@@ -192,7 +193,7 @@ int ensure_pnp(clc_ctx* ctx, size_t doubles)
 
 int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
 {
-    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), ctx->target_blocks);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), ctx->target_blocks, ctx->xcd_map);
     const int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;
     if (!plan.atomic_merge) ctx->partial_dirty = true;           // slab mode scribbles over the armed rows
@@ -256,6 +257,7 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         const int v = atoi(e);
         if (v > 0) ctx->target_blocks = v;
     }
+    if (const char* e = getenv("CLC_K2NN_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     if (dopts) {
         ctx->has_det = true;
         ctx->dopts = *dopts;

@@ -87,7 +87,7 @@ struct K2nnPlan {
     bool     atomic_merge; // every job fits the 22-bit global train index -> atomic top-2 merge
 };
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks);
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true);
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
 // In atomic mode d_partial must hold 0xFF bytes in every entry the jobs use (top-2 rows and arrival counters);
 // the workgroup that completes a query block leaves it that way again (self re-arming workspace).

@@ -110,9 +110,14 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
 {
     __shared__ uint32_t s_best[kWaves - 1][R][64], s_second[kWaves - 1][R][64];
     const K2nnJobDev& job = jobs.j[blockIdx.y];
+    // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own L2.
+    // The planner makes `splits` a multiple of 8 (and with it gridDim.x), so XCD x only ever sees the train splits
+    // with (split & 7) == x: each L2 holds an eighth of T plus the queries, the 8 L2s together pull 8 Q + T from HBM
+    // instead of 8 (Q + T), and every XCD gets exactly the same number of workgroups.  (A 2 x 4 arrangement -- half
+    // of Q, a quarter of T per XCD -- fetches less still but leaves the XCDs 8 % out of balance at 79 query blocks
+    // x 78 splits: measured 2 % slower.)
     const uint32_t nblk = job.qblocks * job.splits;
     if (blockIdx.x >= nblk) return;
-    // consecutive workgroups walk the splits of one query block: they read disjoint train slices
     const uint32_t qblock = blockIdx.x / job.splits;
     const uint32_t split = blockIdx.x - qblock * job.splits;
 
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(kMergeQ * kMergeGroups) void k2nn_merge_kernel(cons
     if (job.second_out) job.second_out[qi] = (uint16_t)min(a.second_v, 65535);
 }
 
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map)
 {
     K2nnPlan plan{0, true};
     for (int j = 0; j < njobs; ++j)
@@ -345,6 +350,8 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks)
         uint32_t splits = want;
         const uint32_t max_splits = jb.nt / 64u > 0 ? jb.nt / 64u : 1u;   // >= 64 train vectors per split (16 per wave)
         if (splits > max_splits) splits = max_splits;
+        // a multiple of 8 splits pins train split s to XCD s & 7 (see the sweep kernel)
+        if (xcd_map && splits >= 8u) splits = (splits + 4u) / 8u * 8u > max_splits ? splits / 8u * 8u : (splits + 4u) / 8u * 8u;
         uint32_t per = jb.nt ? (jb.nt + splits - 1) / splits : 1u;
         if (per > kIdxMask + 1u) per = kIdxMask + 1u;                     // index field is 22 bits
         splits = jb.nt ? (jb.nt + per - 1) / per : 1u;
