@@ -545,8 +545,10 @@ int clc_describe_batch_dev(clc_ctx* ctx, int n_images, const void* const* d_imgs
         if (st != ctx->stream) CLC_HIP(ctx, hipStreamSynchronize(st));
         uint8_t* grown = nullptr;
         CLC_HIP(ctx, hipMalloc((void**)&grown, ctx->arena_bytes * (size_t)n_images));
-        CLC_HIP(ctx, hipMemsetAsync(grown, 0, ctx->arena_bytes * (size_t)n_images, st));
-        CLC_HIP(ctx, hipStreamSynchronize(st));
+        hipError_t e = hipMemsetAsync(grown, 0, ctx->arena_bytes * (size_t)n_images, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { (void)hipFree(grown); return fail(ctx, CLC_ERR_HIP, "describe_batch: arena growth", e); }
+        ctx->pyramid_valid = false;
         CLC_HIP(ctx, hipFree(ctx->d_arena));
         ctx->d_arena = grown;
         ctx->arena_slots = n_images;
