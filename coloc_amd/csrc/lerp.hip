@@ -24,11 +24,15 @@ struct LerpArgs {
     const uint8_t* src[kMaxBatch];   // level-0 image of each camera
 };
 
-__device__ __forceinline__ float tap(const uint8_t* __restrict__ img, uint32_t pitch, int W, int H, int x, int y)
+// normalized-float texel read: u8 / 255.0f (GPUDetector.hpp:239).  The correctly rounded quotient is taken from a
+// 256-entry table that each workgroup fills with that very division (one per thread) -- a tap then costs one LDS
+// read instead of a ~10-instruction IEEE division, 16 times per lane.
+__device__ __forceinline__ float tap(const uint8_t* __restrict__ img, uint32_t pitch, int W, int H, int x, int y,
+                                     const float* __restrict__ unorm)
 {
     x = min(max(x, 0), W - 1);
     y = min(max(y, 0), H - 1);
-    return (float)img[(size_t)y * pitch + (size_t)x] / 255.0f;
+    return unorm[img[(size_t)y * pitch + (size_t)x]];
 }
 
 __global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t* __restrict__ arena_base)
@@ -51,6 +55,9 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t*
         *reinterpret_cast<uint32_t*>(arena + L0.offset + (size_t)y * L0.pitch + x0) = packed;
         return;
     }
+    __shared__ float unorm[256];
+    unorm[threadIdx.x] = (float)threadIdx.x / 255.0f;
+    __syncthreads();
     const uint32_t bid = blockIdx.x - a.copy_blocks;
     // which level does this workgroup belong to?  (wave-uniform scan over <= 7 entries)
     int lv = 1;
@@ -79,10 +86,10 @@ __global__ __launch_bounds__(256) void pyramid_kernel(const LerpArgs a, uint8_t*
         const float fx = ((float)x + 0.5f) * gs - 0.5f;      // :165
         const float fl_x = floorf(fx);
         const int i = (int)fl_x;
-        const float f_w = tap(src, a.src_pitch, W, H, i, j);
-        const float f_z = tap(src, a.src_pitch, W, H, i + 1, j);
-        const float f_x = tap(src, a.src_pitch, W, H, i, j + 1);
-        const float f_y = tap(src, a.src_pitch, W, H, i + 1, j + 1);
+        const float f_w = tap(src, a.src_pitch, W, H, i, j, unorm);
+        const float f_z = tap(src, a.src_pitch, W, H, i + 1, j, unorm);
+        const float f_x = tap(src, a.src_pitch, W, H, i, j + 1, unorm);
+        const float f_y = tap(src, a.src_pitch, W, H, i + 1, j + 1, unorm);
         const float wt_x = fx - fl_x;
         const float invwt_x = 1.0f - wt_x;
         const float xa = invwt_x * f_w + wt_x * f_z;         // :172
