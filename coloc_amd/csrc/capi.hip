@@ -106,7 +106,7 @@ struct clc_ctx {
     uint2* d_partial = nullptr;
     size_t partial_cap = 0;
     bool partial_dirty = false;      // armed (all-ones) state of the atomic top-2 rows was lost
-    int target_blocks = 4096;        // K2NN sweep workgroups aimed at per launch (4096..6144 measured equal; fewer = fewer atomics)
+    int target_blocks = 2560;        // K2NN sweep workgroups (of 8 waves) aimed at per launch
     bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results

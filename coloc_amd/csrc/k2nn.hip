@@ -18,8 +18,8 @@
 //     Unsigned order on keys is (distance, index) lexicographic, so best' = min(best, key) keeps
 //     the lowest index among equal distances, and second' = med3(best, second, key) is the second
 //     smallest key = the second smallest distance of the multiset.  3 more lane-ops per pair.
-//   * 2-D decomposition: (query block of 128) x (train split), and the 4 waves of a workgroup cut
-//     their split in four and fold their results through LDS, so that 10k x 10k fills 256 CUs x 8
+//   * 2-D decomposition: (query block of 128) x (train split), and the 8 waves of a workgroup cut
+//     their split in eight and fold their results through LDS, so that 10k x 10k fills 256 CUs x 8
 //     waves/SIMD with only one 8-byte result per (query, workgroup).  Splits are folded into one {best_key, second_key} row per query with two
 //     atomicMin (keys carry the global train index, so the fold is order-free and exact -- the
 //     merge rule of SURVEY.md 8(a) note N1 with "lowest index wins" built into the key order); the
@@ -34,7 +34,7 @@
 namespace clc {
 
 static constexpr int kR = 2;                 // queries per lane
-static constexpr int kWaves = 4;             // waves per workgroup
+static constexpr int kWaves = 8;             // waves per workgroup
 static constexpr int kQPerBlock = 64 * kR;   // the kWaves waves of a workgroup share these queries and cut the train slice in kWaves
 static constexpr uint32_t kKeyShift = 22;    // distance <= 512 needs 10 bits; 22 bits of index
 static constexpr uint32_t kIdxMask = (1u << kKeyShift) - 1u;
@@ -348,7 +348,8 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map)
     for (int j = 0; j < njobs; ++j) {
         K2nnJobDev& jb = jobs[j];
         uint32_t splits = want;
-        const uint32_t max_splits = jb.nt / 64u > 0 ? jb.nt / 64u : 1u;   // >= 64 train vectors per split (16 per wave)
+        const uint32_t min_per = 16u * kWaves;                              // >= 16 train vectors per wave
+        const uint32_t max_splits = jb.nt / min_per > 0 ? jb.nt / min_per : 1u;
         if (splits > max_splits) splits = max_splits;
         // a multiple of 8 splits pins train split s to XCD s & 7 (see the sweep kernel)
         if (xcd_map && splits >= 8u) splits = (splits + 4u) / 8u * 8u > max_splits ? splits / 8u * 8u : (splits + 4u) / 8u * 8u;
