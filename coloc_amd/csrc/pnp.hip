@@ -101,12 +101,13 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
         const double nrm = sqrt(xn * xn + yn * yn + 1.0);
         f[p][0] = xn / nrm; f[p][1] = yn / nrm; f[p][2] = 1.0 / nrm;
     }
-    double sol[48];
-    const int n = ok ? p3p_solve(Xs, f, sol) : 0;
+    // the solver writes its poses straight into this lane's four global slots (a local staging array would live in
+    // scratch memory: it is indexed by the running solution count)
     double* out = Rt + (size_t)48 * sidx;
+    const int n = ok ? p3p_solve(Xs, f, out) : 0;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int k = 0; k < 4; ++k)
-        for (int e = 0; e < 12; ++e) out[12 * k + e] = k < n ? sol[12 * k + e] : qnan;
+    for (int k = n; k < 4; ++k)
+        for (int e = 0; e < 12; ++e) out[12 * k + e] = qnan;
 }
 
 // best hypothesis: most inliers, then lowest cost, then lowest index -- and its inlier mask, in ONE
