@@ -52,42 +52,42 @@ typedef u32x2 __attribute__((address_space(1)))* global_u2_ptr;
 
 int k2nn_queries_per_block() { return kQPerBlock; }
 
-// One 32-bit word of the distance: xor with the (scalar) train word, immediately consumed by the
-// popcount-accumulate.  Emitted as ONE asm statement on purpose: when the v_bcnt directly follows the v_xor
-// that feeds it, the pair issues in ~6.3 cycles; scheduled apart (as the compiler does to "hide latency")
-// the same two instructions cost ~8 (profiles/r01_valu_issue_rates.txt) -- worth 8 % of the sweep.
-__device__ __forceinline__ uint32_t xor_bcnt_acc(uint32_t q, uint32_t t_scalar, uint32_t acc)
-{
-    uint32_t tmp;
-    asm volatile("v_xor_b32 %1, %3, %2\n\tv_bcnt_u32_b32 %0, %1, %0" : "+v"(acc), "=&v"(tmp) : "v"(q), "s"(t_scalar));
-    return acc;
-}
-__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// One train vector (16 wave-uniform dwords) against the R queries of this lane.
+// One train vector (16 wave-uniform dwords in SGPRs) against the R queries of this lane.
+//
+// Per query: 16 x (v_xor_b32 with the scalar train word, immediately consumed by v_bcnt_u32_b32 with accumulate), then
+// key = (distance << 22) + index; second = med3(best, second, key); best = min(best, key).
+// The exact instruction pattern is measured, not guessed (20k x 20k sweep, same device):
+//     v_xor ; v_bcnt ; s_nop 0     311-313 us   <- this file
+//     v_xor ; v_bcnt               368 us       (back to back: the SGPR-operand v_xor after a v_bcnt costs a full 4 cycles)
+//     v_xor ; s_nop 0 ; v_bcnt     324 us       v_xor ; s_nop ; v_bcnt ; s_nop   377 us
+//     ... ; s_nop 1 / two s_nop 0 / s_nop 3 after the pair   316 / 317 / 314 us
+// i.e. the v_bcnt must directly follow the v_xor that feeds it and ONE idle issue slot must follow the pair: then a
+// pair issues in ~6.3 cycles instead of 8 (profiles/r01_valu_issue_rates.txt).  The compiler used to supply that
+// s_nop by accident (it pads every asm statement with a hazard nop); it is spelled out here so that the pattern does
+// not depend on it (an s_nop inside the three top-2 instructions, or the VOP3 encoding of the v_xor, changed nothing or
+// cost 1-2 %).  The first v_bcnt accumulates onto the literal 0 (no v_mov to clear the accumulator).
 template <int R>
 __device__ __forceinline__ void sweep_one(const uint32_t (&q)[R][16], const u32x4 a, const u32x4 b,
                                           const u32x4 c, const u32x4 d, const uint32_t t_rel,
                                           uint32_t (&best)[R], uint32_t (&second)[R])
 {
-    const uint32_t tw[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w,
-                              c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+#define K2NN_PAIR(t, q, accin) "v_xor_b32 %1, " t ", " q "\n\tv_bcnt_u32_b32 %0, %1, " accin "\n\ts_nop 0\n\t"
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        uint32_t acc = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) acc = xor_bcnt_acc(q[r][k], tw[k], acc);
-        // key = (distance << 22) + index; second = med3(best, second, key); best = min(best, key) -- again as
-        // one dependent run (each instruction consumes the previous result)
-        uint32_t key;
-        asm volatile("v_lshl_add_u32 %2, %3, 22, %4\n\tv_med3_u32 %1, %0, %1, %2\n\tv_min_u32 %0, %0, %2"
-                     : "+v"(best[r]), "+v"(second[r]), "=&v"(key) : "v"(acc), "s"(t_rel));
+        uint32_t acc, tmp;
+        asm volatile(K2NN_PAIR("%10", "%2", "0") K2NN_PAIR("%11", "%3", "%0") K2NN_PAIR("%12", "%4", "%0") K2NN_PAIR("%13", "%5", "%0")
+                     K2NN_PAIR("%14", "%6", "%0") K2NN_PAIR("%15", "%7", "%0") K2NN_PAIR("%16", "%8", "%0") K2NN_PAIR("%17", "%9", "%0")
+                     : "=&v"(acc), "=&v"(tmp)
+                     : "v"(q[r][0]), "v"(q[r][1]), "v"(q[r][2]), "v"(q[r][3]), "v"(q[r][4]), "v"(q[r][5]), "v"(q[r][6]), "v"(q[r][7]),
+                       "s"(a.x), "s"(a.y), "s"(a.z), "s"(a.w), "s"(b.x), "s"(b.y), "s"(b.z), "s"(b.w));
+        asm volatile(K2NN_PAIR("%12", "%4", "%0") K2NN_PAIR("%13", "%5", "%0") K2NN_PAIR("%14", "%6", "%0") K2NN_PAIR("%15", "%7", "%0")
+                     K2NN_PAIR("%16", "%8", "%0") K2NN_PAIR("%17", "%9", "%0") K2NN_PAIR("%18", "%10", "%0") K2NN_PAIR("%19", "%11", "%0")
+                     "v_lshl_add_u32 %1, %0, 22, %20\n\tv_med3_u32 %3, %2, %3, %1\n\tv_min_u32 %2, %2, %1"
+                     : "+v"(acc), "=&v"(tmp), "+v"(best[r]), "+v"(second[r])
+                     : "v"(q[r][8]), "v"(q[r][9]), "v"(q[r][10]), "v"(q[r][11]), "v"(q[r][12]), "v"(q[r][13]), "v"(q[r][14]), "v"(q[r][15]),
+                       "s"(c.x), "s"(c.y), "s"(c.z), "s"(c.w), "s"(d.x), "s"(d.y), "s"(d.z), "s"(d.w), "s"(t_rel));
     }
+#undef K2NN_PAIR
 }
 
 // {best_key, second_key} of one query -> the reference's outputs (CUDAK2NN.cu:54 sentinels, :75 acceptance)
