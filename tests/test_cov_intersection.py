@@ -21,7 +21,8 @@ def _spd(rng, scale):
 
 def test_cov_intersection_matches_restatement(tmp_path):
     exe = tmp_path / "ci"
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "coloc_amd", "host"),
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-Wall", "-Wextra", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "coloc_amd", "host"),
                            os.path.join(ROOT, "tests", "host", "ci_driver.cpp"), "-o", str(exe)])
     rng = np.random.default_rng(0)
     cases = []

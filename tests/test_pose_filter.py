@@ -13,7 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def driver(tmp_path_factory):
     exe = tmp_path_factory.mktemp("pf") / "pf"
-    subprocess.check_call(["g++", "-std=c++14", "-O2", "-Wall", "-I", os.path.join(ROOT, "coloc_amd", "host"),
+    # ASan + UBSan: these headers are host code, the only place where sanitizers can run (none on the GPU pool)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-g", "-Wall", "-Wextra", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "coloc_amd", "host"),
                            os.path.join(ROOT, "tests", "host", "pose_filter_driver.cpp"), "-o", str(exe)])
     return str(exe)
 
