@@ -286,7 +286,9 @@ def main():
         out["pose_solve"] = {"what": "clc_pnp_ransac: 256 P3P samples, <=1024 hypotheses x N matches, thr 4 px, host buffers in/out; "
                                      "with_refine = clc_pnp_localize (the same + LM/Huber(16) refinement on the inliers + 6x6 covariance, one submission)",
                              **pose}
-        out["pose_solve_p50_ms"] = pose["N1000"]["p50_ms"]
+        # what the reference times as "PNP in ms" (coloc.hpp:222-225) is localizeImage = robust solve + refinement + covariance
+        out["pose_solve_p50_ms"] = pose["N1000"]["with_refine_p50_ms"]
+        out["pose_ransac_only_p50_ms"] = pose["N1000"]["p50_ms"]
         if not args.no_cpu_baseline and world == 1:
             dq = arena[0].cpu().numpy()
             dt_ = arena[1].cpu().numpy()

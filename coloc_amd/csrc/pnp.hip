@@ -183,7 +183,10 @@ __device__ __forceinline__ void rodrigues(const double* w, double* R)
         R[0] = 1; R[1] = -w[2]; R[2] = w[1]; R[3] = w[2]; R[4] = 1; R[5] = -w[0]; R[6] = -w[1]; R[7] = w[0]; R[8] = 1;
         return;
     }
-    const double th = sqrt(th2), c = cos(th), s = sin(th), k0 = w[0] / th, k1 = w[1] / th, k2 = w[2] / th, v = 1.0 - c;
+    const double th = sqrt(th2), ith = 1.0 / th;
+    double s, c;
+    sincos(th, &s, &c);                 // one shared range reduction
+    const double k0 = w[0] * ith, k1 = w[1] * ith, k2 = w[2] * ith, v = 1.0 - c;
     R[0] = c + k0 * k0 * v;      R[1] = k0 * k1 * v - k2 * s; R[2] = k0 * k2 * v + k1 * s;
     R[3] = k1 * k0 * v + k2 * s; R[4] = c + k1 * k1 * v;      R[5] = k1 * k2 * v - k0 * s;
     R[6] = k2 * k0 * v - k1 * s; R[7] = k2 * k1 * v + k0 * s; R[8] = c + k2 * k2 * v;
@@ -234,11 +237,27 @@ __device__ __forceinline__ void d_rodrigues(const double* w, const double* R, do
     }
 }
 
+// One entry of the same derivative: element e (0..8) of dR/dw_k, for 27 lanes working in parallel.
+__device__ __forceinline__ double d_rodrigues_entry(const double* w, const double* R, const int k, const int e)
+{
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (th2 < 1e-16) {
+        const int pos = k == 0 ? 7 : (k == 1 ? 2 : 3), neg = k == 0 ? 5 : (k == 1 ? 6 : 1);
+        return e == pos ? 1.0 : (e == neg ? -1.0 : 0.0);
+    }
+    const double m0 = (k == 0 ? 1.0 : 0.0) - R[0 + k], m1 = (k == 1 ? 1.0 : 0.0) - R[3 + k], m2 = (k == 2 ? 1.0 : 0.0) - R[6 + k];
+    const double u0 = w[1] * m2 - w[2] * m1, u1 = w[2] * m0 - w[0] * m2, u2 = w[0] * m1 - w[1] * m0;
+    const double b0 = w[k] * w[0] + u0, b1 = w[k] * w[1] + u1, b2 = w[k] * w[2] + u2;
+    const double A[9] = { 0, -b2, b1, b2, 0, -b0, -b1, b0, 0 };
+    const int i = e / 3, j = e - 3 * i;
+    return (A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j] + A[3 * i + 2] * R[6 + j]) / th2;
+}
+
 // Cholesky solve of the damped 6x6 system (A + lambda diag(A)) d = g; returns false if not SPD
 __device__ __forceinline__ bool solve6(const double* A, const double* g, double lambda, double* d)
 {
     // fully unrolled (compile-time indices) so that L, y stay in registers instead of scratch
-    double L[36];
+    double L[36], Linv[6];    // Linv[i] = 1 / L[i][i]: six divisions instead of twenty-seven
     bool spd = true;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
@@ -247,8 +266,8 @@ __device__ __forceinline__ bool solve6(const double* A, const double* g, double 
             double sum = A[6 * i + j] + (i == j ? lambda * (A[6 * i + i] > 1e-12 ? A[6 * i + i] : 1e-12) : 0.0);
 #pragma unroll
             for (int k = 0; k < j; ++k) sum -= L[6 * i + k] * L[6 * j + k];
-            if (i == j) { spd = spd && (sum > 0.0); L[6 * i + i] = sqrt(sum > 0.0 ? sum : 1.0); }
-            else L[6 * i + j] = sum / L[6 * j + j];
+            if (i == j) { spd = spd && (sum > 0.0); L[6 * i + i] = sqrt(sum > 0.0 ? sum : 1.0); Linv[i] = 1.0 / L[6 * i + i]; }
+            else L[6 * i + j] = sum * Linv[j];
         }
     }
     if (!spd) return false;
@@ -258,14 +277,14 @@ __device__ __forceinline__ bool solve6(const double* A, const double* g, double 
         double sum = g[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) sum -= L[6 * i + k] * y[k];
-        y[i] = sum / L[6 * i + i];
+        y[i] = sum * Linv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double sum = y[i];
 #pragma unroll
         for (int k = i + 1; k < 6; ++k) sum -= L[6 * k + i] * d[k];
-        d[i] = sum / L[6 * i + i];
+        d[i] = sum * Linv[i];
     }
     return true;
 }
@@ -298,10 +317,11 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
         if (threadIdx.x == 0) { out->cost = 0.0; out->rmse = 0.0; out->iterations = 0; out->n_used = 0; }
         return;
     }
-    __shared__ double s_par[6], s_try[6], s_R[9], s_dR[3][9], s_sum[kRefineWaves][kRefineSums], s_tot[kRefineSums];
+    extern __shared__ double red[];     // [kRefineSums][kRefineThreads] reduction scratch (dynamic: 116 KB)
+    __shared__ double s_par[6], s_try[6], s_R[9], s_dR[3][9], s_part[kRefineSums][16], s_tot[kRefineSums];
     __shared__ double s_A[kRefineSums];   // sums (JtWJ, JtWr, cost, count) at the CURRENT parameters s_par
     __shared__ int s_flag;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
     const double b2 = huber_a * huber_a;
     if (tid == 0) {
@@ -315,7 +335,15 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
     // One pass over the points at parameters `par`: cost AND the normal-equation sums, so that an
     // accepted trial step needs no second pass (rejections are rare and only waste the Jacobian part).
     auto pass = [&](const double* par) {
-        if (tid == 0) { rodrigues(par, s_R); d_rodrigues(par, s_R, s_dR); }
+        if (tid < 64) {
+            // every lane of the first wave evaluates R (same operands, same result); lane 0 publishes it and lanes
+            // 0..26 each one entry of the three derivative matrices -- the serial prologue of a pass is one
+            // rotation + one entry instead of one rotation + 27 entries
+            double Rl[9];
+            rodrigues(par, Rl);
+            if (tid < 9) s_R[tid] = Rl[tid];
+            if (tid < 27) s_dR[tid / 9][tid % 9] = d_rodrigues_entry(par, Rl, tid / 9, tid % 9);
+        }
         __syncthreads();
         double acc[kRefineSums];
 #pragma unroll
@@ -329,8 +357,12 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
             const double iz = 1.0 / zc, xn = xc * iz, yn = yc * iz;
             const double r0 = x[2 * i] - (fx * xn + sk * yn + cx), r1 = x[2 * i + 1] - (fy * yn + cy);
             const double sq = r0 * r0 + r1 * r1;
-            const double rho = sq <= b2 ? sq : 2.0 * huber_a * sqrt(sq) - b2;
-            const double wgt = sq <= b2 ? 1.0 : huber_a / sqrt(sq);          // rho'(s)
+            double rho = sq, wgt = 1.0;                                      // rho(s), rho'(s)
+            if (sq > b2) {                                                   // Huber tail: rare after RANSAC, and a real branch
+                const double r = sqrt(sq);                                   // (skipped when no lane of the wave needs it)
+                rho = 2.0 * huber_a * r - b2;
+                wgt = huber_a / r;
+            }
             acc[27] += 0.5 * rho;
             acc[28] += 1.0;
             // d(proj)/d(xc,yc,zc)
@@ -356,16 +388,26 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
 #pragma unroll
             for (int a_ = 0; a_ < 6; ++a_) acc[21 + a_] += wgt * (Ju[a_] * r0 + Jv[a_] * r1);   // = -J_r^T W r : descent rhs
         }
+        // Reduction of the 29 sums over the 512 threads THROUGH LDS, transposed: every thread parks its partials in
+        // red[sum][thread] (conflict-free 8-byte writes), then 29 x 16 threads each add 32 of them and 29 threads add
+        // the 16 partial results.  The shuffle tree it replaces (29 values x 6 levels x 2 ds_bpermute per wave, eight
+        // waves on one LDS pipe) took 16-18 k cycles per pass, measured; this takes ~3 k.
 #pragma unroll
-        for (int i = 0; i < kRefineSums; ++i) {
-            double v = acc[i];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) s_sum[wv][i] = v;
+        for (int i = 0; i < kRefineSums; ++i) red[i * kRefineThreads + tid] = acc[i];
+        __syncthreads();
+        if (tid < kRefineSums * 16) {
+            const int i = tid >> 4, part = tid & 15;
+            const double* src = red + i * kRefineThreads + part;
+            double v = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < kRefineThreads / 16; ++k) v += src[16 * k];
+            s_part[i][part] = v;
         }
         __syncthreads();
         if (tid < kRefineSums) {
             double v = 0.0;
-            for (int w_ = 0; w_ < kRefineWaves; ++w_) v += s_sum[w_][tid];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v += s_part[tid][k];
             s_tot[tid] = v;
         }
         __syncthreads();
@@ -434,8 +476,15 @@ hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const dou
                              const int32_t* d_valid)
 {
     if (N <= 0) return hipSuccess;
+    constexpr size_t kRedBytes = sizeof(double) * kRefineSums * kRefineThreads;
+    static bool attr_set = false;       // more than the 64 KB a kernel gets by default
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)pnp_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRedBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
-    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kRefineThreads), 0, stream, d_Rt_in, d_X, d_x, d_mask, N, d_K, huber_a, max_iter,
+    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kRefineThreads), kRedBytes, stream, d_Rt_in, d_X, d_x, d_mask, N, d_K, huber_a, max_iter,
                        d_valid, (RefineOut*)d_out);
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
     return hipGetLastError();
