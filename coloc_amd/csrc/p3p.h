@@ -50,7 +50,7 @@ P3P_HD int p3p_solve_cubic(double a, double b, double c, double* x)
     return 3;
 }
 
-// real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (c4 != 0); returns count (0..4)
+// real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (c4 != 0) in closed form, UNPOLISHED (p3p_polish_root); returns count (0..4)
 P3P_HD int p3p_solve_quartic(const double* co, double* roots)
 {
     const double a = co[3] / co[4], b = co[2] / co[4], c = co[1] / co[4], d = co[0] / co[4];
@@ -87,17 +87,20 @@ P3P_HD int p3p_solve_quartic(const double* co, double* roots)
             if (disc >= 0.0) { const double sq = sqrt(disc); y[n++] = 0.5 * (s + sq); y[n++] = 0.5 * (s - sq); }
         }
     }
-    for (int i = 0; i < n; ++i) {
-        double x = y[i] - 0.25 * a;
-        for (int it = 0; it < 3; ++it) {   // Newton polish on the original polynomial
-            const double f = (((co[4] * x + co[3]) * x + co[2]) * x + co[1]) * x + co[0];
-            const double df = ((4.0 * co[4] * x + 3.0 * co[3]) * x + 2.0 * co[2]) * x + co[1];
-            if (df == 0.0) break;
-            x -= f / df;
-        }
-        roots[i] = x;
-    }
+    for (int i = 0; i < n; ++i) roots[i] = y[i] - 0.25 * a;
     return n;
+}
+
+// Newton polish of one root on the original polynomial
+P3P_HD double p3p_polish_root(const double* co, double x)
+{
+    for (int it = 0; it < 3; ++it) {
+        const double f = (((co[4] * x + co[3]) * x + co[2]) * x + co[1]) * x + co[0];
+        const double df = ((4.0 * co[4] * x + 3.0 * co[3]) * x + 2.0 * co[2]) * x + co[1];
+        if (df == 0.0) break;
+        x -= f / df;
+    }
+    return x;
 }
 
 P3P_HD void p3p_cross(const double* a, const double* b, double* c)
@@ -128,68 +131,91 @@ P3P_HD bool p3p_triad(const double* A, const double* B, const double* C, double 
     return true;
 }
 
-// X: three world points (3x3 row-major, one point per row); f: three UNIT bearing vectors.
-// Rt_out: up to 4 poses, 12 doubles each, row-major [R|t] with x_cam = R X + t.  Returns the count.
-P3P_HD int p3p_solve(const double X[3][3], const double f[3][3], double* Rt_out)
+// Everything of a P3P problem that does not depend on WHICH root is being turned into a pose.
+struct P3PProblem {
+    double N[3], D[2], W[3], co[5];   // u = N(v) / D(v), W(v), the quartic in v
+    double b2;
+    double E[3][3];                   // world triad
+    double roots[4];                  // closed-form roots of the quartic (unpolished) / of the cubic fallback
+    int nr;
+    bool polish;                      // quartic branch: Newton-polish a root before use
+};
+
+// X: three world points (3x3 row-major, one point per row); f: three UNIT bearing vectors.  Returns false if degenerate.
+P3P_HD bool p3p_prepare(const double X[3][3], const double f[3][3], P3PProblem& p)
 {
     double d12[3], d13[3], d23[3];
     for (int i = 0; i < 3; ++i) { d12[i] = X[0][i] - X[1][i]; d13[i] = X[0][i] - X[2][i]; d23[i] = X[1][i] - X[2][i]; }
     const double c2 = p3p_dot(d12, d12), b2 = p3p_dot(d13, d13), a2 = p3p_dot(d23, d23);
-    if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return 0;
+    p.nr = 0;
+    if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return false;
     const double ca = p3p_dot(f[1], f[2]), cb = p3p_dot(f[0], f[2]), cg = p3p_dot(f[0], f[1]);
     const double q = (a2 - c2) / b2;
     // polynomials in v, ascending coefficients
-    const double N[3] = { q + 1.0, -2.0 * q * cb, q - 1.0 };
-    const double D[2] = { 2.0 * cg, -2.0 * ca };
-    const double W[3] = { 1.0, -2.0 * cb, 1.0 };
+    p.N[0] = q + 1.0; p.N[1] = -2.0 * q * cb; p.N[2] = q - 1.0;
+    p.D[0] = 2.0 * cg; p.D[1] = -2.0 * ca;
+    p.W[0] = 1.0; p.W[1] = -2.0 * cb; p.W[2] = 1.0;
+    p.b2 = b2;
+    const double* N = p.N; const double* D = p.D; const double* W = p.W;
     double DD[3] = { D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1] };
     double NN[5] = { 0, 0, 0, 0, 0 }, ND[4] = { 0, 0, 0, 0 }, DDW[5] = { 0, 0, 0, 0, 0 };
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) NN[i + j] += N[i] * N[j];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) ND[i + j] += N[i] * D[j];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) DDW[i + j] += DD[i] * W[j];
-    double co[5];
     for (int k = 0; k < 5; ++k) {
         const double dd = k < 3 ? DD[k] : 0.0, nd = k < 4 ? ND[k] : 0.0;
-        co[k] = b2 * (dd + NN[k] - 2.0 * cg * nd) - c2 * DDW[k];
+        p.co[k] = b2 * (dd + NN[k] - 2.0 * cg * nd) - c2 * DDW[k];
     }
-    double roots[4];
-    int nr = 0;
+    const double* co = p.co;
     const double scale = fabs(co[0]) + fabs(co[1]) + fabs(co[2]) + fabs(co[3]) + fabs(co[4]);
-    if (!(scale > 0.0)) return 0;
+    if (!(scale > 0.0)) return false;
     if (fabs(co[4]) > 1e-12 * scale) {
-        nr = p3p_solve_quartic(co, roots);
+        p.nr = p3p_solve_quartic(co, p.roots);
+        p.polish = true;
     } else if (fabs(co[3]) > 1e-12 * scale) {
-        nr = p3p_solve_cubic(co[2] / co[3], co[1] / co[3], co[0] / co[3], roots);
+        p.nr = p3p_solve_cubic(co[2] / co[3], co[1] / co[3], co[0] / co[3], p.roots);
+        p.polish = false;
     } else {
-        return 0;
+        return false;
     }
-    double E[3][3];
-    if (!p3p_triad(X[0], X[1], X[2], E)) return 0;
+    return p3p_triad(X[0], X[1], X[2], p.E);
+}
+
+// Root k of a prepared problem -> pose P (12 doubles, row-major [R|t], x_cam = R X + t).  Returns false if the root
+// does not give a valid pose.
+P3P_HD bool p3p_pose_from_root(const P3PProblem& p, const double X[3][3], const double f[3][3], const int k, double* P)
+{
+    if (k >= p.nr) return false;
+    const double v = p.polish ? p3p_polish_root(p.co, p.roots[k]) : p.roots[k];
+    if (!(v > 0.0)) return false;
+    const double den = p.D[0] + p.D[1] * v;
+    if (fabs(den) < 1e-12) return false;
+    const double u = (p.N[0] + (p.N[1] + p.N[2] * v) * v) / den;
+    if (!(u > 0.0)) return false;
+    const double w = p.W[0] + (p.W[1] + p.W[2] * v) * v;
+    if (!(w > 0.0)) return false;
+    const double s1 = sqrt(p.b2 / w), s2 = u * s1, s3 = v * s1;
+    const double Q0[3] = { s1 * f[0][0], s1 * f[0][1], s1 * f[0][2] };
+    const double Q1[3] = { s2 * f[1][0], s2 * f[1][1], s2 * f[1][2] };
+    const double Q2[3] = { s3 * f[2][0], s3 * f[2][1], s3 * f[2][2] };
+    double G[3][3];
+    if (!p3p_triad(Q0, Q1, Q2, G)) return false;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) P[4 * i + j] = G[i][0] * p.E[j][0] + G[i][1] * p.E[j][1] + G[i][2] * p.E[j][2];   // R = G E^T
+    for (int i = 0; i < 3; ++i) P[4 * i + 3] = Q0[i] - (P[4 * i] * X[0][0] + P[4 * i + 1] * X[0][1] + P[4 * i + 2] * X[0][2]);
+    bool finite = true;
+    for (int i = 0; i < 12; ++i) finite = finite && (P[i] == P[i]) && fabs(P[i]) < 1e300;
+    return finite;
+}
+
+// All poses of one problem, compacted: Rt_out receives up to 4 poses of 12 doubles.  Returns the count.
+P3P_HD int p3p_solve(const double X[3][3], const double f[3][3], double* Rt_out)
+{
+    P3PProblem p;
+    if (!p3p_prepare(X, f, p)) return 0;
     int ns = 0;
-    for (int k = 0; k < nr && ns < 4; ++k) {
-        const double v = roots[k];
-        if (!(v > 0.0)) continue;
-        const double den = D[0] + D[1] * v;
-        if (fabs(den) < 1e-12) continue;
-        const double u = (N[0] + (N[1] + N[2] * v) * v) / den;
-        if (!(u > 0.0)) continue;
-        const double w = W[0] + (W[1] + W[2] * v) * v;
-        if (!(w > 0.0)) continue;
-        const double s1 = sqrt(b2 / w), s2 = u * s1, s3 = v * s1;
-        const double Q0[3] = { s1 * f[0][0], s1 * f[0][1], s1 * f[0][2] };
-        const double Q1[3] = { s2 * f[1][0], s2 * f[1][1], s2 * f[1][2] };
-        const double Q2[3] = { s3 * f[2][0], s3 * f[2][1], s3 * f[2][2] };
-        double G[3][3];
-        if (!p3p_triad(Q0, Q1, Q2, G)) continue;
-        double* P = Rt_out + 12 * ns;
-        for (int i = 0; i < 3; ++i) {
-            for (int j = 0; j < 3; ++j) P[4 * i + j] = G[i][0] * E[j][0] + G[i][1] * E[j][1] + G[i][2] * E[j][2];   // R = G E^T
-        }
-        for (int i = 0; i < 3; ++i) P[4 * i + 3] = Q0[i] - (P[4 * i] * X[0][0] + P[4 * i + 1] * X[0][1] + P[4 * i + 2] * X[0][2]);
-        bool finite = true;
-        for (int i = 0; i < 12; ++i) finite = finite && (P[i] == P[i]) && fabs(P[i]) < 1e300;
-        if (finite) ++ns;
-    }
+    for (int k = 0; k < p.nr && ns < 4; ++k)
+        if (p3p_pose_from_root(p, X, f, k, Rt_out + 12 * ns)) ++ns;
     return ns;
 }
 

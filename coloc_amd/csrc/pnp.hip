@@ -79,14 +79,18 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const double* __restrict
     }
 }
 
-// ---- batched minimal solver: one P3P problem per lane -------------------------------------------
-// samples: S x 3 point indices.  Writes 4 pose slots per sample (H = 4 S); unused slots are NaN so
-// that they score worst (every comparison with NaN is false: 0 inliers, cost = N * thr2).
+// ---- batched minimal solver: one P3P problem per FOUR lanes ------------------------------------------
+// samples: S x 3 point indices.  The four lanes of a sample all build the quartic and solve it in closed form (the
+// same instructions on the same numbers), then lane r polishes root r and turns it into pose slot r of the sample
+// (H = 4 S slots).  Slots without a valid pose are NaN so that they score worst (every comparison with NaN is false:
+// 0 inliers, cost = N * thr2).  One lane per sample doing the four roots in turn took 13-15 us; the per-root half of
+// the chain now runs four wide.
 __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, const double* __restrict__ x,
                                                  const double* __restrict__ K, const int32_t* __restrict__ samples,
                                                  const int S, const int N, double* __restrict__ Rt)
 {
-    const int sidx = blockIdx.x * 64 + threadIdx.x;
+    const int gid = blockIdx.x * 64 + threadIdx.x;
+    const int sidx = gid >> 2, root = gid & 3;
     if (sidx >= S) return;
     double Xs[3][3], f[3][3];
     bool ok = true;
@@ -101,13 +105,14 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
         const double nrm = sqrt(xn * xn + yn * yn + 1.0);
         f[p][0] = xn / nrm; f[p][1] = yn / nrm; f[p][2] = 1.0 / nrm;
     }
-    // the solver writes its poses straight into this lane's four global slots (a local staging array would live in
-    // scratch memory: it is indexed by the running solution count)
-    double* out = Rt + (size_t)48 * sidx;
-    const int n = ok ? p3p_solve(Xs, f, out) : 0;
+    P3PProblem prob;
+    ok = ok && p3p_prepare(Xs, f, prob);
+    double P[12];
+    const bool have = ok && p3p_pose_from_root(prob, Xs, f, root, P);
+    double* out = Rt + (size_t)48 * sidx + 12 * root;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int k = n; k < 4; ++k)
-        for (int e = 0; e < 12; ++e) out[12 * k + e] = qnan;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) out[e] = have ? P[e] : qnan;
 }
 
 // best hypothesis: most inliers, then lowest cost, then lowest index -- and its inlier mask, in ONE
@@ -497,7 +502,7 @@ hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const 
 {
     if (S <= 0 || N <= 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
-    hipLaunchKernelGGL(p3p_kernel, dim3((S + 63) / 64), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt);
+    hipLaunchKernelGGL(p3p_kernel, dim3((4 * S + 63) / 64), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt);
     hipLaunchKernelGGL(pnp_score_kernel, dim3(4 * S), dim3(256), 0, stream, (const double*)d_Rt, d_X, d_x, N, d_K, thr2, d_count, d_cost);
     hipLaunchKernelGGL(pnp_select_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_Rt,
                        (const int32_t*)d_count, (const double*)d_cost, 4 * S, d_X, d_x, N, d_K, thr2, d_mask, (PnpResult*)d_result);
