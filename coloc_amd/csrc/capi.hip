@@ -908,7 +908,7 @@ static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, i
     const size_t out_d = res_d + ((size_t)N + 7) / 8;
     int rc = ensure_pnp(ctx, in_d + scr_d + out_d + 8);
     if (rc != CLC_OK) return rc;
-    rc = ensure_pinned(ctx, (in_d > out_d ? in_d : out_d) * sizeof(double) + 64);
+    rc = ensure_pinned(ctx, (in_d + out_d) * sizeof(double) + 64);
     if (rc != CLC_OK) return rc;
     double* dX = ctx->d_pnp;
     double* dx = dX + (size_t)3 * N;
@@ -919,30 +919,36 @@ static int pnp_ransac_impl(clc_ctx* ctx, const double* h_X, const double* h_x, i
     int32_t* dCount = (int32_t*)(dCost + (size_t)4 * S);
     double* dRes = ctx->d_pnp + in_d + scr_d;
     uint8_t* dMask = (uint8_t*)(dRes + res_d);
-    // stage inputs
+    // Inputs go into the pinned buffer and stay there: the first launch reads them over PCIe and stages them into
+    // device memory itself, the last launch writes record + mask back into the pinned buffer.  No copy commands: a
+    // pose solve is three (four with refinement) kernel launches and one stream synchronisation.
     double* hp = (double*)ctx->h_pin;
+    double* hout = hp + in_d;
     memcpy(hp, h_X, sizeof(double) * 3 * N);
     memcpy(hp + (size_t)3 * N, h_x, sizeof(double) * 2 * N);
     memcpy(hp + (size_t)5 * N, h_K, sizeof(double) * 9);
     memcpy(hp + (size_t)5 * N + 16, h_samples, sizeof(int32_t) * 3 * S);
-    CLC_HIP(ctx, hipMemcpyAsync(dX, hp, in_d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    CLC_HIP(ctx, launch_pnp_ransac(dX, dx, N, dK, dSamples, S, thr2, dRt, dCount, dCost, dMask, dRes, ctx->stream, &ctx->prof));
-    double* dRef = dRes + (pnp_result_bytes() + 7) / 8;
+    const size_t ref_off = (pnp_result_bytes() + 7) / 8;
+    PnpHostStage hs;
+    hs.src = hp;
+    hs.n_doubles = (int)in_d;
+    hs.h_mask = (uint8_t*)(hout + res_d);
+    hs.h_result = hout;
+    CLC_HIP(ctx, launch_pnp_ransac(dX, dx, N, dK, dSamples, S, thr2, dRt, dCount, dCost, dMask, dRes, ctx->stream, &ctx->prof, &hs));
     if (refine)
-        CLC_HIP(ctx, launch_pnp_refine(dRes /* PnpResult.Rt */, dX, dx, dMask, N, dK, refine_huber, 50, dRef, ctx->stream, &ctx->prof,
-                                       (const int32_t*)((const uint8_t*)dRes + pnp_result_valid_offset())));
-    CLC_HIP(ctx, hipMemcpyAsync(hp, dRes, out_d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        CLC_HIP(ctx, launch_pnp_refine(dRes /* PnpResult.Rt */, dX, dx, dMask, N, dK, refine_huber, 50, dRes + ref_off, ctx->stream,
+                                       &ctx->prof, (const int32_t*)((const uint8_t*)dRes + pnp_result_valid_offset()), hout + ref_off));
     if (h_all_Rt) CLC_HIP(ctx, hipMemcpyAsync(h_all_Rt, dRt, sizeof(double) * 48 * S, hipMemcpyDeviceToHost, ctx->stream));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     struct { double Rt[12]; double cost; int32_t h; int32_t count; } r;
-    memcpy(&r, hp, sizeof r);
+    memcpy(&r, hout, sizeof r);
     if (h_Rt) memcpy(h_Rt, r.Rt, sizeof(double) * 12);
-    if (h_mask) memcpy(h_mask, (const uint8_t*)(hp + res_d), (size_t)N);
+    if (h_mask) memcpy(h_mask, (const uint8_t*)(hout + res_d), (size_t)N);
     if (n_inliers) *n_inliers = r.h >= 0 ? r.count : 0;
     if (cost) *cost = r.cost;
     if (refine) {
         struct { double Rt[12]; double cov[36]; double cost; double rmse; int32_t iterations; int32_t n_used; } f;
-        memcpy(&f, hp + (pnp_result_bytes() + 7) / 8, sizeof f);
+        memcpy(&f, hout + ref_off, sizeof f);
         if (h_Rt) memcpy(h_Rt, f.Rt, sizeof f.Rt);
         if (h_cov) memcpy(h_cov, f.cov, sizeof f.cov);
         if (rmse) *rmse = f.rmse;

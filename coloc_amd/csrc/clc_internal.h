@@ -105,9 +105,18 @@ hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const 
 
 // P3P hypotheses for S minimal samples (4 slots each) -> score -> select + inlier mask of the winner.
 // d_result receives one packed record {double Rt[12]; double cost; int32 h; int32 count} (pnp_result_bytes()).
+// hs (nullable): the inputs are still in the caller's pinned host buffer [X 3N | x 2N | K 16 | samples]; the first
+// launch reads them from there and stages them into d_X.. itself, the last one mirrors record + mask into pinned host
+// memory -- no copy commands around the launches.
+struct PnpHostStage {
+    const double* src;      // pinned host input block
+    int           n_doubles;// its length
+    uint8_t*      h_mask;   // pinned host: N bytes
+    void*         h_result; // pinned host: PnpResult
+};
 hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
                              int S, double thr2, double* d_Rt, int32_t* d_count, double* d_cost, uint8_t* d_mask,
-                             void* d_result, hipStream_t stream, Profiler* prof = nullptr);
+                             void* d_result, hipStream_t stream, Profiler* prof = nullptr, const PnpHostStage* hs = nullptr);
 size_t pnp_result_bytes();
 // five-point problems for S minimal samples (10 slots of {F(9), E(9)} each) -> symmetric-epipolar score -> select + mask.
 // d_result: {double E[9]; double F[9]; double cost; int32 h; int32 count} (epi_result_bytes()).
@@ -122,7 +131,8 @@ hipError_t launch_epipolar(const double* d_F, int H, const double* d_x1, const d
 // d_out: {double Rt[12]; double cov[36]; double cost; double rmse; int32 iterations; int32 n_used}
 hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,
                              const double* d_K, double huber_a, int max_iter, void* d_out, hipStream_t stream,
-                             Profiler* prof = nullptr, const int32_t* d_valid = nullptr);
+                             Profiler* prof = nullptr, const int32_t* d_valid = nullptr, void* h_out = nullptr);
+// (h_out: pinned host record written INSTEAD of d_out, so that no device-to-host copy command is needed)
 size_t pnp_result_valid_offset();   // byte offset of the int32 "winning hypothesis" (< 0: none) in the ransac result record
 size_t pnp_refine_out_bytes();
 

@@ -87,8 +87,18 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const double* __restrict
 // the chain now runs four wide.
 __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, const double* __restrict__ x,
                                                  const double* __restrict__ K, const int32_t* __restrict__ samples,
-                                                 const int S, const int N, double* __restrict__ Rt)
+                                                 const int S, const int N, double* __restrict__ Rt,
+                                                 const int solve_blocks, const double* __restrict__ stage_src,
+                                                 double* __restrict__ stage_dst, const int stage_n)
 {
+    if ((int)blockIdx.x >= solve_blocks) {
+        // staging duty (clc_pnp_ransac / clc_pnp_localize): X, x, K and samples above are the caller's PINNED HOST
+        // buffer, read here straight over PCIe; these extra workgroups copy it into device memory for the scoring
+        // launches that follow (which read every point a thousand times) -- no separate host-to-device copy command
+        const int nb = (int)gridDim.x - solve_blocks;
+        for (int i = ((int)blockIdx.x - solve_blocks) * 64 + (int)threadIdx.x; i < stage_n; i += nb * 64) stage_dst[i] = stage_src[i];
+        return;
+    }
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int sidx = gid >> 2, root = gid & 3;
     if (sidx >= S) return;
@@ -134,8 +144,11 @@ __global__ __launch_bounds__(256) void pnp_select_mask_kernel(const double* __re
                                                               const double* __restrict__ cost, const int H,
                                                               const double* __restrict__ X, const double* __restrict__ x, const int N,
                                                               const double* __restrict__ K, const double thr2,
-                                                              uint8_t* __restrict__ mask, PnpResult* __restrict__ res)
+                                                              uint8_t* __restrict__ mask, PnpResult* __restrict__ res,
+                                                              uint8_t* __restrict__ h_mask, PnpResult* __restrict__ h_res)
 {
+    // h_mask / h_res (nullable): the caller's pinned host buffer -- the record and the mask are written there as well,
+    // so that the host needs no device-to-host copy command after the launch
     __shared__ int s_h[256];
     int bh = -1;
     for (int h = threadIdx.x; h < H; h += 256)
@@ -153,13 +166,26 @@ __global__ __launch_bounds__(256) void pnp_select_mask_kernel(const double* __re
     const bool ok = h >= 0 && count[h] > 0;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (blockIdx.x == 0) {
-        if (threadIdx.x < 12) res->Rt[threadIdx.x] = ok ? Rt[(size_t)12 * h + threadIdx.x] : 0.0;
-        if (threadIdx.x == 12) { res->h = ok ? h : -1; res->count = ok ? count[h] : 0; res->cost = ok ? cost[h] : 0.0; }
+        if (threadIdx.x < 12) {
+            const double v = ok ? Rt[(size_t)12 * h + threadIdx.x] : 0.0;
+            res->Rt[threadIdx.x] = v;
+            if (h_res) h_res->Rt[threadIdx.x] = v;
+        }
+        if (threadIdx.x == 12) {
+            const int32_t hh = ok ? h : -1, cc = ok ? count[h] : 0;
+            const double qq = ok ? cost[h] : 0.0;
+            res->h = hh; res->count = cc; res->cost = qq;
+            if (h_res) { h_res->h = hh; h_res->count = cc; h_res->cost = qq; }
+        }
     }
     if (i >= N) return;
-    if (!ok) { mask[i] = 0; return; }
-    const double e = reproj_err(Rt + (size_t)12 * h, K, X[3 * i], X[3 * i + 1], X[3 * i + 2], x[2 * i], x[2 * i + 1]);
-    mask[i] = e < thr2 ? 1 : 0;
+    uint8_t m = 0;
+    if (ok) {
+        const double e = reproj_err(Rt + (size_t)12 * h, K, X[3 * i], X[3 * i + 1], X[3 * i + 2], x[2 * i], x[2 * i + 1]);
+        m = e < thr2 ? 1 : 0;
+    }
+    mask[i] = m;
+    if (h_mask) h_mask[i] = m;
 }
 
 // ---- single-pose refinement + 6x6 covariance ------------------------
@@ -314,8 +340,9 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
                                                                     const double* __restrict__ x, const uint8_t* __restrict__ mask,
                                                                     const int N, const double* __restrict__ K, const double huber_a,
                                                                     const int max_iter, const int32_t* __restrict__ valid,
-                                                                    RefineOut* __restrict__ out)
+                                                                    RefineOut* __restrict__ out_dev, RefineOut* __restrict__ out_host)
 {
+    RefineOut* const out = out_host ? out_host : out_dev;      // pinned host record (no D2H copy command) or device record
     if (valid && *valid < 0) {          // chained after clc_pnp_ransac that found no pose: nothing to refine
         if (threadIdx.x < 12) out->Rt[threadIdx.x] = 0.0;
         if (threadIdx.x < 36) out->cov[threadIdx.x] = 0.0;
@@ -478,7 +505,7 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
 
 hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,
                              const double* d_K, double huber_a, int max_iter, void* d_out, hipStream_t stream, Profiler* prof,
-                             const int32_t* d_valid)
+                             const int32_t* d_valid, void* h_out)
 {
     if (N <= 0) return hipSuccess;
     constexpr size_t kRedBytes = sizeof(double) * kRefineSums * kRefineThreads;
@@ -490,7 +517,7 @@ hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const dou
     }
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
     hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kRefineThreads), kRedBytes, stream, d_Rt_in, d_X, d_x, d_mask, N, d_K, huber_a, max_iter,
-                       d_valid, (RefineOut*)d_out);
+                       d_valid, (RefineOut*)d_out, (RefineOut*)h_out);
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
     return hipGetLastError();
 }
@@ -498,14 +525,30 @@ size_t pnp_refine_out_bytes() { return sizeof(RefineOut); }
 
 hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
                              int S, double thr2, double* d_Rt /* 48*S */, int32_t* d_count, double* d_cost,
-                             uint8_t* d_mask, void* d_result, hipStream_t stream, Profiler* prof)
+                             uint8_t* d_mask, void* d_result, hipStream_t stream, Profiler* prof, const PnpHostStage* hs)
 {
     if (S <= 0 || N <= 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
-    hipLaunchKernelGGL(p3p_kernel, dim3((4 * S + 63) / 64), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt);
+    const int solve_blocks = (4 * S + 63) / 64;
+    if (hs) {
+        // inputs still sit in the pinned host buffer: the solver lanes read their three points from there, extra
+        // workgroups stage everything into d_X.. for the launches below
+        int stage_blocks = (hs->n_doubles + 255) / 256;
+        if (stage_blocks > 64) stage_blocks = 64;
+        const double* hX = hs->src;
+        const double* hx = hX + (size_t)3 * N;
+        const double* hK = hx + (size_t)2 * N;
+        const int32_t* hSamples = (const int32_t*)(hK + 16);
+        hipLaunchKernelGGL(p3p_kernel, dim3(solve_blocks + stage_blocks), dim3(64), 0, stream, hX, hx, hK, hSamples, S, N, d_Rt,
+                           solve_blocks, hs->src, const_cast<double*>(d_X), hs->n_doubles);
+    } else {
+        hipLaunchKernelGGL(p3p_kernel, dim3(solve_blocks), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt, solve_blocks,
+                           (const double*)nullptr, (double*)nullptr, 0);
+    }
     hipLaunchKernelGGL(pnp_score_kernel, dim3(4 * S), dim3(256), 0, stream, (const double*)d_Rt, d_X, d_x, N, d_K, thr2, d_count, d_cost);
     hipLaunchKernelGGL(pnp_select_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_Rt,
-                       (const int32_t*)d_count, (const double*)d_cost, 4 * S, d_X, d_x, N, d_K, thr2, d_mask, (PnpResult*)d_result);
+                       (const int32_t*)d_count, (const double*)d_cost, 4 * S, d_X, d_x, N, d_K, thr2, d_mask, (PnpResult*)d_result,
+                       hs ? hs->h_mask : nullptr, hs ? (PnpResult*)hs->h_result : nullptr);
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, false, stream);
     return hipGetLastError();
 }
