@@ -141,3 +141,21 @@ def test_workspace_rearms_across_changing_shapes(gpu_ctx, oracle):
         assert (outs[0] == -1).all() and outs[3].shape == (0,)
         assert np.array_equal(outs[1], oracle.k2nn(descs[0], descs[2], 40))
         assert np.array_equal(outs[2], oracle.k2nn(descs[2], descs[0], 40))
+
+
+def test_random_shapes_stress(gpu_ctx, oracle):
+    """150 random (nq, nt, threshold) shapes -- sizes around the 128-query block, the 16-vectors-per-wave and the
+    multiple-of-8 split boundaries, with planted near-duplicates and exact duplicates -- against the oracle."""
+    rng = np.random.default_rng(2026)
+    edges = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025]
+    for it in range(150):
+        nq = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, 3500))
+        nt = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, 3500))
+        Q, T = synth.planted_descriptors(nq, nt, seed=int(rng.integers(1 << 30)))
+        if nt >= 4 and nq >= 2:                       # exact duplicate train rows -> tie -> rejected
+            T[nt - 1] = T[0]
+            Q[0] = T[0]
+        thr = int(rng.integers(0, 300))               # > 255 exercises the uint8 truncation (CUDAK2NN.cu:46)
+        m, b, s = gpu_ctx.match_2nn(Q, T, thr, want_dist=True)
+        mo, bo, so = oracle.k2nn(Q, T, thr, want_dist=True)
+        assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so), (it, nq, nt, thr)
