@@ -21,7 +21,10 @@
  *   - inputs need no padding (the reference needs +8 readable train vectors,
  *     GPUMatcher.hpp:183-186).
  *   - a context is thread-compatible: one host thread at a time; several contexts per
- *     process / device are fine; no hidden process-global state.
+ *     process / device are fine; no hidden process-global state.  A context owns ONE set of device
+ *     workspaces (pyramid arena, matcher top-2 rows and arrival counters, pose scratch), so the `_dev`
+ *     calls made on one context must be ordered with respect to each other -- same stream, or
+ *     streams joined by events; use one context per concurrently running stream.
  */
 #ifndef COLOC_HIP_H
 #define COLOC_HIP_H
