@@ -509,11 +509,13 @@ hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const dou
 {
     if (N <= 0) return hipSuccess;
     constexpr size_t kRedBytes = sizeof(double) * kRefineSums * kRefineThreads;
-    static bool attr_set = false;       // more than the 64 KB a kernel gets by default
-    if (!attr_set) {
+    static bool attr_set[64] = {};      // per device: more than the 64 KB a kernel gets by default
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
         const hipError_t e = hipFuncSetAttribute((const void*)pnp_refine_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRedBytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
     hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(kRefineThreads), kRedBytes, stream, d_Rt_in, d_X, d_x, d_mask, N, d_K, huber_a, max_iter,
