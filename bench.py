@@ -240,7 +240,14 @@ def main():
                        "k2nn_sweep_us": sweep_us, "k2nn_merge_us": avg_us("k2nn_merge_kernel"),
                        "cameras_per_describe_launch": 1 if args.per_camera_launches else len(cams),
                        "Mdesc_per_s_kernel": (NKP * (1 if args.per_camera_launches else len(cams)) / clatch_us) if clatch_us else None,
-                       "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6},
+                       "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6,
+                       # CLATCH issues 1188 wave64 VALU instructions per descriptor (512 v_dot4_u32_u8 + the 3136 sample
+                       # coordinates + fp64 sincos; rocprofv3 SQ_INSTS_VALU, profiles/r01_clatch_ablation.txt)
+                       "clatch_valu": ({"lane_ops_per_descriptor": 1188 * 64,
+                                        "achieved_Tlaneop_per_s": 1188 * 64 * NKP * (1 if args.per_camera_launches else len(cams)) / clatch_us / 1e6,
+                                        "peak_Tlaneop_per_s": VALU_PEAK_TLANEOPS,
+                                        "frac": 1188 * 64 * NKP * (1 if args.per_camera_launches else len(cams)) / clatch_us / 1e6 / VALU_PEAK_TLANEOPS,
+                                        "also_bound_by": "LDS array ~71 % busy (SQ_LDS_IDX_ACTIVE), 3 waves/SIMD"} if clatch_us else None)},
             "roofline": roof,
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
             "collective": ("none" if world == 1 else ("RCCL all_gather_into_tensor" if args.backend == "nccl"
