@@ -184,6 +184,15 @@ def main():
     if graph is not None:
         prof = prof_all
 
+    # the exchange step on its own (every rank takes part; outside the timed region): SURVEY.md 8(e) asks for it separately
+    allgather_us = None
+    if world > 1 and args.backend == "nccl":
+        fence()
+        tg = time.perf_counter()
+        for _ in range(20):
+            dist.all_gather_into_tensor(arena.view(-1), mine.view(-1))
+        torch.cuda.synchronize()
+        allgather_us = (time.perf_counter() - tg) / 20 * 1e6
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -252,6 +261,7 @@ def main():
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
             "collective": ("none" if world == 1 else ("RCCL all_gather_into_tensor" if args.backend == "nccl"
                                                       else "REHEARSAL: gloo all_gather staged through host memory")),
+            "allgather_us_rank0": allgather_us,
         }
         # GPU-resident front end on a real frame (informational): pyramid -> FAST-9/NMS/orientation ->
         # CLATCH with the keypoint count kept in device memory (no host round trip)
