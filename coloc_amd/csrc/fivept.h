@@ -28,6 +28,18 @@
 #define FPT_HD static inline
 #endif
 
+// Every array of the solver.  On the device ONE problem runs per wave (all lanes execute the same scalar code on
+// the same numbers), and this struct lives in LDS: kept as per-lane locals the arrays would be dynamically indexed
+// private (scratch) memory, and a solve is a chain of ~10^5 dependent accesses (measured 4.4 ms per problem in
+// scratch).  On the host it is a local variable.
+struct FptWorkspace {
+    double A[5][9], EE[4][9], e[9][20], M[10][20], G[9][20], tr[20], t[20], M0[10][20], Ax[100];
+    double hr[10][10], hi[10][10], gc[10], gsr[10], gsi[10];      // eigenvalues
+    double lu[10][11];                                            // shifted solve
+    double zr[10], zi[10], v[10], y[10], mono[20], dmx[20], dmy[20], dmz[20];
+    int piv[5], is_piv[9];
+};
+
 // exponents of the 20 monomials in the order above
 FPT_HD int fpt_mono_index(int i, int j, int k)
 {
@@ -71,10 +83,56 @@ FPT_HD void fpt_poly_mul_add(const double* a, const double* b, double scale, dou
     }
 }
 
-// solve (A - lambda I) y = rhs for a 10 x 10 A by LU with partial pivoting; returns false if singular to working precision
-FPT_HD bool fpt_solve_shifted(const double* A, double lambda, const double* rhs, double* y)
+// ---- structured polynomial products -------------------------------------------------------------------------
+// The entries of E are LINEAR in (x, y, z) (monomials 16..19), the entries of E E^T QUADRATIC (monomials 10..19):
+// the only products the constraints need are linear x linear (16 terms) and quadratic x linear (40 terms), with the
+// target monomial of every term known at compile time.  (The generic 20 x 20 loop with exponent look-ups that this
+// replaces was half of the solver's run time.)
+constexpr signed char kFptExp[20][3] = { {3,0,0},{2,1,0},{2,0,1},{1,2,0},{1,1,1},{1,0,2},{0,3,0},{0,2,1},{0,1,2},{0,0,3},
+                                         {2,0,0},{1,1,0},{1,0,1},{0,2,0},{0,1,1},{0,0,2},{1,0,0},{0,1,0},{0,0,1},{0,0,0} };
+constexpr int fpt_mono_index_c(int i, int j, int k)
 {
-    double M[10][11];
+    return (i + j + k == 3) ? (i == 3 ? 0 : i == 2 ? (j == 1 ? 1 : 2) : i == 1 ? (j == 2 ? 3 : (j == 1 ? 4 : 5)) : (j == 3 ? 6 : (j == 2 ? 7 : (j == 1 ? 8 : 9))))
+         : (i + j + k == 2) ? (i == 2 ? 10 : i == 1 ? (j == 1 ? 11 : 12) : (j == 2 ? 13 : (j == 1 ? 14 : 15)))
+         : (i + j + k == 1) ? (i == 1 ? 16 : (j == 1 ? 17 : 18)) : 19;
+}
+constexpr int fpt_prod_index_c(int m, int n)
+{
+    return fpt_mono_index_c(kFptExp[m][0] + kFptExp[n][0], kFptExp[m][1] + kFptExp[n][1], kFptExp[m][2] + kFptExp[n][2]);
+}
+// c += scale * a * b, a and b linear (coefficients at 16..19), c quadratic
+FPT_HD void fpt_mul_lin_lin(const double* a, const double* b, double scale, double* c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int m = 16; m < 20; ++m) {
+        const double am = scale * a[m];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int n = 16; n < 20; ++n) c[fpt_prod_index_c(m, n)] += am * b[n];
+    }
+}
+// c += scale * a * b, a quadratic (coefficients at 10..19), b linear, c cubic
+FPT_HD void fpt_mul_quad_lin(const double* a, const double* b, double scale, double* c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int m = 10; m < 20; ++m) {
+        const double am = scale * a[m];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (int n = 16; n < 20; ++n) c[fpt_prod_index_c(m, n)] += am * b[n];
+    }
+}
+
+// solve (A - lambda I) y = rhs for a 10 x 10 A by LU with partial pivoting; returns false if singular to working precision
+FPT_HD bool fpt_solve_shifted(const double* A, double lambda, const double* rhs, double* y, FptWorkspace& w)
+{
+    double (&M)[10][11] = w.lu;
     for (int r = 0; r < 10; ++r) {
         for (int c = 0; c < 10; ++c) M[r][c] = A[10 * r + c] - (r == c ? lambda : 0.0);
         M[r][10] = rhs[r];
@@ -102,10 +160,11 @@ FPT_HD bool fpt_solve_shifted(const double* A, double lambda, const double* rhs,
 }
 
 // All eigenvalues of a real 10 x 10 matrix (copied; A is not modified).
-FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi)
+FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi, FptWorkspace& w)
 {
     const int n = 10;
-    double hr[10][10], hi[10][10];
+    double (&hr)[10][10] = w.hr;
+    double (&hi)[10][10] = w.hi;
     for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) { hr[r][c] = A[10 * r + c]; hi[r][c] = 0.0; }
     // Hessenberg by elimination with row/column interchanges (similarity transforms)
     for (int m = 1; m < n - 1; ++m) {
@@ -165,7 +224,9 @@ FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi)
         }
         for (int i = l; i <= m; ++i) { hr[i][i] -= sr; hi[i][i] -= si; }
         // QR step on the active block [l, m]: H = Q R by Givens rotations, then H <- R Q
-        double gc[10], gsr[10], gsi[10];
+        double (&gc)[10] = w.gc;
+        double (&gsr)[10] = w.gsr;
+        double (&gsi)[10] = w.gsi;
         for (int k = l; k < m; ++k) {
             // rotation G = [c, s; -conj(s), c] with c real that zeroes H[k+1][k]
             const double ar = hr[k][k], ai = hi[k][k], br = hr[k + 1][k], bi = hi[k + 1][k];
@@ -225,16 +286,17 @@ FPT_HD double fpt_constraint_residual(const double* E)
 }
 
 // q1, q2: 5 x 2 normalised coordinates in view 1 / view 2 (q2^T E q1 = 0).  E_out: up to 10 x 9 (row-major 3x3).
-FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_out)
+FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_out, FptWorkspace& w)
 {
     // ---- 1. null space of the 5 x 9 constraint matrix by reduced row echelon form
-    double A[5][9];
+    double (&A)[5][9] = w.A;
     for (int i = 0; i < 5; ++i) {
         const double a[3] = { q2[i][0], q2[i][1], 1.0 }, b[3] = { q1[i][0], q1[i][1], 1.0 };
         for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) A[i][3 * r + c] = a[r] * b[c];
     }
-    int piv[5];
-    bool is_piv[9] = { false, false, false, false, false, false, false, false, false };
+    int (&piv)[5] = w.piv;
+    int (&is_piv)[9] = w.is_piv;
+    for (int i = 0; i < 9; ++i) is_piv[i] = 0;
     int row = 0;
     for (int col = 0; col < 9 && row < 5; ++col) {
         int p = row;
@@ -251,11 +313,11 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
             for (int k = 0; k < 9; ++k) A[r][k] -= f * A[row][k];
         }
         piv[row] = col;
-        is_piv[col] = true;
+        is_piv[col] = 1;
         ++row;
     }
     if (row < 5) return 0;                      // degenerate sample
-    double EE[4][9];
+    double (&EE)[4][9] = w.EE;
     {
         int nb = 0;
         for (int f = 0; f < 9; ++f) {
@@ -267,40 +329,41 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
         }
     }
     // ---- 2. the ten cubic constraints.  e[a][b] = linear polynomial x EE0 + y EE1 + z EE2 + EE3
-    double e[9][20];
+    double (&e)[9][20] = w.e;
     for (int k = 0; k < 9; ++k) {
         for (int m = 0; m < 20; ++m) e[k][m] = 0.0;
         e[k][16] = EE[0][k]; e[k][17] = EE[1][k]; e[k][18] = EE[2][k]; e[k][19] = EE[3][k];
     }
-    double M[10][20];
+    double (&M)[10][20] = w.M;
     for (int r = 0; r < 10; ++r) for (int m = 0; m < 20; ++m) M[r][m] = 0.0;
     {
         // det(E): e0 (e4 e8 - e5 e7) - e1 (e3 e8 - e5 e6) + e2 (e3 e7 - e4 e6)
-        double t[20];
+        double (&t)[20] = w.t;
         const int tri[3][5] = { { 0, 4, 8, 5, 7 }, { 1, 3, 8, 5, 6 }, { 2, 3, 7, 4, 6 } };
         for (int s = 0; s < 3; ++s) {
             for (int m = 0; m < 20; ++m) t[m] = 0.0;
-            fpt_poly_mul_add(e[tri[s][1]], e[tri[s][2]], 1.0, t);
-            fpt_poly_mul_add(e[tri[s][3]], e[tri[s][4]], -1.0, t);
-            fpt_poly_mul_add(e[tri[s][0]], t, s == 1 ? -1.0 : 1.0, M[0]);
+            fpt_mul_lin_lin(e[tri[s][1]], e[tri[s][2]], 1.0, t);
+            fpt_mul_lin_lin(e[tri[s][3]], e[tri[s][4]], -1.0, t);
+            fpt_mul_quad_lin(t, e[tri[s][0]], s == 1 ? -1.0 : 1.0, M[0]);
         }
         // G = E E^T (quadratic), tr = trace(G);  C = 2 G E - tr E
-        double G[9][20], tr[20];
+        double (&G)[9][20] = w.G;
+        double (&tr)[20] = w.tr;
         for (int m = 0; m < 20; ++m) tr[m] = 0.0;
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) {
                 for (int m = 0; m < 20; ++m) G[3 * a + b][m] = 0.0;
-                for (int c = 0; c < 3; ++c) fpt_poly_mul_add(e[3 * a + c], e[3 * b + c], 1.0, G[3 * a + b]);
+                for (int c = 0; c < 3; ++c) fpt_mul_lin_lin(e[3 * a + c], e[3 * b + c], 1.0, G[3 * a + b]);
             }
         for (int m = 0; m < 20; ++m) tr[m] = G[0][m] + G[4][m] + G[8][m];
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) {
                 double* row_ = M[1 + 3 * a + b];
-                for (int c = 0; c < 3; ++c) fpt_poly_mul_add(G[3 * a + c], e[3 * c + b], 2.0, row_);
-                fpt_poly_mul_add(tr, e[3 * a + b], -1.0, row_);
+                for (int c = 0; c < 3; ++c) fpt_mul_quad_lin(G[3 * a + c], e[3 * c + b], 2.0, row_);
+                fpt_mul_quad_lin(tr, e[3 * a + b], -1.0, row_);
             }
     }
-    double M0[10][20];                       // the constraints before elimination: used to polish the roots
+    double (&M0)[10][20] = w.M0;             // the constraints before elimination: used to polish the roots
     for (int r = 0; r < 10; ++r) {
         double nr = 0.0;
         for (int m = 0; m < 20; ++m) nr = fabs(M[r][m]) > nr ? fabs(M[r][m]) : nr;
@@ -324,14 +387,15 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
         }
     }
     // action matrix of multiplication by x on b = [x2 xy xz y2 yz z2 x y z 1]
-    double Ax[100];
+    double (&Ax)[100] = w.Ax;
     for (int i = 0; i < 100; ++i) Ax[i] = 0.0;
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 10; ++c) Ax[10 * r + c] = -M[r][10 + c];   // x3, x2y, x2z, xy2, xyz, xz2
     Ax[10 * 6 + 0] = 1.0; Ax[10 * 7 + 1] = 1.0; Ax[10 * 8 + 2] = 1.0; Ax[10 * 9 + 6] = 1.0;
     // ---- 4. eigenvalues of Ax: Hessenberg form by stabilised elimination, then single-shift QR in complex
     //         arithmetic (Wilkinson shift, Givens rotations, deflation) -- no characteristic polynomial
-    double zr[10], zi[10];
-    fpt_eigenvalues10(Ax, zr, zi);
+    double (&zr)[10] = w.zr;
+    double (&zi)[10] = w.zi;
+    fpt_eigenvalues10(Ax, zr, zi, w);
     // ---- real roots -> eigenvectors by inverse iteration on Ax, refined eigenvalue by the eigen-equation
     int ns = 0;
     double anorm = 0.0;
@@ -339,11 +403,12 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
     for (int k = 0; k < 10 && ns < 10; ++k) {
         if (fabs(zi[k]) > 1e-6 * (1.0 + fabs(zr[k]))) continue;
         double lam = zr[k];
-        double v[10], y[10];
+        double (&v)[10] = w.v;
+        double (&y)[10] = w.y;
         for (int i = 0; i < 10; ++i) v[i] = 1.0 / (1.0 + i);
         bool ok = true;
         for (int it = 0; it < 4 && ok; ++it) {
-            ok = fpt_solve_shifted(Ax, lam + 1e-11 * (anorm + 1.0), v, y);
+            ok = fpt_solve_shifted(Ax, lam + 1e-11 * (anorm + 1.0), v, y, w);
             if (!ok) break;
             double nrm = 0.0;
             for (int i = 0; i < 10; ++i) nrm = fabs(y[i]) > nrm ? fabs(y[i]) : nrm;
@@ -361,7 +426,10 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
         // polish (x, y, z) on the ten cubic constraints themselves (Gauss-Newton, 3 unknowns): the eigen-solution
         // of a nearly defective action matrix is only good to ~1e-5, the constraints pin it to rounding
         for (int it = 0; it < 4; ++it) {
-            double mono[20], dmx[20], dmy[20], dmz[20];
+            double (&mono)[20] = w.mono;
+            double (&dmx)[20] = w.dmx;
+            double (&dmy)[20] = w.dmy;
+            double (&dmz)[20] = w.dmz;
             for (int m = 0; m < 20; ++m) {
                 int ei, ej, ek;
                 fpt_mono_exp(m, &ei, &ej, &ek);
