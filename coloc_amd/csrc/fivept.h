@@ -35,9 +35,15 @@
 struct FptWorkspace {
     double A[5][9], EE[4][9], e[9][20], M[10][20], G[9][20], tr[20], t[20], M0[10][20], Ax[100];
     double hr[10][10], hi[10][10], gc[10], gsr[10], gsi[10];      // eigenvalues
-    double lu[10][11];                                            // shifted solve
-    double zr[10], zi[10], v[10], y[10], mono[20], dmx[20], dmy[20], dmz[20];
+    double zr[10], zi[10];
     int piv[5], is_piv[9];
+    // one slot per eigenvalue: on the device the ten roots are refined by ten lanes at once
+    struct Root {
+        double lu[10][11];                                        // shifted solve
+        double v[10], y[10], mono[20], dmx[20], dmy[20], dmz[20];
+        double cand[9];                                           // the essential matrix this root gives
+        int valid;
+    } root[10];
 };
 
 // exponents of the 20 monomials in the order above
@@ -130,9 +136,8 @@ FPT_HD void fpt_mul_quad_lin(const double* a, const double* b, double scale, dou
 }
 
 // solve (A - lambda I) y = rhs for a 10 x 10 A by LU with partial pivoting; returns false if singular to working precision
-FPT_HD bool fpt_solve_shifted(const double* A, double lambda, const double* rhs, double* y, FptWorkspace& w)
+FPT_HD bool fpt_solve_shifted(const double* A, double lambda, const double* rhs, double* y, double (&M)[10][11])
 {
-    double (&M)[10][11] = w.lu;
     for (int r = 0; r < 10; ++r) {
         for (int c = 0; c < 10; ++c) M[r][c] = A[10 * r + c] - (r == c ? lambda : 0.0);
         M[r][10] = rhs[r];
@@ -285,6 +290,89 @@ FPT_HD double fpt_constraint_residual(const double* E)
     return n2 > 0.0 ? worst / (n2 * sqrt(n2)) : 1.0;
 }
 
+// Eigenvalue k of the action matrix -> candidate essential matrix w.root[k].cand (valid = 0 if the eigenvalue is
+// complex, the eigenvector does not settle, or the result does not satisfy the cubic constraints).
+FPT_HD void fpt_root_candidate(FptWorkspace& w, const int k, const double anorm)
+{
+    FptWorkspace::Root& rw = w.root[k];
+    rw.valid = 0;
+    const double (&Ax)[100] = w.Ax;
+    const double (&zr)[10] = w.zr;
+    const double (&zi)[10] = w.zi;
+    const double (&M0)[10][20] = w.M0;
+    const double (&EE)[4][9] = w.EE;
+    {
+        if (fabs(zi[k]) > 1e-6 * (1.0 + fabs(zr[k]))) return;
+        double lam = zr[k];
+        double (&v)[10] = rw.v;
+        double (&y)[10] = rw.y;
+        for (int i = 0; i < 10; ++i) v[i] = 1.0 / (1.0 + i);
+        bool ok = true;
+        for (int it = 0; it < 4 && ok; ++it) {
+            ok = fpt_solve_shifted(Ax, lam + 1e-11 * (anorm + 1.0), v, y, rw.lu);
+            if (!ok) break;
+            double nrm = 0.0;
+            for (int i = 0; i < 10; ++i) nrm = fabs(y[i]) > nrm ? fabs(y[i]) : nrm;
+            if (!(nrm > 0.0)) { ok = false; break; }
+            for (int i = 0; i < 10; ++i) v[i] = y[i] / nrm;
+            // eigenvalue from the component of largest magnitude: (A v)_m / v_m
+            int mi = 0;
+            for (int i = 1; i < 10; ++i) if (fabs(v[i]) > fabs(v[mi])) mi = i;
+            double av = 0.0;
+            for (int j = 0; j < 10; ++j) av += Ax[10 * mi + j] * v[j];
+            lam = av / v[mi];
+        }
+        if (!ok || fabs(v[9]) < 1e-12) return;
+        double x = v[6] / v[9], yv = v[7] / v[9], z = v[8] / v[9];
+        // polish (x, y, z) on the ten cubic constraints themselves (Gauss-Newton, 3 unknowns): the eigen-solution
+        // of a nearly defective action matrix is only good to ~1e-5, the constraints pin it to rounding
+        for (int it = 0; it < 4; ++it) {
+            double (&mono)[20] = rw.mono;
+            double (&dmx)[20] = rw.dmx;
+            double (&dmy)[20] = rw.dmy;
+            double (&dmz)[20] = rw.dmz;
+            for (int m = 0; m < 20; ++m) {
+                int ei, ej, ek;
+                fpt_mono_exp(m, &ei, &ej, &ek);
+                const double px[4] = { 1.0, x, x * x, x * x * x }, py[4] = { 1.0, yv, yv * yv, yv * yv * yv }, pz[4] = { 1.0, z, z * z, z * z * z };
+                mono[m] = px[ei] * py[ej] * pz[ek];
+                dmx[m] = ei ? ei * px[ei - 1] * py[ej] * pz[ek] : 0.0;
+                dmy[m] = ej ? ej * px[ei] * py[ej - 1] * pz[ek] : 0.0;
+                dmz[m] = ek ? ek * px[ei] * py[ej] * pz[ek - 1] : 0.0;
+            }
+            double JtJ[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, Jtr[3] = { 0, 0, 0 };
+            for (int r = 0; r < 10; ++r) {
+                double rr = 0.0, jx = 0.0, jy = 0.0, jz = 0.0;
+                for (int m = 0; m < 20; ++m) { rr += M0[r][m] * mono[m]; jx += M0[r][m] * dmx[m]; jy += M0[r][m] * dmy[m]; jz += M0[r][m] * dmz[m]; }
+                JtJ[0] += jx * jx; JtJ[1] += jx * jy; JtJ[2] += jx * jz; JtJ[4] += jy * jy; JtJ[5] += jy * jz; JtJ[8] += jz * jz;
+                Jtr[0] += jx * rr; Jtr[1] += jy * rr; Jtr[2] += jz * rr;
+            }
+            JtJ[3] = JtJ[1]; JtJ[6] = JtJ[2]; JtJ[7] = JtJ[5];
+            const double det = JtJ[0] * (JtJ[4] * JtJ[8] - JtJ[5] * JtJ[7]) - JtJ[1] * (JtJ[3] * JtJ[8] - JtJ[5] * JtJ[6])
+                             + JtJ[2] * (JtJ[3] * JtJ[7] - JtJ[4] * JtJ[6]);
+            if (!(fabs(det) > 1e-300)) break;
+            const double dx_ = (Jtr[0] * (JtJ[4] * JtJ[8] - JtJ[5] * JtJ[7]) - JtJ[1] * (Jtr[1] * JtJ[8] - JtJ[5] * Jtr[2])
+                              + JtJ[2] * (Jtr[1] * JtJ[7] - JtJ[4] * Jtr[2])) / det;
+            const double dy_ = (JtJ[0] * (Jtr[1] * JtJ[8] - JtJ[5] * Jtr[2]) - Jtr[0] * (JtJ[3] * JtJ[8] - JtJ[5] * JtJ[6])
+                              + JtJ[2] * (JtJ[3] * Jtr[2] - Jtr[1] * JtJ[6])) / det;
+            const double dz_ = (JtJ[0] * (JtJ[4] * Jtr[2] - Jtr[1] * JtJ[7]) - JtJ[1] * (JtJ[3] * Jtr[2] - Jtr[1] * JtJ[6])
+                              + Jtr[0] * (JtJ[3] * JtJ[7] - JtJ[4] * JtJ[6])) / det;
+            if (!(dx_ == dx_) || !(dy_ == dy_) || !(dz_ == dz_)) break;
+            x -= dx_; yv -= dy_; z -= dz_;
+            if (fabs(dx_) + fabs(dy_) + fabs(dz_) < 1e-15 * (1.0 + fabs(x) + fabs(yv) + fabs(z))) break;
+        }
+        bool finite = true;
+        for (int c = 0; c < 9; ++c) {
+            const double ev = x * EE[0][c] + yv * EE[1][c] + z * EE[2][c] + EE[3][c];
+            rw.cand[c] = ev;
+            finite = finite && (ev == ev) && fabs(ev) < 1e300;
+        }
+        // an eigenvalue that was not a true real root (or an eigenvector that did not settle) yields a matrix that
+        // is not essential: keep only candidates that satisfy the cubic constraints
+        if (finite && fpt_constraint_residual(rw.cand) < 1e-9) rw.valid = 1;
+    }
+}
+
 // q1, q2: 5 x 2 normalised coordinates in view 1 / view 2 (q2^T E q1 = 0).  E_out: up to 10 x 9 (row-major 3x3).
 FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_out, FptWorkspace& w)
 {
@@ -396,90 +484,34 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
     double (&zr)[10] = w.zr;
     double (&zi)[10] = w.zi;
     fpt_eigenvalues10(Ax, zr, zi, w);
-    // ---- real roots -> eigenvectors by inverse iteration on Ax, refined eigenvalue by the eigen-equation
-    int ns = 0;
+
+    // ---- real roots -> eigenvectors by inverse iteration on Ax, refined eigenvalue by the eigen-equation, polished
+    //      on the constraints: one root per lane on the device, in turn on the host
     double anorm = 0.0;
     for (int i = 0; i < 100; ++i) anorm = fabs(Ax[i]) > anorm ? fabs(Ax[i]) : anorm;
-    for (int k = 0; k < 10 && ns < 10; ++k) {
-        if (fabs(zi[k]) > 1e-6 * (1.0 + fabs(zr[k]))) continue;
-        double lam = zr[k];
-        double (&v)[10] = w.v;
-        double (&y)[10] = w.y;
-        for (int i = 0; i < 10; ++i) v[i] = 1.0 / (1.0 + i);
-        bool ok = true;
-        for (int it = 0; it < 4 && ok; ++it) {
-            ok = fpt_solve_shifted(Ax, lam + 1e-11 * (anorm + 1.0), v, y, w);
-            if (!ok) break;
-            double nrm = 0.0;
-            for (int i = 0; i < 10; ++i) nrm = fabs(y[i]) > nrm ? fabs(y[i]) : nrm;
-            if (!(nrm > 0.0)) { ok = false; break; }
-            for (int i = 0; i < 10; ++i) v[i] = y[i] / nrm;
-            // eigenvalue from the component of largest magnitude: (A v)_m / v_m
-            int mi = 0;
-            for (int i = 1; i < 10; ++i) if (fabs(v[i]) > fabs(v[mi])) mi = i;
-            double av = 0.0;
-            for (int j = 0; j < 10; ++j) av += Ax[10 * mi + j] * v[j];
-            lam = av / v[mi];
-        }
-        if (!ok || fabs(v[9]) < 1e-12) continue;
-        double x = v[6] / v[9], yv = v[7] / v[9], z = v[8] / v[9];
-        // polish (x, y, z) on the ten cubic constraints themselves (Gauss-Newton, 3 unknowns): the eigen-solution
-        // of a nearly defective action matrix is only good to ~1e-5, the constraints pin it to rounding
-        for (int it = 0; it < 4; ++it) {
-            double (&mono)[20] = w.mono;
-            double (&dmx)[20] = w.dmx;
-            double (&dmy)[20] = w.dmy;
-            double (&dmz)[20] = w.dmz;
-            for (int m = 0; m < 20; ++m) {
-                int ei, ej, ek;
-                fpt_mono_exp(m, &ei, &ej, &ek);
-                const double px[4] = { 1.0, x, x * x, x * x * x }, py[4] = { 1.0, yv, yv * yv, yv * yv * yv }, pz[4] = { 1.0, z, z * z, z * z * z };
-                mono[m] = px[ei] * py[ej] * pz[ek];
-                dmx[m] = ei ? ei * px[ei - 1] * py[ej] * pz[ek] : 0.0;
-                dmy[m] = ej ? ej * px[ei] * py[ej - 1] * pz[ek] : 0.0;
-                dmz[m] = ek ? ek * px[ei] * py[ej] * pz[ek - 1] : 0.0;
-            }
-            double JtJ[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, Jtr[3] = { 0, 0, 0 };
-            for (int r = 0; r < 10; ++r) {
-                double rr = 0.0, jx = 0.0, jy = 0.0, jz = 0.0;
-                for (int m = 0; m < 20; ++m) { rr += M0[r][m] * mono[m]; jx += M0[r][m] * dmx[m]; jy += M0[r][m] * dmy[m]; jz += M0[r][m] * dmz[m]; }
-                JtJ[0] += jx * jx; JtJ[1] += jx * jy; JtJ[2] += jx * jz; JtJ[4] += jy * jy; JtJ[5] += jy * jz; JtJ[8] += jz * jz;
-                Jtr[0] += jx * rr; Jtr[1] += jy * rr; Jtr[2] += jz * rr;
-            }
-            JtJ[3] = JtJ[1]; JtJ[6] = JtJ[2]; JtJ[7] = JtJ[5];
-            const double det = JtJ[0] * (JtJ[4] * JtJ[8] - JtJ[5] * JtJ[7]) - JtJ[1] * (JtJ[3] * JtJ[8] - JtJ[5] * JtJ[6])
-                             + JtJ[2] * (JtJ[3] * JtJ[7] - JtJ[4] * JtJ[6]);
-            if (!(fabs(det) > 1e-300)) break;
-            const double dx_ = (Jtr[0] * (JtJ[4] * JtJ[8] - JtJ[5] * JtJ[7]) - JtJ[1] * (Jtr[1] * JtJ[8] - JtJ[5] * Jtr[2])
-                              + JtJ[2] * (Jtr[1] * JtJ[7] - JtJ[4] * Jtr[2])) / det;
-            const double dy_ = (JtJ[0] * (Jtr[1] * JtJ[8] - JtJ[5] * Jtr[2]) - Jtr[0] * (JtJ[3] * JtJ[8] - JtJ[5] * JtJ[6])
-                              + JtJ[2] * (JtJ[3] * Jtr[2] - Jtr[1] * JtJ[6])) / det;
-            const double dz_ = (JtJ[0] * (JtJ[4] * Jtr[2] - Jtr[1] * JtJ[7]) - JtJ[1] * (JtJ[3] * Jtr[2] - Jtr[1] * JtJ[6])
-                              + Jtr[0] * (JtJ[3] * JtJ[7] - JtJ[4] * JtJ[6])) / det;
-            if (!(dx_ == dx_) || !(dy_ == dy_) || !(dz_ == dz_)) break;
-            x -= dx_; yv -= dy_; z -= dz_;
-            if (fabs(dx_) + fabs(dy_) + fabs(dz_) < 1e-15 * (1.0 + fabs(x) + fabs(yv) + fabs(z))) break;
-        }
-        // skip duplicates of an already accepted root
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+    if (threadIdx.x < 10) fpt_root_candidate(w, (int)threadIdx.x, anorm);
+    __syncthreads();
+#else
+    for (int k = 0; k < 10; ++k) fpt_root_candidate(w, k, anorm);
+#endif
+    // compaction in eigenvalue order, skipping duplicates of an already accepted root
+    int ns = 0;
+    for (int k = 0; k < 10; ++k) {
+        if (!w.root[k].valid) continue;
+        const double* cand = w.root[k].cand;
+        double scale = 0.0;
+        for (int c = 0; c < 9; ++c) scale = fmax(scale, fabs(cand[c]));
         bool dup = false;
-        for (int s = 0; s < ns; ++s) {
+        for (int s2 = 0; s2 < ns; ++s2) {
             double d = 0.0;
-            for (int c = 0; c < 9; ++c) {
-                const double ev = x * EE[0][c] + yv * EE[1][c] + z * EE[2][c] + EE[3][c];
-                d = fmax(d, fabs(ev - E_out[9 * s + c]));
-            }
-            if (d < 1e-9 * (1.0 + fabs(x) + fabs(yv) + fabs(z))) dup = true;
+            for (int c = 0; c < 9; ++c) d = fmax(d, fabs(cand[c] - E_out[9 * s2 + c]));
+            if (d < 1e-9 * (1.0 + scale)) dup = true;
         }
         if (dup) continue;
-        bool finite = true;
-        for (int c = 0; c < 9; ++c) {
-            const double ev = x * EE[0][c] + yv * EE[1][c] + z * EE[2][c] + EE[3][c];
-            E_out[9 * ns + c] = ev;
-            finite = finite && (ev == ev) && fabs(ev) < 1e300;
-        }
-        // an eigenvalue that was not a true real root (or an eigenvector that did not settle) yields a matrix that
-        // is not essential: keep only candidates that satisfy the cubic constraints
-        if (finite && fpt_constraint_residual(E_out + 9 * ns) < 1e-9) ++ns;
+        for (int c = 0; c < 9; ++c) E_out[9 * ns + c] = cand[c];
+        ++ns;
     }
     return ns;
 }
