@@ -164,37 +164,61 @@ FPT_HD bool fpt_solve_shifted(const double* A, double lambda, const double* rhs,
     return true;
 }
 
+// Element loops of the eigenvalue routine: on the device the wave that owns the problem spreads them over its lanes
+// (every element update of a row / column operation is independent), on the host they are ordinary loops.  The
+// arithmetic per element is the same either way.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FPT_PAR_FOR(j, lo, hi) for (int j = (lo) + (int)threadIdx.x, once_ = 1; once_ && j <= (hi); once_ = 0)
+#define FPT_SYNC() __syncthreads()
+#else
+#define FPT_PAR_FOR(j, lo, hi) for (int j = (lo); j <= (hi); ++j)
+#define FPT_SYNC() ((void)0)
+#endif
+
 // All eigenvalues of a real 10 x 10 matrix (copied; A is not modified).
 FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi, FptWorkspace& w)
 {
     const int n = 10;
     double (&hr)[10][10] = w.hr;
     double (&hi)[10][10] = w.hi;
-    for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) { hr[r][c] = A[10 * r + c]; hi[r][c] = 0.0; }
+    FPT_SYNC();
+    FPT_PAR_FOR(idx, 0, 99) { hr[idx / 10][idx % 10] = A[idx]; hi[idx / 10][idx % 10] = 0.0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    FPT_PAR_FOR(idx, 64, 99) { hr[idx / 10][idx % 10] = A[idx]; hi[idx / 10][idx % 10] = 0.0; }
+#endif
+    FPT_SYNC();
     // Hessenberg by elimination with row/column interchanges (similarity transforms)
     for (int m = 1; m < n - 1; ++m) {
         int p = m;
         double x = 0.0;
         for (int j = m; j < n; ++j) if (fabs(hr[j][m - 1]) > fabs(x)) { x = hr[j][m - 1]; p = j; }
+        FPT_SYNC();
         if (p != m) {
-            for (int j = m - 1; j < n; ++j) { const double t = hr[p][j]; hr[p][j] = hr[m][j]; hr[m][j] = t; }
-            for (int j = 0; j < n; ++j) { const double t = hr[j][p]; hr[j][p] = hr[j][m]; hr[j][m] = t; }
+            FPT_PAR_FOR(j, m - 1, n - 1) { const double t = hr[p][j]; hr[p][j] = hr[m][j]; hr[m][j] = t; }
+            FPT_SYNC();
+            FPT_PAR_FOR(j, 0, n - 1) { const double t = hr[j][p]; hr[j][p] = hr[j][m]; hr[j][m] = t; }
+            FPT_SYNC();
         }
         if (x != 0.0) {
             for (int i = m + 1; i < n; ++i) {
                 double y = hr[i][m - 1];
+                FPT_SYNC();
                 if (y == 0.0) continue;
                 y /= x;
-                hr[i][m - 1] = 0.0;
-                for (int j = m; j < n; ++j) hr[i][j] -= y * hr[m][j];
-                for (int j = 0; j < n; ++j) hr[j][m] += y * hr[j][i];
+                FPT_PAR_FOR(j, m, n - 1) hr[i][j] -= y * hr[m][j];
+                FPT_PAR_FOR(j, m - 1, m - 1) hr[i][j] = 0.0;
+                FPT_SYNC();
+                FPT_PAR_FOR(j, 0, n - 1) hr[j][m] += y * hr[j][i];
+                FPT_SYNC();
             }
         }
     }
-    for (int r = 2; r < n; ++r) for (int c = 0; c < r - 1; ++c) hr[r][c] = 0.0;
+    FPT_SYNC();
+    for (int r = 2; r < n; ++r) FPT_PAR_FOR(c, 0, r - 2) hr[r][c] = 0.0;
+    FPT_SYNC();
     double norm = 0.0;
     for (int r = 0; r < n; ++r) for (int c = 0; c < n; ++c) norm = fabs(hr[r][c]) > norm ? fabs(hr[r][c]) : norm;
-    if (!(norm > 0.0)) { for (int i = 0; i < n; ++i) { wr[i] = 0.0; wi[i] = 0.0; } return; }
+    if (!(norm > 0.0)) { FPT_SYNC(); FPT_PAR_FOR(i, 0, n - 1) { wr[i] = 0.0; wi[i] = 0.0; } FPT_SYNC(); return; }
     int m = n - 1, iter = 0;
     while (m >= 0) {
         // look for a negligible subdiagonal element
@@ -202,12 +226,15 @@ FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi, FptWorksp
         while (l > 0) {
             const double sd = fabs(hr[l][l - 1]) + fabs(hi[l][l - 1]);
             const double dg = fabs(hr[l][l]) + fabs(hi[l][l]) + fabs(hr[l - 1][l - 1]) + fabs(hi[l - 1][l - 1]);
-            if (sd <= 1e-15 * (dg > 0.0 ? dg : norm)) { hr[l][l - 1] = 0.0; hi[l][l - 1] = 0.0; break; }
+            if (sd <= 1e-15 * (dg > 0.0 ? dg : norm)) break;
             --l;
         }
-        if (l == m) { wr[m] = hr[m][m]; wi[m] = hi[m][m]; --m; iter = 0; continue; }
+        FPT_SYNC();
+        if (l > 0) { FPT_PAR_FOR(j, 0, 0) { hr[l][l - 1] = 0.0; hi[l][l - 1] = 0.0; } }
+        FPT_SYNC();
+        if (l == m) { const double a_ = hr[m][m], b_ = hi[m][m]; FPT_SYNC(); FPT_PAR_FOR(j, 0, 0) { wr[m] = a_; wi[m] = b_; } --m; iter = 0; continue; }
         if (++iter > 300) {                       // give up on this block: report the diagonal
-            for (int i = l; i <= m; ++i) { wr[i] = hr[i][i]; wi[i] = hi[i][i]; }
+            FPT_PAR_FOR(i, l, m) { wr[i] = hr[i][i]; wi[i] = hi[i][i]; }
             m = l - 1; iter = 0; continue;
         }
         // Wilkinson shift: eigenvalue of the trailing 2 x 2 closer to h[m][m]  (exceptional shifts now and then)
@@ -227,7 +254,9 @@ FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi, FptWorksp
             sr = d1 < d2 ? t1r : t2r; si = d1 < d2 ? t1i : t2i;
             if (iter % 11 == 10) { sr += 0.7 * (fabs(cr) + fabs(ci)); si += 0.3 * (fabs(cr) + fabs(ci)); }
         }
-        for (int i = l; i <= m; ++i) { hr[i][i] -= sr; hi[i][i] -= si; }
+        FPT_SYNC();
+        FPT_PAR_FOR(i, l, m) { hr[i][i] -= sr; hi[i][i] -= si; }
+        FPT_SYNC();
         // QR step on the active block [l, m]: H = Q R by Givens rotations, then H <- R Q
         double (&gc)[10] = w.gc;
         double (&gsr)[10] = w.gsr;
@@ -246,31 +275,36 @@ FPT_HD void fpt_eigenvalues10(const double* A, double* wr, double* wi, FptWorksp
                 const double ur = ar / na, ui = ai / na;
                 s_r = (ur * br + ui * bi) / nrm; s_i = (ui * br - ur * bi) / nrm;
             }
-            gc[k] = c; gsr[k] = s_r; gsi[k] = s_i;
+            FPT_SYNC();
+            FPT_PAR_FOR(j, 0, 0) { gc[k] = c; gsr[k] = s_r; gsi[k] = s_i; }
             // rows k, k+1, columns k..m:  [x; y] <- [c x + s y; -conj(s) x + c y]
-            for (int j = k; j <= m; ++j) {
+            FPT_PAR_FOR(j, k, m) {
                 const double xr = hr[k][j], xi = hi[k][j], yr = hr[k + 1][j], yi = hi[k + 1][j];
                 hr[k][j] = c * xr + (s_r * yr - s_i * yi);
                 hi[k][j] = c * xi + (s_r * yi + s_i * yr);
-                hr[k + 1][j] = -(s_r * xr + s_i * xi) + c * yr;       // -conj(s) x = -(s_r - i s_i)(x)
-                hi[k + 1][j] = -(s_r * xi - s_i * xr) + c * yi;
+                hr[k + 1][j] = j == k ? 0.0 : -(s_r * xr + s_i * xi) + c * yr;       // -conj(s) x = -(s_r - i s_i)(x)
+                hi[k + 1][j] = j == k ? 0.0 : -(s_r * xi - s_i * xr) + c * yi;
             }
-            hr[k + 1][k] = 0.0; hi[k + 1][k] = 0.0;
+            FPT_SYNC();
         }
         for (int k = l; k < m; ++k) {
             // columns k, k+1, rows l..min(k+2, m): [x, y] <- [x c + y conj(s), -x s + y c]   (multiplication by G^H)
             const double c = gc[k], s_r = gsr[k], s_i = gsi[k];
             const int rmax = k + 2 < m ? k + 2 : m;
-            for (int i = l; i <= rmax; ++i) {
+            FPT_SYNC();
+            FPT_PAR_FOR(i, l, rmax) {
                 const double xr = hr[i][k], xi = hi[i][k], yr = hr[i][k + 1], yi = hi[i][k + 1];
                 hr[i][k] = c * xr + (yr * s_r + yi * s_i);
                 hi[i][k] = c * xi + (yi * s_r - yr * s_i);
                 hr[i][k + 1] = -(xr * s_r - xi * s_i) + c * yr;
                 hi[i][k + 1] = -(xr * s_i + xi * s_r) + c * yi;
             }
+            FPT_SYNC();
         }
-        for (int i = l; i <= m; ++i) { hr[i][i] += sr; hi[i][i] += si; }
+        FPT_PAR_FOR(i, l, m) { hr[i][i] += sr; hi[i][i] += si; }
+        FPT_SYNC();
     }
+    FPT_SYNC();
 }
 
 // relative residual of the essential-matrix constraints 2 E E^T E - tr(E E^T) E = 0 (which imply det E = 0)
