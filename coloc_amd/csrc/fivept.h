@@ -342,7 +342,7 @@ FPT_HD void fpt_root_candidate(FptWorkspace& w, const int k, const double anorm)
         double (&y)[10] = rw.y;
         for (int i = 0; i < 10; ++i) v[i] = 1.0 / (1.0 + i);
         bool ok = true;
-        for (int it = 0; it < 4 && ok; ++it) {
+        for (int it = 0; it < 2 && ok; ++it) {          // two steps settle it (the polish below does the rest)
             ok = fpt_solve_shifted(Ax, lam + 1e-11 * (anorm + 1.0), v, y, rw.lu);
             if (!ok) break;
             double nrm = 0.0;
@@ -492,21 +492,42 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
         nr = nr > 0.0 ? 1.0 / nr : 1.0;
         for (int m = 0; m < 20; ++m) M0[r][m] = M[r][m] * nr;
     }
-    // ---- 3. Gauss-Jordan on the 10 cubic monomials
+    // ---- 3. Gauss-Jordan on the 10 cubic monomials (on the device the 200 entries of an elimination step are
+    //         spread over the lanes; the multipliers are read before anything is written)
     for (int c = 0; c < 10; ++c) {
         int p = c;
         double best = fabs(M[c][c]);
         for (int r = c + 1; r < 10; ++r) if (fabs(M[r][c]) > best) { best = fabs(M[r][c]); p = r; }
         if (best < 1e-14) return 0;
-        if (p != c) for (int k = 0; k < 20; ++k) { const double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; }
+        FPT_SYNC();
+        if (p != c) { FPT_PAR_FOR(k, 0, 19) { const double t = M[c][k]; M[c][k] = M[p][k]; M[p][k] = t; } }
+        FPT_SYNC();
         const double inv = 1.0 / M[c][c];
-        for (int k = 0; k < 20; ++k) M[c][k] *= inv;
+        FPT_SYNC();
+        FPT_PAR_FOR(k, 0, 19) M[c][k] *= inv;
+        FPT_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+        double f[4];
+        for (int pass = 0; pass < 4; ++pass) {
+            const int idx = (int)threadIdx.x + 64 * pass;
+            f[pass] = idx < 200 ? M[idx / 20][c] : 0.0;
+        }
+        FPT_SYNC();
+        for (int pass = 0; pass < 4; ++pass) {
+            const int idx = (int)threadIdx.x + 64 * pass;
+            if (idx >= 200) continue;
+            const int r = idx / 20, k = idx - 20 * r;
+            if (r != c && f[pass] != 0.0) M[r][k] -= f[pass] * M[c][k];
+        }
+        FPT_SYNC();
+#else
         for (int r = 0; r < 10; ++r) {
             if (r == c) continue;
             const double f = M[r][c];
             if (f == 0.0) continue;
             for (int k = 0; k < 20; ++k) M[r][k] -= f * M[c][k];
         }
+#endif
     }
     // action matrix of multiplication by x on b = [x2 xy xz y2 yz z2 x y z 1]
     double (&Ax)[100] = w.Ax;
