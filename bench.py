@@ -303,6 +303,27 @@ def main():
         out["pose_solve"] = {"what": "clc_pnp_ransac: 256 P3P samples, <=1024 hypotheses x N matches, thr 4 px, host buffers in/out; "
                                      "with_refine = clc_pnp_localize (the same + LM/Huber(16) refinement on the inliers + 6x6 covariance, one submission)",
                              **pose}
+        # two-view filter: five-point RANSAC over 1000 correspondences, 30 % outliers, host buffers in/out
+        try:
+            rng2 = np.random.default_rng(11)
+            Nc = 1000
+            Xs = np.stack([rng2.uniform(-5, 5, Nc), rng2.uniform(-5, 5, Nc), rng2.uniform(4, 20, Nc)], 1)
+            Kc = np.array([[1000.0, 0, 640], [0, 1000.0, 360], [0, 0, 1]])
+            ang = 0.2
+            Rc = np.array([[np.cos(ang), 0, -np.sin(ang)], [0, 1, 0], [np.sin(ang), 0, np.cos(ang)]])
+            p1 = Xs @ Kc.T; p1 = p1[:, :2] / p1[:, 2:3]
+            p2 = (Xs @ Rc.T + np.array([0.5, 0.1, 0.2])) @ Kc.T; p2 = p2[:, :2] / p2[:, 2:3] + rng2.normal(0, 0.5, (Nc, 2))
+            oi = rng2.choice(Nc, 300, replace=False)
+            p2[oi] = np.stack([rng2.uniform(0, 1280, 300), rng2.uniform(0, 720, 300)], 1)
+            te = []
+            for it in range(45):
+                t1 = time.perf_counter()
+                _, _, emask = ctx.essential_ransac(p1, p2, Kc, Kc, n_samples=256, seed=it + 1, thr2=4.0)
+                te.append((time.perf_counter() - t1) * 1e3)
+            out["two_view"] = {"what": "clc_essential_ransac: 256 five-point samples (<= 2560 hypotheses) x 1000 correspondences, thr 2 px",
+                               "p50_ms": float(np.median(te[5:])), "inliers": int(emask.sum())}
+        except Exception as exc:                       # an f-row extra must never take the headline line down
+            out["two_view"] = {"error": repr(exc)}
         if world == 1:
             # accepted matches, and the end-to-end rates of the host-buffer entry points (uploads, downloads and
             # the synchronisation included; never used as `value`)
