@@ -50,7 +50,10 @@ P3P_HD int p3p_solve_cubic(double a, double b, double c, double* x)
     return 3;
 }
 
-// real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (c4 != 0) in closed form, UNPOLISHED (p3p_polish_root); returns count (0..4)
+// real roots of c4 x^4 + c3 x^3 + c2 x^2 + c1 x + c0 (c4 != 0) in closed form, UNPOLISHED (p3p_polish_root).
+// Fixed slots, no compaction (a running count would index the output dynamically = scratch memory on the device):
+// roots[0], roots[1] come from the first quadratic factor, roots[2], roots[3] from the second; returns the mask of
+// the slots that hold a real root.
 P3P_HD int p3p_solve_quartic(const double* co, double* roots)
 {
     const double a = co[3] / co[4], b = co[2] / co[4], c = co[1] / co[4], d = co[0] / co[4];
@@ -59,36 +62,36 @@ P3P_HD int p3p_solve_quartic(const double* co, double* roots)
     const double p = b - 0.375 * a2;
     const double q = c - 0.5 * a * b + 0.125 * a2 * a;
     const double r = d - 0.25 * a * c + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
-    int n = 0;
-    double y[4];
+    int mask = 0;
+    double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
     if (fabs(q) < 1e-14 * (1.0 + fabs(p) + fabs(r))) {
         // biquadratic
         const double disc = p * p - 4.0 * r;
         if (disc >= 0.0) {
             const double s = sqrt(disc);
             const double z0 = 0.5 * (-p + s), z1 = 0.5 * (-p - s);
-            if (z0 >= 0.0) { y[n++] = sqrt(z0); y[n++] = -sqrt(z0); }
-            if (z1 >= 0.0) { y[n++] = sqrt(z1); y[n++] = -sqrt(z1); }
+            if (z0 >= 0.0) { y0 = sqrt(z0); y1 = -y0; mask |= 3; }
+            if (z1 >= 0.0) { y2 = sqrt(z1); y3 = -y2; mask |= 12; }
         }
     } else {
         // resolvent: m^3 + p m^2 + (p^2/4 - r) m - q^2/8 = 0, take the largest real root (it is > 0)
         double m3[3];
         const int nm = p3p_solve_cubic(p, 0.25 * p * p - r, -0.125 * q * q, m3);
         double m = m3[0];
-        for (int i = 1; i < nm; ++i) m = m3[i] > m ? m3[i] : m;
+        if (nm == 3) { m = m3[1] > m ? m3[1] : m; m = m3[2] > m ? m3[2] : m; }
         if (m > 0.0) {
             const double s = sqrt(2.0 * m);
             const double t0 = 0.5 * p + m;
             const double t1 = q / (2.0 * s);
             // y^2 + s y + (t0 - t1) = 0  and  y^2 - s y + (t0 + t1) = 0
             double disc = s * s - 4.0 * (t0 - t1);
-            if (disc >= 0.0) { const double sq = sqrt(disc); y[n++] = 0.5 * (-s + sq); y[n++] = 0.5 * (-s - sq); }
+            if (disc >= 0.0) { const double sq = sqrt(disc); y0 = 0.5 * (-s + sq); y1 = 0.5 * (-s - sq); mask |= 3; }
             disc = s * s - 4.0 * (t0 + t1);
-            if (disc >= 0.0) { const double sq = sqrt(disc); y[n++] = 0.5 * (s + sq); y[n++] = 0.5 * (s - sq); }
+            if (disc >= 0.0) { const double sq = sqrt(disc); y2 = 0.5 * (s + sq); y3 = 0.5 * (s - sq); mask |= 12; }
         }
     }
-    for (int i = 0; i < n; ++i) roots[i] = y[i] - 0.25 * a;
-    return n;
+    roots[0] = y0 - 0.25 * a; roots[1] = y1 - 0.25 * a; roots[2] = y2 - 0.25 * a; roots[3] = y3 - 0.25 * a;
+    return mask;
 }
 
 // Newton polish of one root on the original polynomial
@@ -137,7 +140,7 @@ struct P3PProblem {
     double b2;
     double E[3][3];                   // world triad
     double roots[4];                  // closed-form roots of the quartic (unpolished) / of the cubic fallback
-    int nr;
+    int mask;                         // which of the four slots hold a real root
     bool polish;                      // quartic branch: Newton-polish a root before use
 };
 
@@ -147,7 +150,7 @@ P3P_HD bool p3p_prepare(const double X[3][3], const double f[3][3], P3PProblem& 
     double d12[3], d13[3], d23[3];
     for (int i = 0; i < 3; ++i) { d12[i] = X[0][i] - X[1][i]; d13[i] = X[0][i] - X[2][i]; d23[i] = X[1][i] - X[2][i]; }
     const double c2 = p3p_dot(d12, d12), b2 = p3p_dot(d13, d13), a2 = p3p_dot(d23, d23);
-    p.nr = 0;
+    p.mask = 0;
     if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return false;
     const double ca = p3p_dot(f[1], f[2]), cb = p3p_dot(f[0], f[2]), cg = p3p_dot(f[0], f[1]);
     const double q = (a2 - c2) / b2;
@@ -170,10 +173,11 @@ P3P_HD bool p3p_prepare(const double X[3][3], const double f[3][3], P3PProblem& 
     const double scale = fabs(co[0]) + fabs(co[1]) + fabs(co[2]) + fabs(co[3]) + fabs(co[4]);
     if (!(scale > 0.0)) return false;
     if (fabs(co[4]) > 1e-12 * scale) {
-        p.nr = p3p_solve_quartic(co, p.roots);
+        p.mask = p3p_solve_quartic(co, p.roots);
         p.polish = true;
     } else if (fabs(co[3]) > 1e-12 * scale) {
-        p.nr = p3p_solve_cubic(co[2] / co[3], co[1] / co[3], co[0] / co[3], p.roots);
+        p.roots[3] = 0.0;
+        p.mask = (1 << p3p_solve_cubic(co[2] / co[3], co[1] / co[3], co[0] / co[3], p.roots)) - 1;
         p.polish = false;
     } else {
         return false;
@@ -185,8 +189,9 @@ P3P_HD bool p3p_prepare(const double X[3][3], const double f[3][3], P3PProblem& 
 // does not give a valid pose.
 P3P_HD bool p3p_pose_from_root(const P3PProblem& p, const double X[3][3], const double f[3][3], const int k, double* P)
 {
-    if (k >= p.nr) return false;
-    const double v = p.polish ? p3p_polish_root(p.co, p.roots[k]) : p.roots[k];
+    if (!((p.mask >> k) & 1)) return false;
+    const double rk = k == 0 ? p.roots[0] : (k == 1 ? p.roots[1] : (k == 2 ? p.roots[2] : p.roots[3]));   // no dynamic index
+    const double v = p.polish ? p3p_polish_root(p.co, rk) : rk;
     if (!(v > 0.0)) return false;
     const double den = p.D[0] + p.D[1] * v;
     if (fabs(den) < 1e-12) return false;
@@ -214,7 +219,7 @@ P3P_HD int p3p_solve(const double X[3][3], const double f[3][3], double* Rt_out)
     P3PProblem p;
     if (!p3p_prepare(X, f, p)) return 0;
     int ns = 0;
-    for (int k = 0; k < p.nr && ns < 4; ++k)
+    for (int k = 0; k < 4; ++k)
         if (p3p_pose_from_root(p, X, f, k, Rt_out + 12 * ns)) ++ns;
     return ns;
 }
