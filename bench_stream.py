@@ -9,8 +9,8 @@ configuration.  One camera per rank (python -m torch.distributed.run --nproc-per
 Per frame and camera (reference include/coloc/coloc.hpp:201-272 intraPoseEstimator + :362-389 fusion):
   1. front end on the frame image, device-resident: pyramid -> FAST-9/NMS/orientation -> CLATCH
      (timing realism: the synthetic frames carry no geometry, so these descriptors are not matched);
-  2. map tracking: the frame's observed descriptors (map descriptors with bit noise + distractors) against the
-     map on the GPU, threshold MatcherOptions.thresh = 60 -> 2D-3D correspondences (GPUMatcher.hpp:174-178,252-271);
+  2. map tracking: the frame's observed descriptors (map descriptors with bit noise + distractors; device-resident
+     like the CLATCH output they stand in for) against the map on the GPU (clc_match_map_dev), threshold MatcherOptions.thresh = 60 -> 2D-3D correspondences (GPUMatcher.hpp:174-178,252-271);
   3. clc_pnp_localize: 256 P3P samples -> scored hypotheses -> LM refinement + 6x6 covariance;
   4. fusion: each camera's position is fused with its neighbour's estimate of it (here: the neighbour's own
      error-free relative offset, so the fused value can be checked) by covariance intersection.
@@ -104,8 +104,14 @@ def main():
             q = np.concatenate([obs, frng.integers(0, 256, size=(n_dis, 64), dtype=np.uint8)])
             xy = np.concatenate([uv[vis] + frng.normal(0, 0.5, (len(vis), 2)),
                                  np.stack([frng.uniform(0, W, n_dis), frng.uniform(0, H, n_dis)], 1)])
+            # in the real loop these descriptors are CLATCH output and already on the device (stage 1): upload the synthetic
+            # stand-ins outside the timed stage, then match on the device and bring back only the match indices
+            d_q = torch.from_numpy(q).to(dev)
+            d_m = torch.empty(q.shape[0], dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
             t1b = time.perf_counter()
-            m = ctx.match_map(q, 60)                     # train = map: m[i] = map index or -1  (IndMatch(map, query))
+            ctx.match_map_dev(d_q.data_ptr(), q.shape[0], 60, d_m.data_ptr(), sptr)   # train = map: m[i] = map index or -1  (IndMatch(map, query))
+            m = d_m.cpu().numpy()
             t2 = time.perf_counter()
             sel = np.nonzero(m >= 0)[0]
             # 3. robust pose + refinement + covariance

@@ -45,7 +45,7 @@ EXPORTS = [
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
-    "clc_essential_fivepoint", "clc_describe_batch_dev",
+    "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -112,6 +112,7 @@ def load_library():
     lib.clc_match_jobs_dev.argtypes = [vp, vp, vp, ci, vp, vp]
     lib.clc_match_pairs.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp]
     lib.clc_set_map.argtypes = [vp, vp, ci]
+    lib.clc_match_map_dev.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.clc_match_map.argtypes = [vp, vp, ci, ci, vp]
     lib.clc_pnp_residuals.argtypes = [vp, vp, ci, vp, vp, ci, vp, vp]
     lib.clc_pnp_score.argtypes = [vp, vp, ci, vp, vp, ci, vp, C.c_double, vp, vp]
@@ -324,6 +325,9 @@ class Context:
     def set_map(self, desc):
         desc = np.ascontiguousarray(desc, dtype=np.uint8).reshape(-1, 64)
         self._chk(self.lib.clc_set_map(self.h, _p(desc), desc.shape[0]))
+
+    def match_map_dev(self, d_q, nq, threshold, d_match, stream=None):
+        self._chk(self.lib.clc_match_map_dev(self.h, d_q, nq, int(threshold), d_match, stream))
 
     def match_map(self, Q, threshold=60):
         Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)

@@ -762,6 +762,14 @@ int clc_match_map(clc_ctx* ctx, const void* h_q, int nq, int threshold, int32_t*
     return match_host(ctx, h_q, nq, ctx->d_m, ctx->map_n, threshold, h_match, nullptr, nullptr);
 }
 
+int clc_match_map_dev(clc_ctx* ctx, const void* d_q, int nq, int threshold, int32_t* d_match, void* stream)
+{
+    if (!ctx || nq < 0 || (nq > 0 && (!d_q || !d_match))) return fail(ctx, CLC_ERR_BAD_ARG, "match_map_dev: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "match_map_dev: context created without matcher options");
+    if (ctx->map_n < 0) return fail(ctx, CLC_ERR_STATE, "match_map_dev before set_map");
+    return clc_match_2nn_dev(ctx, d_q, nq, ctx->d_m, ctx->map_n, threshold, d_match, stream);
+}
+
 /* ---- PnP ------------------------------------------------------------------------------------ */
 
 static int pnp_upload(clc_ctx* ctx, const double* h_Rt, int H, const double* h_X, const double* h_x, int N,

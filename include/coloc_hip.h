@@ -209,6 +209,9 @@ int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, 
 /* Map database: GPUMatcher::setMapData (GPUMatcher.hpp:110-117) / matchFeaturesWithMap (:252-271). */
 int clc_set_map(clc_ctx* ctx, const void* h_desc, int n);
 int clc_match_map(clc_ctx* ctx, const void* h_q, int nq, int threshold, int32_t* h_match);
+/* The same against descriptors that are still on the GPU (clc_describe*_dev output): enqueue only; d_match[i] = map
+ * index or -1.  In a streaming loop the frame's descriptors then never leave the device, only the nq x 4 B result does. */
+int clc_match_map_dev(clc_ctx* ctx, const void* d_q, int nq, int threshold, int32_t* d_match, void* stream);
 
 /* ---- pose scoring: the data-parallel core of SfM_Localizer::Localize (Localizer.hpp:82-93) --- */
 

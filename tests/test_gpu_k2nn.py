@@ -159,3 +159,20 @@ def test_random_shapes_stress(gpu_ctx, oracle):
         m, b, s = gpu_ctx.match_2nn(Q, T, thr, want_dist=True)
         mo, bo, so = oracle.k2nn(Q, T, thr, want_dist=True)
         assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so), (it, nq, nt, thr)
+
+
+def test_map_tracking_on_device_equals_host_path(gpu_ctx, oracle):
+    """clc_match_map_dev (query descriptors already on the GPU) == clc_match_map == the oracle."""
+    import torch
+    M = synth.random_descriptors(3000, seed=41)
+    Q, _ = synth.planted_descriptors(1200, 10, seed=42)
+    Q[:500] = M[:500]; Q[:500, 5] ^= 0x81
+    gpu_ctx.set_map(M)
+    want = oracle.k2nn(Q, M, 60)
+    assert np.array_equal(gpu_ctx.match_map(Q, 60), want)
+    d_q = torch.from_numpy(Q).cuda()
+    d_m = torch.full((Q.shape[0],), -7, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.match_map_dev(d_q.data_ptr(), Q.shape[0], 60, d_m.data_ptr())
+    gpu_ctx.sync()
+    assert np.array_equal(d_m.cpu().numpy(), want)
