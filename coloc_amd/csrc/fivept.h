@@ -487,34 +487,42 @@ FPT_HD int fivept_solve(const double q1[5][2], const double q2[5][2], double* E_
         e[k][16] = EE[0][k]; e[k][17] = EE[1][k]; e[k][18] = EE[2][k]; e[k][19] = EE[3][k];
     }
     double (&M)[10][20] = w.M;
-    for (int r = 0; r < 10; ++r) for (int m = 0; m < 20; ++m) M[r][m] = 0.0;
-    {
-        // det(E): e0 (e4 e8 - e5 e7) - e1 (e3 e8 - e5 e6) + e2 (e3 e7 - e4 e6)
-        double (&t)[20] = w.t;
-        const int tri[3][5] = { { 0, 4, 8, 5, 7 }, { 1, 3, 8, 5, 6 }, { 2, 3, 7, 4, 6 } };
-        for (int s = 0; s < 3; ++s) {
-            for (int m = 0; m < 20; ++m) t[m] = 0.0;
-            fpt_mul_lin_lin(e[tri[s][1]], e[tri[s][2]], 1.0, t);
-            fpt_mul_lin_lin(e[tri[s][3]], e[tri[s][4]], -1.0, t);
-            fpt_mul_quad_lin(t, e[tri[s][0]], s == 1 ? -1.0 : 1.0, M[0]);
+    double (&G)[9][20] = w.G;
+    double (&tr)[20] = w.tr;
+    // (on the device: one polynomial per lane -- ten lanes build G = E E^T and det(E), then nine lanes the rows of
+    //  2 G E - tr(G) E; on the host the same in turn)
+    FPT_SYNC();
+    FPT_PAR_FOR(g, 0, 9) {
+        if (g < 9) {
+            // G = E E^T (quadratic)
+            const int a = g / 3, b = g - 3 * a;
+            for (int m = 0; m < 20; ++m) G[g][m] = 0.0;
+            for (int c = 0; c < 3; ++c) fpt_mul_lin_lin(e[3 * a + c], e[3 * b + c], 1.0, G[g]);
+        } else {
+            // det(E): e0 (e4 e8 - e5 e7) - e1 (e3 e8 - e5 e6) + e2 (e3 e7 - e4 e6)
+            double (&t)[20] = w.t;
+            for (int m = 0; m < 20; ++m) M[0][m] = 0.0;
+            const int tri[3][5] = { { 0, 4, 8, 5, 7 }, { 1, 3, 8, 5, 6 }, { 2, 3, 7, 4, 6 } };
+            for (int s = 0; s < 3; ++s) {
+                for (int m = 0; m < 20; ++m) t[m] = 0.0;
+                fpt_mul_lin_lin(e[tri[s][1]], e[tri[s][2]], 1.0, t);
+                fpt_mul_lin_lin(e[tri[s][3]], e[tri[s][4]], -1.0, t);
+                fpt_mul_quad_lin(t, e[tri[s][0]], s == 1 ? -1.0 : 1.0, M[0]);
+            }
         }
-        // G = E E^T (quadratic), tr = trace(G);  C = 2 G E - tr E
-        double (&G)[9][20] = w.G;
-        double (&tr)[20] = w.tr;
-        for (int m = 0; m < 20; ++m) tr[m] = 0.0;
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
-                for (int m = 0; m < 20; ++m) G[3 * a + b][m] = 0.0;
-                for (int c = 0; c < 3; ++c) fpt_mul_lin_lin(e[3 * a + c], e[3 * b + c], 1.0, G[3 * a + b]);
-            }
-        for (int m = 0; m < 20; ++m) tr[m] = G[0][m] + G[4][m] + G[8][m];
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) {
-                double* row_ = M[1 + 3 * a + b];
-                for (int c = 0; c < 3; ++c) fpt_mul_quad_lin(G[3 * a + c], e[3 * c + b], 2.0, row_);
-                fpt_mul_quad_lin(tr, e[3 * a + b], -1.0, row_);
-            }
     }
+    FPT_SYNC();
+    FPT_PAR_FOR(m, 0, 19) tr[m] = G[0][m] + G[4][m] + G[8][m];
+    FPT_SYNC();
+    FPT_PAR_FOR(g, 0, 8) {
+        // C = 2 G E - tr E
+        const int a = g / 3, b = g - 3 * a;
+        double* row_ = M[1 + g];
+        for (int m = 0; m < 20; ++m) row_[m] = 0.0;
+        for (int c = 0; c < 3; ++c) fpt_mul_quad_lin(G[3 * a + c], e[3 * c + b], 2.0, row_);
+        fpt_mul_quad_lin(tr, e[3 * a + b], -1.0, row_);
+    }
+    FPT_SYNC();
     double (&M0)[10][20] = w.M0;             // the constraints before elimination: used to polish the roots
     for (int r = 0; r < 10; ++r) {
         double nr = 0.0;
