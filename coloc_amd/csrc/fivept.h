@@ -40,7 +40,7 @@ struct FptWorkspace {
     // one slot per eigenvalue: on the device the ten roots are refined by ten lanes at once
     struct Root {
         double lu[10][11];                                        // shifted solve
-        double v[10], y[10], mono[20], dmx[20], dmy[20], dmz[20];
+        double v[10], y[10];
         double cand[9];                                           // the essential matrix this root gives
         int valid;
     } root[10];
@@ -391,22 +391,29 @@ FPT_HD void fpt_root_candidate(FptWorkspace& w, const int k, const double anorm)
         // polish (x, y, z) on the ten cubic constraints themselves (Gauss-Newton, 3 unknowns): the eigen-solution
         // of a nearly defective action matrix is only good to ~1e-5, the constraints pin it to rounding
         for (int it = 0; it < 4; ++it) {
-            double (&mono)[20] = rw.mono;
-            double (&dmx)[20] = rw.dmx;
-            double (&dmy)[20] = rw.dmy;
-            double (&dmz)[20] = rw.dmz;
+            // monomials and their derivatives with compile-time exponents, loops fully unrolled on the device: the 80
+            // values stay in registers and the 10 x 20 x 4 multiply-adds below read M0 at fixed LDS offsets
+            double mono[20], dmx[20], dmy[20], dmz[20];
+            const double px[4] = { 1.0, x, x * x, x * x * x }, py[4] = { 1.0, yv, yv * yv, yv * yv * yv }, pz[4] = { 1.0, z, z * z, z * z * z };
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
             for (int m = 0; m < 20; ++m) {
-                int ei, ej, ek;
-                fpt_mono_exp(m, &ei, &ej, &ek);
-                const double px[4] = { 1.0, x, x * x, x * x * x }, py[4] = { 1.0, yv, yv * yv, yv * yv * yv }, pz[4] = { 1.0, z, z * z, z * z * z };
+                const int ei = kFptExp[m][0], ej = kFptExp[m][1], ek = kFptExp[m][2];
                 mono[m] = px[ei] * py[ej] * pz[ek];
-                dmx[m] = ei ? ei * px[ei - 1] * py[ej] * pz[ek] : 0.0;
-                dmy[m] = ej ? ej * px[ei] * py[ej - 1] * pz[ek] : 0.0;
-                dmz[m] = ek ? ek * px[ei] * py[ej] * pz[ek - 1] : 0.0;
+                dmx[m] = ei ? ei * px[ei ? ei - 1 : 0] * py[ej] * pz[ek] : 0.0;
+                dmy[m] = ej ? ej * px[ei] * py[ej ? ej - 1 : 0] * pz[ek] : 0.0;
+                dmz[m] = ek ? ek * px[ei] * py[ej] * pz[ek ? ek - 1 : 0] : 0.0;
             }
             double JtJ[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, Jtr[3] = { 0, 0, 0 };
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
             for (int r = 0; r < 10; ++r) {
                 double rr = 0.0, jx = 0.0, jy = 0.0, jz = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
                 for (int m = 0; m < 20; ++m) { rr += M0[r][m] * mono[m]; jx += M0[r][m] * dmx[m]; jy += M0[r][m] * dmy[m]; jz += M0[r][m] * dmz[m]; }
                 JtJ[0] += jx * jx; JtJ[1] += jx * jy; JtJ[2] += jx * jz; JtJ[4] += jy * jy; JtJ[5] += jy * jz; JtJ[8] += jz * jz;
                 Jtr[0] += jx * rr; Jtr[1] += jy * rr; Jtr[2] += jz * rr;
