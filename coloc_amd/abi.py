@@ -45,7 +45,8 @@ EXPORTS = [
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
-    "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev",
+    "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
+    "clc_k2nn_queries_per_block",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -134,6 +135,8 @@ def load_library():
     lib.clc_profile_reset.argtypes = [vp]
     lib.clc_profile_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(ci)]
     lib.clc_kernel_name.restype = C.c_char_p
+    lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
+    lib.clc_k2nn_queries_per_block.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -295,6 +298,14 @@ class Context:
         self._chk(self.lib.clc_describe_batch_dev(self.h, n, imgs, width, height, pitch, kps, cnt, out, stream))
 
     # -- match
+    def set_k2nn_formulation(self, name):
+        """"matrix" (FP4 matrix pipe, default) or "popcount" (xor + popcount on the vector ALU): same results."""
+        self._chk(self.lib.clc_k2nn_set_formulation(self.h, {"matrix": 0, "popcount": 1}[name]))
+
+    @property
+    def k2nn_queries_per_block(self):
+        return int(self.lib.clc_k2nn_queries_per_block(self.h))
+
     def match_2nn(self, Q, T, threshold=40, want_dist=False):
         Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
         T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 64)

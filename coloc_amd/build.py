@@ -15,7 +15,10 @@ SOURCES = ["capi.hip", "k2nn.hip", "clatch.hip", "lerp.hip", "pnp.hip", "detect.
 HEADERS = ["clc_internal.h", "clc_sincos.h", "p3p.h", "fivept.h", "latch_pattern.inc", "latch_layout.inc", os.path.join("..", "host", "HIPCovIntersection.hpp"), os.path.join("..", "..", "include", "coloc_hip.h")]
 # -ffp-contract=off: the fp32 sample-coordinate / bilinear expressions and the fp64 residuals must
 # evaluate in source order without fused multiply-add.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in plain VGPRs (gfx950's register file is unified), so the K2NN top-2 reads
+# them directly instead of through v_accvgpr_read copies.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def hipcc_path():

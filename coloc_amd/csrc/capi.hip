@@ -106,7 +106,8 @@ struct clc_ctx {
     uint2* d_partial = nullptr;
     size_t partial_cap = 0;
     bool partial_dirty = false;      // armed (all-ones) state of the atomic top-2 rows was lost
-    int target_blocks = 2560;        // K2NN sweep workgroups (of 8 waves) aimed at per launch
+    int formulation = K2NN_MATRIX;   // K2NN sweep formulation (k2nn.hip): FP4 matrix pipe, or round 1's popcount kernel for A/B runs
+    int target_blocks = 0;           // K2NN sweep workgroups aimed at per launch; 0 = the formulation's default
     bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
@@ -127,6 +128,9 @@ int fail(clc_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
         if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
         else snprintf(buf, sizeof buf, "%s", what);
         ctx->err = buf;
+        // Any HIP failure on this context -- including one that only surfaces at a later synchronisation -- may have cut a
+        // K2NN sweep short and left top-2 rows / arrival counters un-armed: re-arm the workspace before the next sweep.
+        if (code == CLC_ERR_HIP) ctx->partial_dirty = true;
     }
     return code;
 }
@@ -191,9 +195,13 @@ int ensure_pnp(clc_ctx* ctx, size_t doubles)
     return CLC_OK;
 }
 
+// matrix: 3 workgroups of 4 waves per CU (152 VGPRs); popcount: 10 rounds of 8-wave workgroups (measured optima)
+int default_target_blocks(int formulation) { return formulation == K2NN_POPCOUNT ? 2560 : 768; }
+
 int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
 {
-    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), ctx->target_blocks, ctx->xcd_map);
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), target, ctx->xcd_map, ctx->formulation);
     const int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;
     if (!plan.atomic_merge) ctx->partial_dirty = true;           // slab mode scribbles over the armed rows
@@ -201,7 +209,7 @@ int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
         CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
         ctx->partial_dirty = false;
     }
-    const hipError_t e = launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, &ctx->prof);
+    const hipError_t e = launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, &ctx->prof, ctx->formulation);
     if (e != hipSuccess) { ctx->partial_dirty = true; return fail(ctx, CLC_ERR_HIP, "launch_k2nn", e); }
     return CLC_OK;
 }
@@ -258,6 +266,7 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         if (v > 0) ctx->target_blocks = v;
     }
     if (const char* e = getenv("CLC_K2NN_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
+    if (const char* e = getenv("CLC_K2NN_FORMULATION")) ctx->formulation = (e[0] == 'p' || e[0] == '1') ? K2NN_POPCOUNT : K2NN_MATRIX;
     if (dopts) {
         ctx->has_det = true;
         ctx->dopts = *dopts;
@@ -592,6 +601,19 @@ int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4)
 }
 
 /* ---- match ---------------------------------------------------------------------------------- */
+
+int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation)
+{
+    if (!ctx || (formulation != CLC_K2NN_MATRIX && formulation != CLC_K2NN_POPCOUNT))
+        return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_set_formulation: bad argument");
+    ctx->formulation = formulation == CLC_K2NN_POPCOUNT ? K2NN_POPCOUNT : K2NN_MATRIX;
+    return CLC_OK;
+}
+
+int clc_k2nn_queries_per_block(const clc_ctx* ctx)
+{
+    return k2nn_queries_per_block(ctx ? ctx->formulation : K2NN_MATRIX);
+}
 
 int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int threshold,
                       int32_t* d_match, void* stream)

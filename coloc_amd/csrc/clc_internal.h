@@ -86,14 +86,16 @@ struct K2nnPlan {
     size_t   partial_elems;// uint2 entries needed
     bool     atomic_merge; // every job fits the 22-bit global train index -> atomic top-2 merge
 };
+// The two formulations of the sweep (k2nn.hip): FP4 matrix pipe (default) and round 1's xor + popcount VALU kernel.
+enum { K2NN_MATRIX = 0, K2NN_POPCOUNT = 1 };
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true);
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true, int formulation = K2NN_MATRIX);
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
 // In atomic mode d_partial must hold 0xFF bytes in every entry the jobs use (top-2 rows and arrival counters);
 // the workgroup that completes a query block leaves it that way again (self re-arming workspace).
 hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream,
-                       Profiler* prof = nullptr);
-int k2nn_queries_per_block();
+                       Profiler* prof = nullptr, int formulation = K2NN_MATRIX);
+int k2nn_queries_per_block(int formulation);
 
 // ---- PnP -------------------------------------------------------------------------------------
 hipError_t launch_pnp_residuals(const double* d_Rt, int H, const double* d_X, const double* d_x,

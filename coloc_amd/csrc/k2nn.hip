@@ -2,9 +2,27 @@
 //
 // Semantics: reference src/CUDAK2NN.cu:46-75 (per query: running best / second-best Hamming
 // distance over all train vectors in index order, accept iff second - best > threshold, ties for
-// the minimum keep the lowest train index).  The ARCHITECTURE is not the reference's: that kernel
-// is a 1-D grid of 256 queries per block (40 blocks at 10k queries, CUDAK2NN.cu:79) built around
-// a 32-lane shuffle butterfly.  Here:
+// the minimum keep the lowest train index).  The ARCHITECTURE is not the reference's (a 1-D grid of
+// 256 queries per block, 40 blocks at 10k queries, CUDAK2NN.cu:79, around a 32-lane shuffle butterfly).
+//
+// Two formulations of the same sweep live here; both produce the same {best_key, second_key} rows and share the
+// in-launch finalize (atomic fold + arrival counter) and the slab/merge fallback.  Selected per context
+// (CLC_K2NN_FORMULATION=popcount|matrix, default matrix); the tests run both against the oracle.
+//
+// (A) matrix pipe -- k2nn_sweep_mx_kernel (default).  d(q, t) = (512 - <q, t>) / 2 with bits as +-1.
+//   v_mfma_scale_f32_32x32x64_f8f6f4 takes FP4 (E2M1) operands, 64 k-values per instruction, in the cycles of the bf16
+//   32x32x16 form: 8 MFMAs give the 1024 distances of a 32-train x 32-query tile, 0.25 cycles per comparison per SIMD
+//   against ~1.8 for the popcount form.  Everything stays exact:
+//     query bit b -> nibble 0x2 | b << 3 (+1 / -1), train bit b -> nibble 0x2 | ~b << 3 (-1 / +1): sum = 2 d - 512;
+//     the A (train) operand carries the E8M0 block scale 2^12 and C = 2^23 + 2^21 + (train index inside the split,
+//     < 8192), so the accumulator is 2^23 + (d << 13) + index: an integer below 2^24, exact in fp32 in any order, whose
+//     FLOAT BITS 0x4B000000 + (d << 13) + index are already the (distance, index) key, ordered like the floats.
+//   Top-2 per query = two v_med3_f32 on the raw accumulator registers (lane = query column, the 16 accumulator
+//   registers = 16 train rows); no key-forming instruction.  Descriptors stay in their 64-byte bit form in memory:
+//   a wave expands its 64 queries into B operands once (registers), the workgroup expands each 32-train tile into
+//   LDS (coalesced 8-byte loads, 7 VALU ops per 16 bytes of FP4) for its four waves.
+//
+// (B) popcount -- k2nn_sweep_kernel (round 1's kernel, kept as the measured A/B reference):
 //
 //   * lane = query.  Each lane keeps R complete 512-bit queries in VGPRs (16 dwords each), so a
 //     distance needs NO cross-lane traffic at all.
@@ -18,17 +36,14 @@
 //     Unsigned order on keys is (distance, index) lexicographic, so best' = min(best, key) keeps
 //     the lowest index among equal distances, and second' = med3(best, second, key) is the second
 //     smallest key = the second smallest distance of the multiset.  3 more lane-ops per pair.
-//   * 2-D decomposition: (query block of 128) x (train split), and the 8 waves of a workgroup cut
-//     their split in eight and fold their results through LDS, so that 10k x 10k fills 256 CUs x 8
-//     waves/SIMD with only one 8-byte result per (query, workgroup).  Splits are folded into one {best_key, second_key} row per query with two
+//
+// Both: 2-D decomposition (query block) x (train split) so that 10k x 10k fills 256 CUs (the reference's 1-D grid
+//     would be 40 blocks).  Splits are folded into one {best_key, second_key} row per query with two
 //     atomicMin (keys carry the global train index, so the fold is order-free and exact -- the
 //     merge rule of SURVEY.md 8(a) note N1 with "lowest index wins" built into the key order); the
 //     workgroup whose arrival completes a query block (a per-block arrival counter) applies the threshold,
 //     writes the int32 results and re-arms rows and counter -- no second launch, no spinning.
 //     Train sets beyond 2^22 vectors fall back to per-split slabs + an ordered merge kernel.
-//
-// Bound: integer VALU (32 of the 35 lane-ops per pair are the algorithmic xor+popcount); HBM
-// traffic is the compulsory 64*(nq+nt) B plus 8 B of atomics per (query, split).
 #include "clc_internal.h"
 
 namespace clc {
@@ -50,7 +65,16 @@ typedef const u32x4 __attribute__((address_space(4)))* const_u4_ptr;
 typedef const u32x4 __attribute__((address_space(1)))* global_cu4_ptr;
 typedef u32x2 __attribute__((address_space(1)))* global_u2_ptr;
 
-int k2nn_queries_per_block() { return kQPerBlock; }
+// matrix-pipe formulation
+static constexpr int kMxQT = 2;                          // 32-query tiles per wave (B operands: 32 VGPRs each)
+static constexpr int kMxWaves = 4;                       // waves per workgroup; they share the train tiles through LDS
+static constexpr int kMxQPerBlock = 32 * kMxQT * kMxWaves;
+static constexpr uint32_t kMxIdxBits = 13;               // train index inside a split rides in the accumulator: splits <= 8192 rows
+static constexpr uint32_t kMxMaxSplit = 1u << kMxIdxBits;
+static constexpr uint32_t kMxMagic = 0x4B000000u;        // float bits of 2^23
+static constexpr uint32_t kMxInf = 0x7F800000u;          // "no key yet": above every accumulator value
+
+int k2nn_queries_per_block(int formulation) { return formulation == K2NN_POPCOUNT ? kQPerBlock : kMxQPerBlock; }
 
 // One train vector (16 wave-uniform dwords in SGPRs) against the R queries of this lane.
 //
@@ -249,6 +273,184 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
     }
 }
 
+// ---- (A) matrix-pipe sweep ---------------------------------------------------------------------------------------
+typedef int mx_v4i __attribute__((ext_vector_type(4)));
+typedef int mx_v8i __attribute__((ext_vector_type(8)));
+typedef float mx_v16f __attribute__((ext_vector_type(16)));
+typedef const uint32_t __attribute__((address_space(1)))* global_cu32_ptr;
+typedef const u32x2 __attribute__((address_space(1)))* global_cu2_ptr;
+
+// 32 descriptor bits -> 32 FP4 nibbles 0x2 | bit << 3 (+1.0 / -1.0).  Nibble k of dword m holds bit 4 k + m: the
+// k order inside a row is arbitrary as long as queries and trains use the same one.
+__device__ __forceinline__ u32x4 mx_expand(const uint32_t x)
+{
+    u32x4 y;
+    y.x = ((x << 3) & 0x88888888u) | 0x22222222u;
+    y.y = ((x << 2) & 0x88888888u) | 0x22222222u;
+    y.z = ((x << 1) & 0x88888888u) | 0x22222222u;
+    y.w = (x & 0x88888888u) | 0x22222222u;
+    return y;
+}
+// Keys are positive finite floats, "none" is +inf: float order == unsigned order of the bits.  v_med3_f32 through the
+// builtin, NOT inline asm: the compiler pads the MFMA-result -> VALU-read hazard only for instructions it can see
+// (an asm v_med3_u32 placed straight after the last MFMA of a tile read the PREVIOUS tile's accumulator register).
+__device__ __forceinline__ float mx_med3(const float a, const float b, const float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// accumulator bits -> the canonical key (distance << 22) | (t0 + index in split); kEmpty for "none" and for the
+// penalised padding rows of a partial last tile (their distance field is above 512)
+__device__ __forceinline__ uint32_t mx_decode(const uint32_t bits, const uint32_t t0)
+{
+    const uint32_t rel = bits - kMxMagic;
+    const uint32_t d = rel >> kMxIdxBits;
+    if (bits == kMxInf || d > 512u) return kEmpty;
+    return (d << kKeyShift) | (t0 + (rel & (kMxMaxSplit - 1u)));
+}
+
+__global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial)
+{
+    constexpr int QT = kMxQT;
+    constexpr int kStride = 65;      // uint4 per k-step of a train tile in LDS: 64 lanes + 1 pad, so that the 8 k-steps
+                                     // one row is expanded into land in different banks (ds_write_b128, 8 lanes per pass)
+    __shared__ u32x4 s_a[2][8 * kStride];
+    __shared__ uint32_t s_best[kMxQPerBlock], s_second[kMxQPerBlock];
+    __shared__ uint32_t s_arrival;
+    const K2nnJobDev& job = jobs.j[blockIdx.y];
+    // consecutive workgroups walk the splits of one query block and the planner makes `splits` a multiple of 8:
+    // with round-robin placement XCD x only sees train splits = x (mod 8) (see the popcount kernel)
+    const uint32_t nblk = job.qblocks * job.splits;
+    if (blockIdx.x >= nblk) return;
+    const uint32_t qblock = blockIdx.x / job.splits;
+    const uint32_t split = blockIdx.x - qblock * job.splits;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // B operands: lane (row = l & 31, half h = l >> 5) holds the 32 k-values of words 2 j + h of its query row
+    mx_v4i b[QT][8];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        uint32_t row = qblock * kMxQPerBlock + (wave * QT + qt) * 32u + (lane & 31u);
+        if (row >= job.nq) row = job.nq - 1u;                       // clamp: duplicate work, never stored
+        const global_cu32_ptr qp = (global_cu32_ptr)(uintptr_t)job.q + (size_t)row * 16u + (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32x4 v = mx_expand(qp[2 * j]);
+            b[qt][j] = mx_v4i{ (int)v.x, (int)v.y, (int)v.z, (int)v.w };
+        }
+    }
+    // C of the first MFMA of a tile: 2^23 + 2^21 + index (inside the split) of the lane's 16 train rows
+    // (C/D layout of the 32x32 forms: column = lane & 31, row = 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3))
+    float cinit[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[i] = 8388608.0f + 2097152.0f + (float)(8 * (i >> 2) + 4 * (int)(lane >> 5) + (i & 3));
+    float best[QT], second[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { best[qt] = __uint_as_float(kMxInf); second[qt] = __uint_as_float(kMxInf); }
+
+    // this workgroup's train rows [s0, s1): t_per_split is a multiple of 32, so only the train set's last tile can be partial
+    const uint32_t s0 = min(split * job.t_per_split, job.nt);       // (the planner may pad with empty trailing splits)
+    const uint32_t s1 = min(s0 + job.t_per_split, job.nt);
+    const uint32_t ntiles = (s1 - s0 + 31u) >> 5;
+    const int scale_a = 0x8B8B8B8B, scale_b = 0x7F7F7F7F;            // E8M0 block scales: 2^12 (trains), 1 (queries)
+    // train tile = 32 rows x 64 B = 2 KB contiguous: thread tid owns its 8 bytes number tid = row tid >> 3, words
+    // 2 j', 2 j' + 1 (j' = tid & 7), i.e. both lane halves of k-step j' of that row
+    const uint32_t my_row = tid >> 3, my_j = tid & 7u;
+    const uint32_t dst = my_j * kStride + my_row;
+    const global_cu2_ptr tbase = (global_cu2_ptr)(uintptr_t)job.t + (size_t)my_j;
+    auto load_bits = [&](const uint32_t tile) -> u32x2 {
+        uint32_t row = s0 + tile * 32u + my_row;
+        if (row >= job.nt) row = job.nt - 1u;                       // stays in bounds; such rows are penalised through C
+        return tbase[(size_t)row * 8u];
+    };
+    u32x2 r0 = load_bits(0u), r1 = load_bits(min(1u, ntiles - 1u));
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const uint32_t buf = t & 1u;
+        s_a[buf][dst] = mx_expand(~r0.x);
+        s_a[buf][dst + 32] = mx_expand(~r0.y);
+        r0 = r1;
+        __syncthreads();          // one barrier per tile: buffer `buf` was last read two iterations ago, before the previous barrier
+        if (t + 2u < ntiles) r1 = load_bits(t + 2u);                // bits of the tile after next: in flight for a whole tile
+        if (t + 1u == ntiles && ((s1 - s0) & 31u)) {
+            // partial last tile: rows past the end get a penalty that puts their distance field above 512
+            const uint32_t valid = (s1 - s0) & 31u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((uint32_t)(8 * (i >> 2) + 4 * (int)(lane >> 5) + (i & 3)) >= valid) cinit[i] += 4194304.0f + 8192.0f;
+        }
+        mx_v16f acc[QT];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32x4 av = s_a[buf][j * kStride + lane];
+            const mx_v8i a8 = { (int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0 };
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const mx_v8i b8 = { b[qt][j].x, b[qt][j].y, b[qt][j].z, b[qt][j].w, 0, 0, 0, 0 };
+                mx_v16f c;
+                if (j == 0) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) c[i] = cinit[i];
+                } else c = acc[qt];
+                acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4 /* A: fp4 */, 4 /* B: fp4 */, 0, scale_a, 0, scale_b);
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                second[qt] = mx_med3(best[qt], second[qt], acc[qt][i]);
+                best[qt] = mx_med3(best[qt], acc[qt][i], 0.0f);       // = min: every key is > 0
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cinit[i] += 32.0f;
+    }
+
+    // lanes l and l ^ 32 hold the same query column (different train rows): fold them, decode to canonical keys with the
+    // index relative to s0 (slab mode) or global (atomic mode), and hand the workgroup's 256 results over through LDS so
+    // that thread i finishes query i of the block with coalesced rows
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const uint32_t mb = __float_as_uint(best[qt]), ms = __float_as_uint(second[qt]);
+        const uint32_t ob = __shfl_xor(mb, 32), os = __shfl_xor(ms, 32);
+        if (lane < 32u) {
+            const uint32_t slot = (wave * QT + qt) * 32u + lane;
+            const uint32_t base = job.atomic_merge ? s0 : 0u;
+            s_best[slot] = mx_decode(min(mb, ob), base);
+            s_second[slot] = mx_decode(min(min(ms, os), max(mb, ob)), base);
+        }
+    }
+    __syncthreads();
+    const uint32_t qi = qblock * kMxQPerBlock + tid;
+    const uint32_t bkey_l = s_best[tid], skey_l = s_second[tid];
+    if (!job.atomic_merge) {
+        const global_u2_ptr prow = (global_u2_ptr)(uintptr_t)partial + job.partial_off + (size_t)split * job.nq_pad;
+        if (qi < job.nq) prow[qi] = u32x2{ bkey_l, skey_l };
+        return;
+    }
+    // same fold / arrival / finalize protocol as the popcount kernel (see there for why no fence is needed): every
+    // thread's atomics RETURN, every wave waits for them, the workgroup barrier joins the four waves, then one lane
+    // counts the workgroup in; the last arrival of a query block turns the rows into results and re-arms them.
+    unsigned int* top = reinterpret_cast<unsigned int*>(partial + job.partial_off);
+    uint32_t seen = 0;
+    if (qi < job.nq && bkey_l != kEmpty) {
+        const uint32_t old = atomicMin(top + 2u * qi, bkey_l);
+        const uint32_t cand = bkey_l < old ? min(old, skey_l) : bkey_l;
+        seen |= old;
+        if (cand != kEmpty) seen |= atomicMin(top + 2u * qi + 1u, cand);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(seen) : : "memory");
+    __syncthreads();
+    unsigned int* cnt = reinterpret_cast<unsigned int*>(partial) + job.cnt_off + qblock;
+    if (tid == 0) s_arrival = atomicAdd(cnt, 1u) + 1u;
+    __syncthreads();
+    if (s_arrival != job.splits - 1u) return;
+    if (tid == 0) atomicExch(cnt, kEmpty);
+    if (qi < job.nq) {
+        const uint32_t bkey = atomicExch(top + 2u * qi, kEmpty);
+        const uint32_t skey = atomicExch(top + 2u * qi + 1u, kEmpty);
+        emit_result(job, qi, bkey, skey);
+    }
+}
+
 // Atomic mode, jobs with an EMPTY train set only (no sweep workgroup exists that could finalize them):
 // the reference leaves best_i uninitialised there (CUDAK2NN.cu:54,75); defined here as "no match".
 __global__ __launch_bounds__(256) void k2nn_nomatch_kernel(const K2nnJobList jobs)
@@ -331,14 +533,16 @@ __global__ __launch_bounds__(kMergeQ * kMergeGroups) void k2nn_merge_kernel(cons
     if (job.second_out) job.second_out[qi] = (uint16_t)min(a.second_v, 65535);
 }
 
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map)
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map, int formulation)
 {
+    const bool mx = formulation != K2NN_POPCOUNT;
+    const uint32_t qpb = mx ? kMxQPerBlock : kQPerBlock;
     K2nnPlan plan{0, true};
     for (int j = 0; j < njobs; ++j)
         if (jobs[j].nt > kIdxMask + 1u) plan.atomic_merge = false;
     uint32_t total_qblocks = 0;
     for (int j = 0; j < njobs; ++j) {
-        jobs[j].qblocks = (jobs[j].nq + kQPerBlock - 1) / kQPerBlock;
+        jobs[j].qblocks = (jobs[j].nq + qpb - 1) / qpb;
         total_qblocks += jobs[j].qblocks;
     }
     if (total_qblocks == 0) total_qblocks = 1;
@@ -348,14 +552,22 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map)
     for (int j = 0; j < njobs; ++j) {
         K2nnJobDev& jb = jobs[j];
         uint32_t splits = want;
-        const uint32_t min_per = 16u * kWaves;                              // >= 16 train vectors per wave
+        // popcount: >= 16 train vectors per wave; matrix: >= 2 tiles of 32 per workgroup
+        const uint32_t min_per = mx ? 64u : 16u * kWaves;
         const uint32_t max_splits = jb.nt / min_per > 0 ? jb.nt / min_per : 1u;
         if (splits > max_splits) splits = max_splits;
-        // a multiple of 8 splits pins train split s to XCD s & 7 (see the sweep kernel)
+        // a multiple of 8 splits pins train split s to XCD s & 7 (see the sweep kernels)
         if (xcd_map && splits >= 8u) splits = (splits + 4u) / 8u * 8u > max_splits ? splits / 8u * 8u : (splits + 4u) / 8u * 8u;
         uint32_t per = jb.nt ? (jb.nt + splits - 1) / splits : 1u;
+        if (mx) {
+            per = (per + 31u) & ~31u;                                     // whole tiles of 32 train rows
+            if (per > kMxMaxSplit) per = kMxMaxSplit;                     // 13-bit index inside a split (in the accumulator)
+        }
         if (per > kIdxMask + 1u) per = kIdxMask + 1u;                     // index field is 22 bits
         splits = jb.nt ? (jb.nt + per - 1) / per : 1u;
+        // rounding `per` up to whole tiles can leave a split count that is not a multiple of 8: pad it with empty
+        // trailing splits (their workgroups only take part in the arrival count) to keep the XCD pinning
+        if (mx && xcd_map && splits >= 8u) splits = (splits + 7u) & ~7u;
         jb.splits = splits;
         jb.t_per_split = per;
         jb.nq_pad = (jb.nq + 63u) & ~63u;
@@ -371,7 +583,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map)
     return plan;
 }
 
-hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream, Profiler* prof)
+hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream, Profiler* prof, int formulation)
 {
     for (int base = 0; base < njobs; base += kK2nnJobsPerLaunch) {
         const int cnt = njobs - base < kK2nnJobsPerLaunch ? njobs - base : kK2nnJobsPerLaunch;
@@ -388,7 +600,10 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
         if (max_nq == 0) continue;
         if (grid_x > 0) {
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, true, stream);
-            hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
+            if (formulation == K2NN_POPCOUNT)
+                hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
+            else
+                hipLaunchKernelGGL(k2nn_sweep_mx_kernel, dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial);
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, false, stream);
         }
         if (list.j[0].atomic_merge) {

@@ -198,6 +198,16 @@ int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, in
 int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs,
                        int njobs, int32_t* d_match, void* stream);
 
+/* Which formulation of the all-pairs sweep a context uses (same results bit for bit, same workspace):
+ * CLC_K2NN_MATRIX (default): bits as +-1 FP4 values on the matrix pipe, exact distances in the fp32 accumulator;
+ * CLC_K2NN_POPCOUNT: xor + popcount on the vector ALU, the literal form of CUDAK2NN.cu:58-66 (kept for A/B timing).
+ * Also settable at context creation through the environment, CLC_K2NN_FORMULATION=matrix|popcount. */
+enum { CLC_K2NN_MATRIX = 0, CLC_K2NN_POPCOUNT = 1 };
+int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation);
+/* Queries per sweep workgroup of the context's formulation: the grain on which a caller that deals query slices out
+ * to several GPUs (clc_match_job.q_offset / nq) should cut them, so that no workgroup is split between two jobs. */
+int clc_k2nn_queries_per_block(const clc_ctx* ctx);
+
 /* The all-pairs loop of GPUMatcher::computeMatches (GPUMatcher.hpp:143-155) on host buffers: uploads
  * each camera's descriptors once (the reference re-uploads both sides for every pair,
  * GPUMatcher.hpp:188-196), sweeps every listed (first, second) pair in one launch group (Q = first,

@@ -9,6 +9,15 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["matrix", "popcount"])
+def k2nn_formulation(request, gpu_ctx):
+    """Every test of this file runs under both formulations of the sweep (coloc_amd/csrc/k2nn.hip): the FP4
+    matrix-pipe kernel (default) and the xor + popcount kernel; both must equal the oracle bit for bit."""
+    gpu_ctx.set_k2nn_formulation(request.param)
+    yield request.param
+    gpu_ctx.set_k2nn_formulation("matrix")
+
+
 @pytest.mark.parametrize("nq,nt,thr", [
     (1, 1, 40), (1, 2, 40), (5, 2, 0), (63, 64, 40), (64, 65, 40), (255, 257, 60), (256, 256, 40),
     (257, 1000, 40), (511, 513, 40), (512, 31, 40), (513, 33, 40), (1000, 1, 40), (3000, 2500, 60),
@@ -97,12 +106,13 @@ def test_full_size_properties(gpu_ctx, oracle):
     assert np.array_equal(perm[m2[acc]], m1[acc])
 
 
-def test_train_set_beyond_22_bit_index_uses_slab_merge(oracle):
+def test_train_set_beyond_22_bit_index_uses_slab_merge(oracle, k2nn_formulation):
     """nt > 2^22: the global train index no longer fits the key, so the sweep writes per-split slabs and
     the ordered merge kernel folds them.  Planted duplicates straddle split borders."""
     from coloc_amd import Context
     nt, nq = (1 << 22) + 4099, 96
     ctx = Context(device=0, width=160, height=120, maxkp=nt, detector=False)
+    ctx.set_k2nn_formulation(k2nn_formulation)
     rng = np.random.default_rng(12)
     T = rng.integers(0, 256, size=(nt, 64), dtype=np.uint8)
     Q = rng.integers(0, 256, size=(nq, 64), dtype=np.uint8)
@@ -144,10 +154,11 @@ def test_workspace_rearms_across_changing_shapes(gpu_ctx, oracle):
 
 
 def test_random_shapes_stress(gpu_ctx, oracle):
-    """150 random (nq, nt, threshold) shapes -- sizes around the 128-query block, the 16-vectors-per-wave and the
-    multiple-of-8 split boundaries, with planted near-duplicates and exact duplicates -- against the oracle."""
+    """150 random (nq, nt, threshold) shapes -- sizes around the 128- / 256-query blocks, the 32-row train tiles, the
+    16-vectors-per-wave and the multiple-of-8 split boundaries, with planted near-duplicates and exact duplicates --
+    against the oracle."""
     rng = np.random.default_rng(2026)
-    edges = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025]
+    edges = [1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025]
     for it in range(150):
         nq = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, 3500))
         nt = int(rng.choice(edges)) if rng.random() < 0.4 else int(rng.integers(1, 3500))
@@ -176,3 +187,49 @@ def test_map_tracking_on_device_equals_host_path(gpu_ctx, oracle):
     gpu_ctx.match_map_dev(d_q.data_ptr(), Q.shape[0], 60, d_m.data_ptr())
     gpu_ctx.sync()
     assert np.array_equal(d_m.cpu().numpy(), want)
+
+
+def test_complement_rows_distance_512(gpu_ctx, oracle):
+    """Distance 512 (a query that is the bitwise complement of a train row) is the largest key the matrix form has to
+    carry exactly; one-row train sets make it the best match."""
+    T = synth.random_descriptors(40, seed=5)
+    Q = (~T[:8]).copy()
+    for nt in (1, 2, 33, 40):
+        m, b, s = gpu_ctx.match_2nn(Q, T[:nt], 0, want_dist=True)
+        mo, bo, so = oracle.k2nn(Q, T[:nt], 0, want_dist=True)
+        assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so), nt
+    assert gpu_ctx.match_2nn(Q[:1], T[:1], 0, want_dist=True)[1][0] == 512
+
+
+def test_repeated_full_size_sweeps_rearm(gpu_ctx, oracle):
+    """Bounded soak (tools/soak_k2nn.py in small): 12 back-to-back 10k x 10k sweeps on one context, each with fresh
+    data, each equal to the oracle -- the self re-arming rows / arrival counters and the in-launch finalize ordering."""
+    for rep in range(12):
+        Q, T = synth.planted_descriptors(10000, 10000, seed=9000 + rep)
+        m, b, s = gpu_ctx.match_2nn(Q, T, 40, want_dist=True)
+        mo, bo, so = oracle.k2nn(Q, T, 40, want_dist=True)
+        assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so), rep
+
+
+def test_two_contexts_two_streams_concurrently(oracle, k2nn_formulation):
+    """Two contexts (each with its own stream and workspace) sweep at the same time on one GPU; both must equal the
+    oracle.  One context per concurrently running stream is the documented rule (include/coloc_hip.h)."""
+    import torch
+    from coloc_amd import Context
+    ctxs = [Context(device=0, width=160, height=120, maxkp=12000, detector=False) for _ in range(2)]
+    for c in ctxs:
+        c.set_k2nn_formulation(k2nn_formulation)
+    data = [synth.planted_descriptors(6000 + 500 * i, 9000 - 700 * i, seed=600 + i) for i in range(2)]
+    dq = [torch.from_numpy(q).cuda() for q, _ in data]
+    dt = [torch.from_numpy(t).cuda() for _, t in data]
+    dm = [torch.full((q.shape[0],), -7, dtype=torch.int32, device="cuda:0") for q, _ in data]
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for i, c in enumerate(ctxs):
+            c.match_2nn_dev(dq[i].data_ptr(), data[i][0].shape[0], dt[i].data_ptr(), data[i][1].shape[0], 40, dm[i].data_ptr())
+    for c in ctxs:
+        c.sync()
+    for i in range(2):
+        assert np.array_equal(dm[i].cpu().numpy(), oracle.k2nn(data[i][0], data[i][1], 40))
+    for c in ctxs:
+        c.close()
