@@ -137,6 +137,28 @@ void orc_pnp_score(const double* err, int H, int N, double thr2, int32_t* count_
  * from its published definition): e = (x2^T F x1)^2 (1/|(F x1)_xy|^2 + 1/|(F^T x2)_xy|^2) / 4. */
 void orc_epipolar_residuals(const double* F, int H, const double* x1, const double* x2, int N, double* err_out);
 
+/* ---- a-contrario RANSAC (oracle/clc_oracle_acr.c; include/coloc/Localizer.hpp:82-93, RobustMatcher.hpp:153-171) ---- */
+
+/* minimal solver callback: `sample` holds the m data indices (3 for kind 0, 5 for kind 1); writes up to 4 (10) models of
+ * 12 (18) doubles -- [R|t] row-major, resp. {F (9), E (9)} -- in solver order and returns how many */
+typedef int (*orc_acr_fit_fn)(void* user, const uint32_t* sample, double* models_out);
+
+/* kind 0: resection, a = X (N x 3), b = x (N x 2 pixels), K1 = intrinsics (9, row-major);
+ * kind 1: essential, a = x1, b = x2 (N x 2 pixels), img_w x img_h = size of image 2 (logalpha0).
+ * precision = +inf: pure a-contrario mode (what the reference passes).  Outputs: the model, the inliers in ascending
+ * residual order (capacity N), the precision found (pixels for kind 0), the minimum log10 NFA, the iteration that
+ * produced the model and the number of iterations run.  Returns 1 if a meaningful model (NFA < 0) was found. */
+int orc_acransac(int kind, const double* a, const double* b, int n, const double* K1, int img_w, int img_h,
+                 int max_iteration, uint64_t seed, double precision, int use_libm, orc_acr_fit_fn fit, void* user,
+                 double* model_out, uint32_t* inliers_out, int* n_inliers_out, double* error_max_out, double* min_nfa_out,
+                 int32_t* best_iter_out, int32_t* iterations_run_out);
+/* log10 C(n, k) and log10 C(k, m) float tables, k = 0..n */
+void orc_acr_tables(int n, int m, int use_libm, float* logc_n, float* logc_k);
+/* min_k NFA(k) of one model given its residuals (kernel units); *k_out = the minimising k */
+double orc_acr_best_nfa(const double* err, int n, int m, int max_models, double logalpha0, double mult, int use_libm, int* k_out);
+double orc_acr_log10(double x);
+void orc_acr_sample(uint64_t seed, uint32_t iter, uint32_t n_index, int m, uint32_t* pos);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,6 +166,61 @@ class Oracle:
         return cnt, cost
 
 
+    # -- a-contrario RANSAC
+    def acr_log10(self, x):
+        self.lib.orc_acr_log10.restype = C.c_double
+        return float(self.lib.orc_acr_log10(C.c_double(float(x))))
+
+    def acr_sample(self, seed, it, n_index, m):
+        pos = (C.c_uint32 * 8)()
+        self.lib.orc_acr_sample(C.c_uint64(int(seed)), C.c_uint32(int(it)), C.c_uint32(int(n_index)), C.c_int(m), pos)
+        return [int(pos[j]) for j in range(m)]
+
+    def acr_tables(self, n, m, use_libm=False):
+        a = np.zeros(n + 1, dtype=np.float32); b = np.zeros(n + 1, dtype=np.float32)
+        self.lib.orc_acr_tables(C.c_int(n), C.c_int(m), C.c_int(1 if use_libm else 0), _ptr(a), _ptr(b))
+        return a, b
+
+    def acr_best_nfa(self, err, m, max_models, logalpha0, mult, use_libm=False):
+        err = np.ascontiguousarray(err, dtype=np.float64)
+        k = C.c_int()
+        self.lib.orc_acr_best_nfa.restype = C.c_double
+        v = self.lib.orc_acr_best_nfa(_ptr(err), C.c_int(err.shape[0]), C.c_int(m), C.c_int(max_models), C.c_double(logalpha0),
+                                      C.c_double(mult), C.c_int(1 if use_libm else 0), C.byref(k))
+        return float(v), int(k.value)
+
+    def acransac(self, kind, a, b, K1, fit, max_iteration=256, seed=1, precision=float("inf"), use_libm=False, img_wh=(0, 0)):
+        """Sequential AC-RANSAC.  kind 0: a = X (N,3), b = x (N,2); kind 1: a = x1, b = x2.  `fit(sample) -> array
+        (n_models, 12 | 18)` is the minimal solver (valid models only, solver order).  Returns a dict."""
+        a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
+        K1 = np.ascontiguousarray(K1, dtype=np.float64).reshape(9)
+        n = a.shape[0]
+        md, m = (12, 3) if kind == 0 else (18, 5)
+        FIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double))
+        calls = []
+
+        def _fit(user, sample, out):
+            smp = [int(sample[j]) for j in range(m)]
+            calls.append(smp)
+            models = np.ascontiguousarray(fit(smp), dtype=np.float64).reshape(-1, md)
+            for k in range(models.shape[0]):
+                for e in range(md):
+                    out[k * md + e] = models[k, e]
+            return int(models.shape[0])
+
+        cb = FIT(_fit)
+        model = np.zeros(md); inl = np.zeros(max(n, 1), dtype=np.uint32)
+        n_inl, best_it, its = C.c_int(), C.c_int32(), C.c_int32()
+        emax, nfa = C.c_double(), C.c_double()
+        self.lib.orc_acransac.restype = C.c_int
+        found = self.lib.orc_acransac(C.c_int(kind), _ptr(a), _ptr(b), C.c_int(n), _ptr(K1), C.c_int(int(img_wh[0])), C.c_int(int(img_wh[1])),
+                                      C.c_int(int(max_iteration)), C.c_uint64(int(seed)), C.c_double(float(precision)),
+                                      C.c_int(1 if use_libm else 0), cb, None, _ptr(model), _ptr(inl), C.byref(n_inl), C.byref(emax),
+                                      C.byref(nfa), C.byref(best_it), C.byref(its))
+        return dict(found=bool(found), model=model, inliers=inl[:n_inl.value].copy(), error_max=emax.value, min_nfa=nfa.value,
+                    best_iter=best_it.value, iterations=its.value, samples=calls)
+
+
 class RefFeeder:
     """The reference's own KFAST.h / FeatureAngle.h, compiled into oracle/_ref/ (build container)."""
 
