@@ -46,7 +46,7 @@ EXPORTS = [
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
-    "clc_k2nn_queries_per_block",
+    "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -135,6 +135,10 @@ def load_library():
     lib.clc_profile_reset.argtypes = [vp]
     lib.clc_profile_read.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(ci)]
     lib.clc_kernel_name.restype = C.c_char_p
+    dp, ip = C.POINTER(C.c_double), C.POINTER(ci)
+    lib.clc_pnp_acransac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, vp, vp, vp, ip, dp, dp, ip]
+    lib.clc_pnp_localize_ac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, vp, ip, dp, dp]
+    lib.clc_essential_acransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, ip, dp, dp, ip]
     lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
     lib.clc_k2nn_queries_per_block.argtypes = [vp]
     _lib = lib
@@ -426,6 +430,48 @@ class Context:
         self._chk(self.lib.clc_pnp_localize(self.h, _p(X), _p(x), X.shape[0], _p(K), _p(samples), int(n_samples), int(seed),
                                             float(thr2), float(huber_a), _p(Rt), _p(cov), _p(mask), C.byref(n), C.byref(rmse)))
         return (Rt.reshape(3, 4) if n.value > 0 else None), cov.reshape(6, 6), mask.astype(bool), rmse.value
+
+    def pnp_acransac(self, X, x, K, max_iteration=256, seed=1, precision=float("inf"), refine=False, huber_a=16.0):
+        """A-contrario RANSAC pose (what the reference runs).  Returns a dict: Rt (3,4) or None, mask, inliers (ascending
+        residual order), error_max (pixels), min_nfa, iterations [, cov, rmse with refine=True]."""
+        X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3)
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        n = X.shape[0]
+        Rt = np.zeros(12); mask = np.zeros(max(n, 1), dtype=np.uint8); inl = np.zeros(max(n, 1), dtype=np.int32)
+        ni, its = C.c_int(), C.c_int()
+        emax, nfa, rmse = C.c_double(), C.c_double(), C.c_double()
+        out = {}
+        if refine:
+            cov = np.zeros(36)
+            self._chk(self.lib.clc_pnp_localize_ac(self.h, _p(X), _p(x), n, _p(K), int(max_iteration), int(seed), float(precision),
+                                                   float(huber_a), _p(Rt), _p(cov), _p(mask), _p(inl), C.byref(ni), C.byref(emax),
+                                                   C.byref(rmse)))
+            out.update(cov=cov.reshape(6, 6), rmse=rmse.value)
+        else:
+            self._chk(self.lib.clc_pnp_acransac(self.h, _p(X), _p(x), n, _p(K), int(max_iteration), int(seed), float(precision),
+                                                _p(Rt), _p(mask), _p(inl), C.byref(ni), C.byref(emax), C.byref(nfa), C.byref(its)))
+            out.update(min_nfa=nfa.value, iterations=its.value)
+        out.update(Rt=Rt.reshape(3, 4) if ni.value > 0 else None, mask=mask[:n].astype(bool), inliers=inl[:ni.value].copy(),
+                   error_max=emax.value)
+        return out
+
+    def essential_acransac(self, x1, x2, K1, K2, img_wh, max_iteration=256, seed=1, precision=float("inf")):
+        """A-contrario five-point RANSAC (RobustMatcher::filterEssential).  Returns a dict: E, F (3,3) or None, mask, inliers, ..."""
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        K1 = np.ascontiguousarray(K1, dtype=np.float64).reshape(9); K2 = np.ascontiguousarray(K2, dtype=np.float64).reshape(9)
+        n = x1.shape[0]
+        E = np.zeros(9); F = np.zeros(9)
+        mask = np.zeros(max(n, 1), dtype=np.uint8); inl = np.zeros(max(n, 1), dtype=np.int32)
+        ni, its = C.c_int(), C.c_int()
+        emax, nfa = C.c_double(), C.c_double()
+        self._chk(self.lib.clc_essential_acransac(self.h, _p(x1), _p(x2), n, _p(K1), _p(K2), int(img_wh[0]), int(img_wh[1]),
+                                                  int(max_iteration), int(seed), float(precision), _p(E), _p(F), _p(mask), _p(inl),
+                                                  C.byref(ni), C.byref(emax), C.byref(nfa), C.byref(its)))
+        ok = ni.value > 0
+        return dict(E=E.reshape(3, 3) if ok else None, F=F.reshape(3, 3) if ok else None, mask=mask[:n].astype(bool),
+                    inliers=inl[:ni.value].copy(), error_max=emax.value, min_nfa=nfa.value, iterations=its.value)
 
     def pnp_refine(self, X, x, K, Rt0, mask=None, huber_a=16.0, max_iter=50):
         """LM refinement of one pose: returns (Rt (3,4), cov (6,6), rmse, iterations)."""

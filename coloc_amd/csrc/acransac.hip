@@ -1,0 +1,320 @@
+// acransac.hip -- a-contrario RANSAC (AC-RANSAC) on gfx950: the model selection OpenMVG runs for the reference's pose
+// and two-view steps,
+//     SfM_Localizer::Localize(P3P_KE_CVPR17, ..., {error_max = +inf, max_iteration = 256})   include/coloc/Localizer.hpp:82-93
+//     ACRANSAC(ACKernelAdaptorEssential<FivePointSolver, SymmetricEpipolarDistanceError>, ...)  include/coloc/RobustMatcher.hpp:153-171
+// restated from the published algorithm (Moisan, Moulon, Monasse, IPOL 2012; see oracle/clc_oracle_acr.c for the
+// sequential form and what is unpinned).  Per model: residuals over ALL data, sorted with their indices, NFA(k) over
+// the k smallest, the model's value = min_k NFA(k); the run keeps the model with the lowest value, and once a
+// meaningful one (NFA < 0) exists the remaining 10 % reserve of iterations sample among its inliers.
+//
+// GPU shape.  The sequential loop evaluates <= 4 (10) models per iteration, one after the other, each with an O(n log n)
+// sort on one CPU thread.  Here a ROUND evaluates a batch of B iterations at once:
+//   solve   : the existing minimal solvers (p3p_kernel: one problem per four lanes; fivept_kernel: one per wave) on the
+//             batch's samples -- samples are a pure function of (seed, iteration, index set), see clc_acr.h;
+//   nfa     : one workgroup per model slot: residuals straight into LDS, bitonic sort of (residual bits, index) in LDS,
+//             NFA(k) for every k in parallel, min-reduction -> {nfa, k, e_k} and the sorted index list;
+//   select  : one workgroup replays the SEQUENTIAL semantics over the batch in iteration / solver order (strict '<'
+//             improvements, the phase-switch rule), stops at the first iteration that changes the index set -- the
+//             iterations after it were sampled speculatively from the old set and are discarded --, updates the device
+//             state, draws the next batch's samples and mirrors the state into pinned host memory.
+// The host only reads that mirror (one stream synchronisation per round) to learn whether another round is needed:
+// typically one round to find the first meaningful model, one or two for the reserve.  Results are identical to the
+// sequential oracle: same samples, bit-identical residuals (same operation order, no FMA contraction), a total order on
+// (residual, index), and the same portable log10 in the NFA terms.
+#include "clc_internal.h"
+#include "clc_acr.h"
+
+namespace clc {
+
+struct AcrHyp {            // per model slot, written by the nfa kernel
+    double nfa;            // min_k NFA(k); +inf for an empty slot
+    double e_k;            // the k-th smallest residual (kernel units)
+    int32_t k;             // minimising k
+    int32_t n_le;          // residuals <= max_threshold (upper-bound mode gate)
+};
+
+// ---- nfa: one workgroup per model slot ---------------------------------------------------------------------------
+__device__ __forceinline__ double acr_err_resection(const double* __restrict__ P, const double* __restrict__ K, const double s,
+                                                    const double Xw, const double Yw, const double Zw, const double uo, const double vo)
+{
+    // ACKernelAdaptorResection_Intrinsics::Errors: (pixel residual * 1 / focal).squaredNorm(); operation order of
+    // oracle/clc_oracle_acr.c acr_errors
+    const double xc = ((P[0] * Xw + P[1] * Yw) + P[2] * Zw) + P[3];
+    const double yc = ((P[4] * Xw + P[5] * Yw) + P[6] * Zw) + P[7];
+    const double zc = ((P[8] * Xw + P[9] * Yw) + P[10] * Zw) + P[11];
+    const double u = (K[0] * xc + K[1] * yc) + K[2] * zc;
+    const double v = (K[3] * xc + K[4] * yc) + K[5] * zc;
+    const double w = (K[6] * xc + K[7] * yc) + K[8] * zc;
+    const double du = (uo - u / w) * s;
+    const double dv = (vo - v / w) * s;
+    return du * du + dv * dv;
+}
+
+__device__ __forceinline__ double acr_err_epipolar(const double* __restrict__ f, const double u1, const double v1, const double u2, const double v2)
+{
+    const double a0 = (f[0] * u1 + f[1] * v1) + f[2];
+    const double a1 = (f[3] * u1 + f[4] * v1) + f[5];
+    const double a2 = (f[6] * u1 + f[7] * v1) + f[8];
+    const double b0 = (f[0] * u2 + f[3] * v2) + f[6];
+    const double b1 = (f[1] * u2 + f[4] * v2) + f[7];
+    const double d = (u2 * a0 + v2 * a1) + a2;
+    return (d * d) * (1.0 / (a0 * a0 + a1 * a1) + 1.0 / (b0 * b0 + b1 * b1)) / 4.0;
+}
+
+__global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, const int P /* power of two >= n */,
+                                                       const double* __restrict__ models, AcrHyp* __restrict__ hyp,
+                                                       uint32_t* __restrict__ sorted_idx)
+{
+    extern __shared__ unsigned char acr_lds[];
+    uint64_t* key = reinterpret_cast<uint64_t*>(acr_lds);               // P residuals as bits (>= 0: bit order == value order)
+    uint32_t* idx = reinterpret_cast<uint32_t*>(acr_lds + (size_t)P * 8);
+    __shared__ double s_nfa[1024 / 64];
+    __shared__ int s_k[1024 / 64], s_cnt[1024 / 64];
+    const int slot = blockIdx.x, tid = threadIdx.x, T = blockDim.x, n = pb.n;
+    const double* model = models + (size_t)slot * pb.model_doubles;
+    // an empty slot (the solver marks it with NaNs) never improves anything
+    if (model[0] != model[0]) {
+        if (tid == 0) { hyp[slot].nfa = __longlong_as_double(0x7ff0000000000000LL); hyp[slot].e_k = 0.0; hyp[slot].k = 0; hyp[slot].n_le = 0; }
+        return;
+    }
+    int cnt = 0;
+    for (int i = tid; i < P; i += T) {
+        uint64_t kb = 0x7ff0000000000000ull;                             // padding: +inf, behind every real residual
+        uint32_t ib = 0xFFFFFFFFu;
+        if (i < n) {
+            const double e = pb.kind == 0
+                ? acr_err_resection(model, pb.K1, pb.norm, pb.a[3 * i], pb.a[3 * i + 1], pb.a[3 * i + 2], pb.b[2 * i], pb.b[2 * i + 1])
+                : acr_err_epipolar(model, pb.a[2 * i], pb.a[2 * i + 1], pb.b[2 * i], pb.b[2 * i + 1]);
+            kb = (uint64_t)__double_as_longlong(e);
+            ib = (uint32_t)i;
+            cnt += e <= pb.max_threshold ? 1 : 0;
+        }
+        key[i] = kb;
+        idx[i] = ib;
+    }
+    __syncthreads();
+    // bitonic sort, ascending in (residual, index): std::sort on pair<double, uint32_t>
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P >> 1); t += T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const uint64_t ka = key[i], kb = key[l];
+                const uint32_t ia = idx[i], ib = idx[l];
+                const bool gt = ka > kb || (ka == kb && ia > ib);
+                if (gt == ((i & k) == 0)) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    // NFA(k), k = m + 1 .. n while e_(k) <= max_threshold; strict '<' keeps the first k
+    double best = __longlong_as_double(0x7ff0000000000000LL);
+    int bk = pb.m;
+    for (int kk = pb.m + 1 + tid; kk <= n; kk += T) {
+        const double e = __longlong_as_double((long long)key[kk - 1]);
+        if (!(e <= pb.max_threshold)) break;                              // sorted: nothing further qualifies either
+        const double v = clc_acr_nfa(pb.loge0, pb.logalpha0, pb.mult, e, kk, pb.m, pb.logc_n[kk], pb.logc_k[kk]);
+        if (v < best) { best = v; bk = kk; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(best, off);
+        const int ok = __shfl_xor(bk, off);
+        if (ov < best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+        cnt += __shfl_xor(cnt, off);
+    }
+    if ((tid & 63) == 0) { s_nfa[tid >> 6] = best; s_k[tid >> 6] = bk; s_cnt[tid >> 6] = cnt; }
+    uint32_t* out_idx = sorted_idx + (size_t)slot * n;
+    for (int i = tid; i < n; i += T) out_idx[i] = idx[i];
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+        for (int w = 0; w < (T + 63) / 64; ++w) {
+            if (s_nfa[w] < best || (s_nfa[w] == best && s_k[w] < bk)) { best = s_nfa[w]; bk = s_k[w]; }
+            total += s_cnt[w];
+        }
+        hyp[slot].nfa = best;
+        hyp[slot].k = bk;
+        hyp[slot].e_k = bk > pb.m ? __longlong_as_double((long long)key[bk - 1]) : 0.0;
+        hyp[slot].n_le = total;
+    }
+}
+
+// ---- select: the sequential semantics over one batch -------------------------------------------------------------
+// Also draws the samples of the NEXT batch (from the index set as it stands after this one).
+__device__ __forceinline__ void acr_draw_samples(const uint64_t seed, const int m, const int iter, const int n_iter, const int n_index,
+                                                 const int index_all, const uint32_t* __restrict__ index_set,
+                                                 int32_t* __restrict__ samples, const int tid, const int T)
+{
+    const int remaining = n_iter - iter;
+    const int nb = remaining < kAcrMaxBatch ? remaining : kAcrMaxBatch;
+    for (int it = tid; it < nb; it += T) {
+        uint32_t pos[8];
+        clc_acr_sample(seed, (uint32_t)(iter + it), (uint32_t)n_index, m, pos);
+        for (int j = 0; j < m; ++j) samples[it * m + j] = (int32_t)(index_all ? pos[j] : index_set[pos[j]]);
+    }
+}
+
+__global__ __launch_bounds__(256) void acr_init_kernel(const AcrProblem pb, const int max_iteration, AcrState* __restrict__ state,
+                                                       int32_t* __restrict__ samples, AcrState* __restrict__ h_state)
+{
+    __shared__ AcrState s;
+    if (threadIdx.x == 0) {
+        s.min_nfa = __longlong_as_double(0x7ff0000000000000LL);
+        s.error_max = s.min_nfa;
+        for (int e = 0; e < 18; ++e) s.model[e] = 0.0;
+        s.n_inliers = 0;
+        s.best_iter = -1;
+        s.iter = 0;
+        s.reserve = max_iteration / 10;
+        s.n_iter = max_iteration - s.reserve;
+        s.n_index = pb.n;
+        s.index_all = 1;
+        s.ac_mode = pb.max_threshold == __longlong_as_double(0x7ff0000000000000LL) ? 1 : 0;
+        s.rounds = 0;
+        s.last_batch = 0;
+        *state = s;
+        if (h_state) *h_state = s;
+    }
+    __syncthreads();
+    acr_draw_samples(pb.seed, pb.m, 0, max_iteration - max_iteration / 10, pb.n, 1, nullptr, samples, threadIdx.x, blockDim.x);
+}
+
+__global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, const int B, const double* __restrict__ models,
+                                                         const AcrHyp* __restrict__ hyp, const uint32_t* __restrict__ sorted_idx,
+                                                         AcrState* __restrict__ state, uint32_t* __restrict__ best_inliers,
+                                                         uint32_t* __restrict__ index_set, int32_t* __restrict__ samples,
+                                                         AcrState* __restrict__ h_state)
+{
+    __shared__ AcrState s;
+    __shared__ int s_best_h, s_copy_index;
+    const int tid = threadIdx.x, T = blockDim.x;
+    if (tid == 0) {
+        s = *state;
+        int best_h = -1, copy_index = 0, consumed = B;
+        for (int it = 0; it < B; ++it) {
+            bool better = false;
+            for (int k = 0; k < pb.max_models; ++k) {
+                const int h = it * pb.max_models + k;
+                const AcrHyp hy = hyp[h];
+                if (!s.ac_mode) { if ((double)hy.n_le > 2.5 * (double)pb.m) s.ac_mode = 1; }
+                if (!s.ac_mode) continue;
+                if (hy.nfa < s.min_nfa) {
+                    better = true;
+                    s.min_nfa = hy.nfa;
+                    s.n_inliers = hy.k;
+                    s.error_max = hy.e_k;
+                    s.best_iter = s.iter + it;
+                    best_h = h;
+                }
+            }
+            const int cur = s.iter + it;
+            if ((better && s.min_nfa < 0.0) || (cur + 1 == s.n_iter && s.reserve)) {
+                if (s.n_inliers == 0) { s.n_iter++; s.reserve--; }
+                else {
+                    copy_index = 1;
+                    s.n_index = s.n_inliers;
+                    s.index_all = 0;
+                    if (s.reserve) { s.n_iter = cur + 1 + s.reserve; s.reserve = 0; }
+                }
+                consumed = it + 1;
+                break;
+            }
+        }
+        s.iter += consumed;
+        s.rounds += 1;
+        s.last_batch = consumed;
+        if (best_h >= 0)
+            for (int e = 0; e < pb.model_doubles; ++e) s.model[e] = models[(size_t)best_h * pb.model_doubles + e];
+        s_best_h = best_h;
+        s_copy_index = copy_index;
+    }
+    __syncthreads();
+    const int best_h = s_best_h, n_inl = s.n_inliers;
+    if (best_h >= 0) {
+        const uint32_t* src = sorted_idx + (size_t)best_h * pb.n;
+        for (int i = tid; i < n_inl; i += T) best_inliers[i] = src[i];
+    }
+    __syncthreads();
+    if (s_copy_index)                                   // vec_index = vec_inliers (ascending residual order, as the sort left them)
+        for (int i = tid; i < n_inl; i += T) index_set[i] = best_inliers[i];
+    __syncthreads();
+    __threadfence_block();
+    const int nx_iter = s.iter, nx_n_iter = s.n_iter, nx_n_index = s.n_index, nx_all = s.index_all;
+    acr_draw_samples(pb.seed, pb.m, nx_iter, nx_n_iter, nx_n_index, nx_all, index_set, samples, tid, T);
+    if (tid == 0) { *state = s; if (h_state) *h_state = s; }
+}
+
+// ---- finish: mask, inlier list and the result record, straight into pinned host memory ---------------------------
+__global__ __launch_bounds__(256) void acr_finish_kernel(const AcrProblem pb, const AcrState* __restrict__ state,
+                                                         const uint32_t* __restrict__ best_inliers, uint8_t* __restrict__ d_mask,
+                                                         AcrResult* __restrict__ d_res, uint8_t* __restrict__ h_mask,
+                                                         int32_t* __restrict__ h_inliers, AcrResult* __restrict__ h_res)
+{
+    const AcrState s = *state;
+    const bool ok = s.min_nfa < 0.0 && s.n_inliers > 0;
+    const int n_inl = ok ? s.n_inliers : 0;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, G = gridDim.x * blockDim.x;
+    // single workgroup: the mask is zeroed, then the inliers are marked
+    for (int i = gid; i < pb.n; i += G) { d_mask[i] = 0; if (h_mask) h_mask[i] = 0; }
+    __syncthreads();
+    for (int i = gid; i < n_inl; i += G) {
+        const uint32_t p = best_inliers[i];
+        d_mask[p] = 1;
+        if (h_mask) h_mask[p] = 1;
+        if (h_inliers) h_inliers[i] = (int32_t)p;
+    }
+    if (gid == 0) {
+        AcrResult r;
+        for (int e = 0; e < 18; ++e) r.model[e] = ok ? s.model[e] : 0.0;
+        r.min_nfa = s.min_nfa;
+        // unormalizeError: resection sqrt(e) / N1(0,0) -> pixels; essential: the squared pixel distance as it is
+        r.error_max = !ok ? 0.0 : (pb.kind == 0 ? sqrt(s.error_max) / pb.norm : s.error_max);
+        r.n_inliers = n_inl;
+        r.valid = ok ? s.best_iter : -1;
+        r.iterations = s.iter;
+        r.rounds = s.rounds;
+        *d_res = r;
+        if (h_res) *h_res = r;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+hipError_t launch_acr_init(const AcrProblem& pb, int max_iteration, AcrState* d_state, int32_t* d_samples, AcrState* h_state, hipStream_t stream)
+{
+    hipLaunchKernelGGL(acr_init_kernel, dim3(1), dim3(256), 0, stream, pb, max_iteration, d_state, d_samples, h_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_acr_round(const AcrProblem& pb, int B, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
+                            uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, AcrState* h_state, hipStream_t stream)
+{
+    int P = 64;
+    while (P < pb.n) P <<= 1;
+    int T = P / 2;
+    if (T < 64) T = 64;
+    if (T > 1024) T = 1024;
+    const size_t lds = (size_t)P * 12;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)acr_nfa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcrMaxLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(acr_nfa_kernel, dim3(B * pb.max_models), dim3(T), lds, stream, pb, P, d_models, d_hyp, d_sorted);
+    hipLaunchKernelGGL(acr_select_kernel, dim3(1), dim3(256), 0, stream, pb, B, d_models, (const AcrHyp*)d_hyp, (const uint32_t*)d_sorted,
+                       d_state, d_best_inliers, d_index_set, d_samples, h_state);
+    return hipGetLastError();
+}
+
+hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
+                             uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream)
+{
+    hipLaunchKernelGGL(acr_finish_kernel, dim3(1), dim3(256), 0, stream, pb, d_state, d_best_inliers, d_mask, d_res, h_mask, h_inliers, h_res);
+    return hipGetLastError();
+}
+
+size_t acr_hyp_bytes() { return sizeof(AcrHyp); }
+
+} // namespace clc

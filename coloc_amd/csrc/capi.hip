@@ -8,6 +8,7 @@
 // stream per context, every HIP status checked and mapped to an int code.
 #include "clc_internal.h"
 #include "../host/HIPCovIntersection.hpp"
+#include "clc_acr.h"
 
 #include <cmath>
 #include <cstdio>
@@ -1130,6 +1131,217 @@ int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const
     if (!h_samples || !h_Rt_out) return fail(ctx, CLC_ERR_BAD_ARG, "pnp_p3p: bad argument");
     return pnp_ransac_impl(ctx, h_X, h_x, N, h_K, h_samples, S, 0, 1.0, nullptr, nullptr, nullptr, nullptr, h_Rt_out);
 }
+
+} // extern "C"
+
+/* ---- a-contrario RANSAC ---------------------------------------------------------------------------------------------- */
+
+namespace {
+
+// log10 C(n, k) and log10 C(k, m), k = 0..n, as OpenMVG tabulates them: a FLOAT log10 table, float accumulation
+// (logcombi<float>); the O(n^2) re-summation of the prefix is replaced by the running prefix -- same additions, same order.
+void acr_tables(int n, int m, float* logc_n, float* logc_k)
+{
+    std::vector<float> lg((size_t)n + 2, 0.0f), prefix((size_t)n + 1, 0.0f);
+    for (int k = 1; k <= n + 1; ++k) lg[k] = (float)clc_acr_log10((double)k);
+    for (int i = 1; i <= n; ++i) prefix[i] = prefix[i - 1] + (lg[n - i + 1] - lg[i]);
+    for (int k = 0; k <= n; ++k) {
+        uint32_t kk = (uint32_t)k;
+        if (kk >= (uint32_t)n || kk == 0) { logc_n[k] = 0.0f; continue; }
+        if ((uint32_t)n - kk < kk) kk = (uint32_t)n - kk;
+        logc_n[k] = prefix[kk];
+    }
+    for (int nn = 0; nn <= n; ++nn) {
+        uint32_t kk = (uint32_t)m;
+        float r = 0.0f;
+        if (!(kk >= (uint32_t)nn || kk == 0)) {
+            if ((uint32_t)nn - kk < kk) kk = (uint32_t)nn - kk;
+            for (uint32_t i = 1; i <= kk; ++i) r += lg[nn - i + 1] - lg[i];
+        }
+        logc_k[nn] = r;
+    }
+}
+
+size_t dbl(size_t bytes) { return (bytes + 7) / 8; }
+
+// kind 0: a = X (3 N), b = x (2 N), K1 = intrinsics; kind 1: a = x1, b = x2 (2 N each), K1 / K2, image 2 of img_w x img_h.
+// h_model: 12 doubles [R|t] (kind 0) or {E (9), F (9)} (kind 1).
+int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N, const double* h_K1, const double* h_K2, int img_w,
+             int img_h, int max_iteration, uint64_t seed, double precision, double refine_huber, double* h_model, uint8_t* h_mask,
+             int32_t* h_inliers, int* n_inliers, double* error_max, double* min_nfa, int* iterations, int* rounds, double* h_cov,
+             double* rmse)
+{
+    const int m = kind == 0 ? 3 : 5, M = kind == 0 ? 4 : 10, md = kind == 0 ? 12 : 18, ad = kind == 0 ? 3 : 2;
+    if (!ctx || N < 0 || max_iteration < 0 || !h_K1 || (kind == 1 && !h_K2) || (N > 0 && (!h_a || !h_b)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "acransac: bad argument");
+    if (n_inliers) *n_inliers = 0;
+    if (error_max) *error_max = 0.0;
+    if (min_nfa) *min_nfa = INFINITY;
+    if (iterations) *iterations = 0;
+    if (rounds) *rounds = 0;
+    if (h_mask && N > 0) memset(h_mask, 0, (size_t)N);
+    if (N <= m || max_iteration == 0) return CLC_OK;                       // ACRANSAC: nData <= sizeSample -> (0, 0), no model
+    if (N > kAcrMaxN) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 8192 correspondences per solve");
+    if (max_iteration > 65536) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 65536 iterations");
+    if (kind == 1 && (img_w <= 0 || img_h <= 0)) return fail(ctx, CLC_ERR_BAD_ARG, "acransac: image size needed for the point-to-line model");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    const bool refine = kind == 0 && refine_huber > 0.0;
+    // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k ] uploaded in one copy, then scratch
+    const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1));
+    const size_t samples_d = dbl(sizeof(int32_t) * kAcrMaxBatch * 5);
+    const size_t models_d = (size_t)kAcrMaxBatch * M * md;
+    const size_t hyp_d = dbl(acr_hyp_bytes() * kAcrMaxBatch * M);
+    const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)kAcrMaxBatch * M * N);
+    const size_t idx_d = dbl(sizeof(uint32_t) * (size_t)N);
+    const size_t state_d = dbl(sizeof(AcrState)), res_d = dbl(sizeof(AcrResult)), mask_d = dbl((size_t)N);
+    const size_t ref_d = refine ? dbl(pnp_refine_out_bytes()) : 0;
+    int rc = ensure_pnp(ctx, in_d + samples_d + models_d + hyp_d + sorted_d + 2 * idx_d + state_d + res_d + mask_d + ref_d + 16);
+    if (rc != CLC_OK) return rc;
+    // pinned: [ inputs | state mirror | result | mask | inlier list | refine record ]
+    const size_t inl_d = dbl(sizeof(int32_t) * (size_t)N);
+    rc = ensure_pinned(ctx, (in_d + state_d + res_d + mask_d + inl_d + ref_d) * sizeof(double) + 64);
+    if (rc != CLC_OK) return rc;
+    double* d = ctx->d_pnp;
+    double* d_a = d;                       d += (size_t)ad * N;
+    double* d_b = d;                       d += (size_t)2 * N;
+    double* d_K1 = d;                      d += 16;
+    double* d_K2 = d;                      d += 16;
+    float* d_cn = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
+    float* d_ck = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
+    int32_t* d_samples = (int32_t*)d;      d += samples_d;
+    double* d_models = d;                  d += models_d;
+    AcrHyp* d_hyp = (AcrHyp*)d;            d += hyp_d;
+    uint32_t* d_sorted = (uint32_t*)d;     d += sorted_d;
+    uint32_t* d_best = (uint32_t*)d;       d += idx_d;
+    uint32_t* d_index = (uint32_t*)d;      d += idx_d;
+    AcrState* d_state = (AcrState*)d;      d += state_d;
+    AcrResult* d_res = (AcrResult*)d;      d += res_d;
+    uint8_t* d_mask = (uint8_t*)d;         d += mask_d;
+    double* d_ref = d;
+    double* hp = (double*)ctx->h_pin;
+    memcpy(hp, h_a, sizeof(double) * ad * N);
+    memcpy(hp + (size_t)ad * N, h_b, sizeof(double) * 2 * N);
+    double* hK = hp + (size_t)(ad + 2) * N;
+    memset(hK, 0, sizeof(double) * 32);
+    memcpy(hK, h_K1, sizeof(double) * 9);
+    if (h_K2) memcpy(hK + 16, h_K2, sizeof(double) * 9);
+    float* h_cn = (float*)(hK + 32);
+    float* h_ck = (float*)(hK + 32 + dbl(sizeof(float) * ((size_t)N + 1)));
+    acr_tables(N, m, h_cn, h_ck);
+    AcrState* h_state = (AcrState*)(hp + in_d);
+    AcrResult* h_res = (AcrResult*)(hp + in_d + state_d);
+    uint8_t* p_mask = (uint8_t*)(hp + in_d + state_d + res_d);
+    int32_t* p_inl = (int32_t*)(hp + in_d + state_d + res_d + mask_d);
+    double* p_ref = hp + in_d + state_d + res_d + mask_d + inl_d;
+
+    AcrProblem pb{};
+    pb.kind = kind; pb.n = N; pb.m = m; pb.max_models = M; pb.model_doubles = md;
+    pb.a = d_a; pb.b = d_b; pb.K1 = d_K1; pb.K2 = d_K2; pb.logc_n = d_cn; pb.logc_k = d_ck;
+    pb.loge0 = clc_acr_log10((double)M * (double)(N - m));
+    if (kind == 0) {
+        // ACKernelAdaptorResection_Intrinsics: residuals on the normalised camera plane (x 1 / focal), logalpha0 = log10(pi)
+        pb.logalpha0 = clc_acr_log10(M_PI);
+        pb.mult = 1.0;
+        pb.norm = 1.0 / h_K1[0];
+    } else {
+        // ACKernelAdaptorEssential: point-to-line, logalpha0 = log10(2 D / A * 0.5) of image 2, error^(1/2)
+        const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
+        pb.logalpha0 = clc_acr_log10(2.0 * D / A * .5);
+        pb.mult = 0.5;
+        pb.norm = 1.0;
+    }
+    pb.max_threshold = std::isinf(precision) ? INFINITY : precision * (pb.norm * pb.norm);
+    pb.seed = seed;
+
+    hipStream_t st = ctx->stream;
+    CLC_HIP(ctx, hipMemcpyAsync(ctx->d_pnp, hp, in_d * sizeof(double), hipMemcpyHostToDevice, st));
+    prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
+    CLC_HIP(ctx, launch_acr_init(pb, max_iteration, d_state, d_samples, nullptr, st));
+    int iter = 0, n_iter = max_iteration - max_iteration / 10;
+    int batch = 32;
+    while (iter < n_iter) {
+        int B = n_iter - iter;
+        if (B > batch) B = batch;
+        if (B > kAcrMaxBatch) B = kAcrMaxBatch;
+        if (kind == 0) CLC_HIP(ctx, launch_p3p(d_a, d_b, N, d_K1, d_samples, B, d_models, st));
+        else CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, B, d_models, st));
+        CLC_HIP(ctx, launch_acr_round(pb, B, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_state, st));
+        CLC_HIP(ctx, hipStreamSynchronize(st));
+        const bool event = h_state->last_batch < B || h_state->index_all == 0;
+        iter = h_state->iter;
+        n_iter = h_state->n_iter;
+        // no meaningful model yet: look further ahead per round; afterwards the whole reserve goes in one batch
+        batch = event ? kAcrMaxBatch : (batch * 2 > kAcrMaxBatch ? kAcrMaxBatch : batch * 2);
+    }
+    CLC_HIP(ctx, launch_acr_finish(pb, d_state, d_best, d_mask, d_res, p_mask, p_inl, h_res, st));
+    prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);
+    if (refine)
+        CLC_HIP(ctx, launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50, d_ref, st,
+                                       &ctx->prof, &d_res->valid, p_ref));
+    CLC_HIP(ctx, hipStreamSynchronize(st));
+    const AcrResult r = *h_res;
+    if (h_model) {
+        if (kind == 0) memcpy(h_model, r.model, sizeof(double) * 12);
+        else { memcpy(h_model, r.model + 9, sizeof(double) * 9); memcpy(h_model + 9, r.model, sizeof(double) * 9); }   // slots hold {F, E}
+    }
+    if (h_mask) memcpy(h_mask, p_mask, (size_t)N);
+    if (h_inliers && r.n_inliers > 0) memcpy(h_inliers, p_inl, sizeof(int32_t) * (size_t)r.n_inliers);
+    if (n_inliers) *n_inliers = r.n_inliers;
+    if (error_max) *error_max = r.error_max;
+    if (min_nfa) *min_nfa = r.min_nfa;
+    if (iterations) *iterations = r.iterations;
+    if (rounds) *rounds = r.rounds;
+    if (refine) {
+        struct { double Rt[12]; double cov[36]; double cost; double rmse; int32_t iterations; int32_t n_used; } f;
+        memcpy(&f, p_ref, sizeof f);
+        if (r.n_inliers > 0) {
+            if (h_model) memcpy(h_model, f.Rt, sizeof f.Rt);
+            if (h_cov) memcpy(h_cov, f.cov, sizeof f.cov);
+            if (rmse) *rmse = f.rmse;
+        }
+    }
+    return CLC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int clc_pnp_acransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, int max_iteration, uint64_t seed,
+                     double precision, double* h_Rt, uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers, double* error_max,
+                     double* min_nfa, int* iterations)
+{
+    if (h_Rt) memset(h_Rt, 0, sizeof(double) * 12);
+    return acr_impl(ctx, 0, h_X, h_x, N, h_K, nullptr, 0, 0, max_iteration, seed, precision, -1.0, h_Rt, h_inlier_mask, h_inliers, n_inliers,
+                    error_max, min_nfa, iterations, nullptr, nullptr, nullptr);
+}
+
+int clc_pnp_localize_ac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, int max_iteration, uint64_t seed,
+                        double precision, double huber_a, double* h_Rt, double* h_cov, uint8_t* h_inlier_mask, int32_t* h_inliers,
+                        int* n_inliers, double* error_max, double* rmse)
+{
+    if (h_Rt) memset(h_Rt, 0, sizeof(double) * 12);
+    if (h_cov) memset(h_cov, 0, sizeof(double) * 36);
+    if (rmse) *rmse = 0.0;
+    return acr_impl(ctx, 0, h_X, h_x, N, h_K, nullptr, 0, 0, max_iteration, seed, precision, huber_a > 0.0 ? huber_a : 16.0, h_Rt,
+                    h_inlier_mask, h_inliers, n_inliers, error_max, nullptr, nullptr, nullptr, h_cov, rmse);
+}
+
+int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1, const double* h_K2,
+                           int img_w, int img_h, int max_iteration, uint64_t seed, double precision, double* h_E, double* h_F,
+                           uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers, double* error_max, double* min_nfa, int* iterations)
+{
+    double EF[18] = {};
+    const int rc = acr_impl(ctx, 1, h_x1, h_x2, N, h_K1, h_K2, img_w, img_h, max_iteration, seed, precision, -1.0, EF, h_inlier_mask,
+                            h_inliers, n_inliers, error_max, min_nfa, iterations, nullptr, nullptr, nullptr);
+    if (h_E) memcpy(h_E, EF, sizeof(double) * 9);
+    if (h_F) memcpy(h_F, EF + 9, sizeof(double) * 9);
+    return rc;
+}
+
+} // extern "C"
+
+extern "C" {
 
 int clc_cov_intersection(const double* CA, const double* CB, const double* ca, const double* cb, double* omega,
                          double* cov_fused, double* pos_fused)

@@ -138,5 +138,53 @@ hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const dou
 size_t pnp_result_valid_offset();   // byte offset of the int32 "winning hypothesis" (< 0: none) in the ransac result record
 size_t pnp_refine_out_bytes();
 
+// the minimal solvers alone (pnp.hip), for the a-contrario rounds: S samples -> 4 S pose slots / 10 S {F, E} slots
+hipError_t launch_p3p(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples, int S, double* d_Rt,
+                      hipStream_t stream);
+hipError_t launch_fivept(const double* d_x1, const double* d_x2, int N, const double* d_K1, const double* d_K2, const int32_t* d_samples,
+                         int S, double* d_FE, hipStream_t stream);
+
+// ---- a-contrario RANSAC (acransac.hip) -----------------------------------------------------------------------
+static constexpr int kAcrMaxBatch = 128;           // iterations evaluated per round
+static constexpr int kAcrMaxN = 8192;              // correspondences per solve: (8 + 4) B x 8192 = 96 KB of LDS per model slot
+static constexpr size_t kAcrMaxLds = (size_t)kAcrMaxN * 12;
+struct AcrProblem {        // passed by value to every kernel of a solve
+    int kind;              // 0: resection (P3P, [R|t] models of 12 doubles), 1: essential (five-point, {F, E} models of 18)
+    int n, m, max_models, model_doubles;
+    const double* a;       // X (3 n)  | x1 (2 n)
+    const double* b;       // x (2 n)  | x2 (2 n)
+    const double* K1;      // 9 doubles row-major (+ padding)
+    const double* K2;
+    const float* logc_n;   // log10 C(n, k), k = 0..n
+    const float* logc_k;   // log10 C(k, m)
+    double loge0, logalpha0, mult, max_threshold;
+    double norm;           // resection: 1 / focal (residuals are scaled to the normalised camera plane); essential: 1
+    uint64_t seed;
+};
+struct AcrState {          // device resident; mirrored into pinned host memory after every round
+    double min_nfa, error_max;
+    double model[18];
+    int32_t n_inliers, best_iter;
+    int32_t iter, n_iter, reserve;
+    int32_t n_index, index_all, ac_mode;
+    int32_t rounds, last_batch;
+};
+struct AcrResult {
+    double model[18];
+    double min_nfa;
+    double error_max;      // un-normalised: pixels (resection), squared pixels (essential)
+    int32_t n_inliers;
+    int32_t valid;         // iteration that produced the model, -1: no meaningful model
+    int32_t iterations, rounds;
+};
+struct AcrHyp;
+size_t acr_hyp_bytes();
+hipError_t launch_acr_init(const AcrProblem& pb, int max_iteration, AcrState* d_state, int32_t* d_samples, AcrState* h_state, hipStream_t stream);
+// nfa + select of one batch of B iterations whose models are in d_models (B x max_models slots)
+hipError_t launch_acr_round(const AcrProblem& pb, int B, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
+                            uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, AcrState* h_state, hipStream_t stream);
+hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
+                             uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream);
+
 } // namespace clc
 #endif

@@ -292,6 +292,40 @@ int clc_pnp_localize(clc_ctx* ctx, const double* h_X, const double* h_x, int N, 
 int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                 const int32_t* h_samples, int S, double* h_Rt_out);
 
+/* ---- a-contrario model selection: what the reference actually runs ------------------------------------------------------
+ * Localizer::localizeImage calls SfM_Localizer::Localize(P3P_KE_CVPR17, ..., {error_max = +inf, max_iteration = 256})
+ * (include/coloc/Localizer.hpp:82-93) and RobustMatcher::filterEssential calls robust::ACRANSAC over the five-point
+ * kernel with precision +inf (include/coloc/RobustMatcher.hpp:153-171): OpenMVG's AC-RANSAC, which needs NO threshold --
+ * per model it sorts the residuals, evaluates the number of false alarms NFA(k) of "the k best are inliers" for every k
+ * and keeps the model / k of lowest NFA; after the first meaningful model (NFA < 0) the reserved 10 % of the iterations
+ * sample among its inliers.  (Moisan, Moulon, Monasse, IPOL 2012; OpenMVG itself is an empty submodule in the reference
+ * tree, so its RNG stream and solver root order are unpinned: samples here are a documented pure function of
+ * (seed, iteration, index set), coloc_amd/csrc/clc_acr.h.)  Batches of iterations are evaluated per round on the GPU --
+ * minimal solves, one sort + NFA scan per model in LDS, a sequential-semantics selection -- with results identical to
+ * the iteration-by-iteration loop (oracle/clc_oracle_acr.c).  precision = INFINITY is the reference's setting; a finite
+ * value is OpenMVG's upper bound on the inlier residual, in pixels^2.  At most 8192 correspondences per solve.
+ *
+ * clc_pnp_acransac: h_X N x 3, h_x N x 2 UNDISTORTED pixels, h_K 9 row-major (fx = K[0] scales residuals to the
+ * normalised camera plane as ACKernelAdaptorResection_Intrinsics does).  Outputs (nullable): h_Rt 12 doubles [R|t],
+ * h_inlier_mask N bytes, h_inliers the inlier indices in ascending residual order (capacity N; vec_inliers),
+ * *n_inliers (0 = no meaningful model; the caller applies Localize's "> 2.5 x 3" test), *error_max the precision found
+ * in pixels (ACRansacOut.first), *min_nfa the log10 NFA (ACRansacOut.second), *iterations actually run. */
+int clc_pnp_acransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, int max_iteration,
+                     uint64_t seed, double precision, double* h_Rt, uint8_t* h_inlier_mask, int32_t* h_inliers,
+                     int* n_inliers, double* error_max, double* min_nfa, int* iterations);
+/* The same followed by clc_pnp_refine on the inliers in one submission: Localizer::localizeImage end to end
+ * (Localizer.hpp:77-108).  h_cov 36 doubles, *rmse as clc_pnp_refine. */
+int clc_pnp_localize_ac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, int max_iteration,
+                        uint64_t seed, double precision, double huber_a, double* h_Rt, double* h_cov,
+                        uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers, double* error_max, double* rmse);
+/* RobustMatcher::filterEssential's ACRANSAC: h_x1 / h_x2 N x 2 undistorted pixels, K1 / K2, img_w x img_h the size of
+ * image 2 (point-to-line alpha0 = 2 D / A / 2, residual^(1/2)); residual = symmetric epipolar distance of
+ * F = K2^-T E K1^-1 as clc_epipolar_residuals.  *error_max is that squared distance at the a-contrario threshold. */
+int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1,
+                           const double* h_K2, int img_w, int img_h, int max_iteration, uint64_t seed, double precision,
+                           double* h_E, double* h_F, uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers,
+                           double* error_max, double* min_nfa, int* iterations);
+
 /* ---- fusion (host arithmetic; no GPU work) ---------------------------------------------------------
  * Covariance intersection of two 3-D position estimates as CoLoC fuses intra- and inter-camera poses
  * (include/coloc/CovIntersection.hpp:24-49, called at include/coloc/coloc.hpp:362-389): omega in [0,1]

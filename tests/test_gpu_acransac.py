@@ -1,0 +1,143 @@
+"""GPU a-contrario RANSAC (clc_pnp_acransac / clc_essential_acransac, coloc_amd/csrc/acransac.hip) against the sequential
+oracle (oracle/clc_oracle_acr.c): the batched rounds must reproduce the iteration-by-iteration loop of OpenMVG's
+ACRANSAC as the reference calls it (Localizer.hpp:82-93: error_max = +inf, 256 iterations; RobustMatcher.hpp:161-171) --
+same model, same inlier list in the same order, same NFA, same threshold, same number of iterations.  The oracle's minimal
+solver is a callback into the product's own P3P / five-point kernels (checked against independent solvers in
+test_gpu_pnp.py / test_gpu_epipolar.py), so what is compared here is exactly the a-contrario machinery."""
+import math
+
+import numpy as np
+import pytest
+
+import synth
+from test_gpu_epipolar import _two_view
+
+pytestmark = pytest.mark.gpu
+
+
+def _p3p_fit(ctx, sc):
+    def fit(sample):
+        h = ctx.pnp_p3p(sc["X"], sc["x"], sc["K"], np.array([sample], dtype=np.int32))[0]
+        return [m for m in h if not np.isnan(m).any()]
+    return fit
+
+
+def _check_pose(ctx, oracle, sc, max_it, seed, precision=float("inf")):
+    got = ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], max_iteration=max_it, seed=seed, precision=precision)
+    want = oracle.acransac(0, sc["X"], sc["x"], sc["K"], _p3p_fit(ctx, sc), max_iteration=max_it, seed=seed, precision=precision)
+    assert (got["Rt"] is not None) == want["found"]
+    assert got["iterations"] == want["iterations"]
+    assert got["min_nfa"] == want["min_nfa"] or (math.isinf(got["min_nfa"]) and math.isinf(want["min_nfa"]))
+    assert np.array_equal(got["inliers"], want["inliers"].astype(np.int32))
+    if want["found"]:
+        assert np.array_equal(got["Rt"].reshape(-1), want["model"])
+        assert got["error_max"] == want["error_max"]
+        m = np.zeros(len(sc["X"]), bool); m[want["inliers"]] = True
+        assert np.array_equal(got["mask"], m)
+    else:
+        assert not got["mask"].any()
+    return got, want
+
+
+@pytest.mark.parametrize("n", [200, 1000, 5000])
+def test_pose_equals_sequential_oracle_config2_sizes(gpu_ctx, oracle, n):
+    """BASELINE config[2] sizes, the reference's settings (256 iterations, precision +inf)."""
+    sc = synth.pnp_scene(n, seed=4000 + n)
+    got, want = _check_pose(gpu_ctx, oracle, sc, 256, seed=1)
+    assert want["found"] and want["min_nfa"] < 0
+    # the a-contrario threshold separates the planted inliers without being told a threshold
+    assert (got["mask"] & sc["inliers"]).sum() >= 0.95 * sc["inliers"].sum()
+    assert (got["mask"] & ~sc["inliers"]).sum() <= 0.02 * n
+    true = np.concatenate([sc["R"], sc["t"][:, None]], 1)
+    assert np.abs(got["Rt"] - true).max() < 0.05
+    assert 0.5 < got["error_max"] < 4.0                      # pixels; the noise is 0.5 px
+    # libm log10 in the oracle (the literal restatement) selects the same inlier set
+    lm = oracle.acransac(0, sc["X"], sc["x"], sc["K"], _p3p_fit(gpu_ctx, sc), max_iteration=256, seed=1, use_libm=True)
+    assert np.array_equal(lm["inliers"], want["inliers"]) and lm["best_iter"] == want["best_iter"]
+
+
+@pytest.mark.parametrize("n,outl,max_it,seed", [(300, 0.6, 256, 2), (800, 0.75, 256, 3), (64, 0.2, 40, 4), (10, 0.0, 30, 5),
+                                                (4, 0.0, 20, 6), (2000, 0.5, 100, 7), (513, 0.4, 256, 8)])
+def test_pose_other_shapes_and_outlier_rates(gpu_ctx, oracle, n, outl, max_it, seed):
+    """Low inlier rates make the first phase long (several rounds, larger batches); tiny n exercises n = m + 1."""
+    sc = synth.pnp_scene(n, seed=4100 + seed, outlier_frac=outl)
+    _check_pose(gpu_ctx, oracle, sc, max_it, seed)
+
+
+def test_pose_no_model_cases(gpu_ctx, oracle):
+    sc = synth.pnp_scene(3, seed=1, outlier_frac=0.0)
+    got = gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"])
+    assert got["Rt"] is None and got["iterations"] == 0 and len(got["inliers"]) == 0
+    rng = np.random.default_rng(3)                           # pure noise: every NFA >= 0, the reserve is spent looking
+    sc = dict(X=rng.uniform(-5, 5, (150, 3)) + [0, 0, 12], x=np.stack([rng.uniform(0, 1280, 150), rng.uniform(0, 720, 150)], 1),
+              K=np.array([[1000.0, 0, 640], [0, 1000.0, 360], [0, 0, 1]]))
+    got, want = _check_pose(gpu_ctx, oracle, sc, 60, seed=9)
+    assert got["Rt"] is None and want["min_nfa"] >= 0 and got["iterations"] == 60
+
+
+def test_pose_upper_bound_mode(gpu_ctx, oracle):
+    """A finite precision (pixels^2) is OpenMVG's upper bound on the inlier residual: the NFA scan stops there."""
+    sc = synth.pnp_scene(600, seed=4555, outlier_frac=0.4)
+    got, want = _check_pose(gpu_ctx, oracle, sc, 128, seed=11, precision=9.0)
+    assert want["found"] and got["error_max"] <= 3.0 + 1e-9
+    got2, _ = _check_pose(gpu_ctx, oracle, sc, 128, seed=11, precision=0.25)
+    assert got2["error_max"] <= 0.5 + 1e-9 and len(got2["inliers"]) < len(got["inliers"])
+
+
+def test_pose_is_deterministic_and_seed_dependent(gpu_ctx):
+    sc = synth.pnp_scene(1000, seed=4777)
+    a = gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], seed=5)
+    b = gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], seed=5)
+    c = gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], seed=6)
+    assert np.array_equal(a["Rt"], b["Rt"]) and np.array_equal(a["inliers"], b["inliers"]) and a["min_nfa"] == b["min_nfa"]
+    assert c["Rt"] is not None and (c["mask"] & sc["inliers"]).sum() >= 0.95 * sc["inliers"].sum()
+
+
+def test_localize_ac_is_acransac_then_refine(gpu_ctx):
+    sc = synth.pnp_scene(1000, seed=4999)
+    a = gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], seed=3)
+    r = gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], seed=3, refine=True)
+    assert np.array_equal(a["inliers"], r["inliers"]) and a["error_max"] == r["error_max"]
+    Rt2, cov2, rmse2, _ = gpu_ctx.pnp_refine(sc["X"], sc["x"], sc["K"], a["Rt"], mask=a["mask"])
+    assert np.allclose(r["Rt"], Rt2, atol=1e-9) and np.allclose(r["cov"], cov2, rtol=1e-6, atol=1e-12) and abs(r["rmse"] - rmse2) < 1e-9
+    true = np.concatenate([sc["R"], sc["t"][:, None]], 1)
+    assert np.abs(r["Rt"] - true).max() < np.abs(a["Rt"] - true).max() + 1e-6 and np.abs(r["Rt"] - true).max() < 5e-3
+
+
+def _f_from_e(E, K1, K2):
+    """F = K2^-T E K1^-1 in the operation order of fivept_kernel (coloc_amd/csrc/pnp.hip), plain IEEE doubles."""
+    def kinv(K):
+        fx, sk, cx, fy, cy = float(K[0, 0]), float(K[0, 1]), float(K[0, 2]), float(K[1, 1]), float(K[1, 2])
+        return [1.0 / fx, -sk / (fx * fy), (sk * cy - cx * fy) / (fx * fy), 0.0, 1.0 / fy, -cy / fy, 0.0, 0.0, 1.0]
+    A1, A2 = kinv(K1), kinv(K2)
+    e = [float(v) for v in E.reshape(9)]
+    T = [0.0] * 9
+    for r in range(3):
+        for c in range(3):
+            T[3 * r + c] = e[3 * r] * A1[c] + e[3 * r + 1] * A1[3 + c] + e[3 * r + 2] * A1[6 + c]
+    F = [0.0] * 9
+    for r in range(3):
+        for c in range(3):
+            F[3 * r + c] = A2[r] * T[c] + A2[3 + r] * T[3 + c] + A2[6 + r] * T[6 + c]
+    return np.array(F)
+
+
+@pytest.mark.parametrize("n,seed", [(300, 21), (1000, 22)])
+def test_essential_equals_sequential_oracle(gpu_ctx, oracle, n, seed):
+    x1, x2, Ftrue, out = _two_view(n, seed=seed)
+    K = synth.pnp_scene(5, seed=seed)["K"]
+
+    def fit(sample):
+        Es = gpu_ctx.essential_fivepoint(x1, x2, K, K, np.array([sample], dtype=np.int32))[0]
+        return [np.concatenate([_f_from_e(E, K, K), E]) for E in Es if not np.isnan(E).any()]
+
+    got = gpu_ctx.essential_acransac(x1, x2, K, K, (1280, 720), max_iteration=256, seed=seed)
+    want = oracle.acransac(1, x1, x2, K, fit, max_iteration=256, seed=seed, img_wh=(1280, 720))
+    assert want["found"] and got["E"] is not None
+    assert got["iterations"] == want["iterations"] and got["min_nfa"] == want["min_nfa"] and got["error_max"] == want["error_max"]
+    assert np.array_equal(got["inliers"], want["inliers"].astype(np.int32))
+    assert np.array_equal(got["F"].reshape(-1), want["model"][:9]) and np.array_equal(got["E"].reshape(-1), want["model"][9:])
+    true_in = np.ones(n, bool); true_in[out] = False
+    assert (got["mask"] & true_in).sum() >= 0.9 * true_in.sum() and (got["mask"] & ~true_in).sum() <= 0.1 * len(out) + 2
+    Fn = got["F"] / np.linalg.norm(got["F"])
+    assert min(np.abs(Fn - Ftrue).max(), np.abs(Fn + Ftrue).max()) < 0.05
