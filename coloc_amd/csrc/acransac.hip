@@ -61,80 +61,200 @@ __device__ __forceinline__ double acr_err_epipolar(const double* __restrict__ f,
     return (d * d) * (1.0 / (a0 * a0 + a1 * a1) + 1.0 / (b0 * b0 + b1 * b1)) / 4.0;
 }
 
-__global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, const int P /* power of two >= n */,
+// (residual bits, index) pairs in lexicographic order: what std::sort does with pair<double, uint32_t>
+struct AcrItem { uint64_t key; uint32_t idx; };
+__device__ __forceinline__ bool acr_gt(const uint64_t ka, const uint32_t ia, const uint64_t kb, const uint32_t ib)
+{
+    return ka > kb || (ka == kb && ia > ib);
+}
+
+// Sorting the residuals of one model.  Each thread holds E consecutive elements in REGISTERS: compare-exchange distances
+// below E stay inside the thread, distances below 64 E are lane exchanges inside the wave (ds_bpermute, no barrier), only
+// distances that cross waves go through LDS (1024 elements on 256 threads: 19 in-register, 33 in-wave, 3 cross-wave steps
+// instead of 55 LDS round trips with a workgroup barrier each).
+// The network runs on ONE 64-bit word per element, compared with v_min_f64 / v_max_f64 (two instructions per exchange
+// instead of a 64-bit compare, an index compare and three selects): the residual's bits with the low 13 mantissa bits
+// replaced by the element index (n <= 8192).  That orders by (top 51 bits of the residual, index); the exact (residual,
+// index) order differs from it only where two residuals agree in their top 51 bits, so afterwards every element recomputes
+// its exact residual, neighbours are compared exactly, and in the (rare) case of an inversion anywhere in the workgroup
+// the exact-key network below re-sorts -- the result is always the exact lexicographic order.
+__device__ __forceinline__ double acr_fmin(const double a, const double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double acr_fmax(const double a, const double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double acr_shfl_xor(const double v, const int mask)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = __shfl_xor((uint32_t)u, mask), hi = __shfl_xor((uint32_t)(u >> 32), mask);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+template <int E, bool EXACT>
+__device__ __forceinline__ void acr_bitonic(uint64_t (&key)[E], uint32_t (&idx)[E], double (&c)[E], const int P, const int tid, const int T,
+                                            uint64_t* lkey, uint32_t* lidx)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+                // both elements in this thread: element e pairs with e | j
+#pragma unroll
+                for (int jj = 1; jj < E; jj <<= 1) {
+                    if (jj != j) continue;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (e & jj) continue;
+                        const bool up = ((tid * E + e) & k) == 0;
+                        if (EXACT) {
+                            const bool gt = acr_gt(key[e], idx[e], key[e | jj], idx[e | jj]);
+                            if (gt == up) {
+                                const uint64_t tk = key[e]; key[e] = key[e | jj]; key[e | jj] = tk;
+                                const uint32_t ti = idx[e]; idx[e] = idx[e | jj]; idx[e | jj] = ti;
+                            }
+                        } else {
+                            const double lo = acr_fmin(c[e], c[e | jj]), hi = acr_fmax(c[e], c[e | jj]);
+                            c[e] = up ? lo : hi;
+                            c[e | jj] = up ? hi : lo;
+                        }
+                    }
+                }
+            } else {
+                const int dt = j / E;                                    // partner thread = tid ^ dt, same e
+                const bool lower = (tid & dt) == 0;
+                if (dt >= 64) {
+                    __syncthreads();                                      // the previous exchange's reads are done
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        lkey[e * T + tid] = EXACT ? key[e] : (uint64_t)__double_as_longlong(c[e]);
+                        if (EXACT) lidx[e * T + tid] = idx[e];
+                    }
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool keep_min = lower == (((tid * E + e) & k) == 0);
+                    if (EXACT) {
+                        uint64_t ok;
+                        uint32_t oi;
+                        if (dt >= 64) { ok = lkey[e * T + (tid ^ dt)]; oi = lidx[e * T + (tid ^ dt)]; }
+                        else {
+                            const uint32_t lo = __shfl_xor((uint32_t)key[e], dt), hi = __shfl_xor((uint32_t)(key[e] >> 32), dt);
+                            ok = ((uint64_t)hi << 32) | lo;
+                            oi = __shfl_xor(idx[e], dt);
+                        }
+                        const bool gt = acr_gt(key[e], idx[e], ok, oi);   // mine > other
+                        if (gt == keep_min) { key[e] = ok; idx[e] = oi; }
+                    } else {
+                        const double o = dt >= 64 ? __longlong_as_double((long long)lkey[e * T + (tid ^ dt)]) : acr_shfl_xor(c[e], dt);
+                        const double lo = acr_fmin(c[e], o), hi = acr_fmax(c[e], o);
+                        c[e] = keep_min ? lo : hi;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int E>
+__global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, const int P /* = blockDim.x * E, power of two >= n */,
                                                        const double* __restrict__ models, AcrHyp* __restrict__ hyp,
                                                        uint32_t* __restrict__ sorted_idx)
 {
     extern __shared__ unsigned char acr_lds[];
-    uint64_t* key = reinterpret_cast<uint64_t*>(acr_lds);               // P residuals as bits (>= 0: bit order == value order)
-    uint32_t* idx = reinterpret_cast<uint32_t*>(acr_lds + (size_t)P * 8);
-    __shared__ double s_nfa[1024 / 64];
-    __shared__ int s_k[1024 / 64], s_cnt[1024 / 64];
     const int slot = blockIdx.x, tid = threadIdx.x, T = blockDim.x, n = pb.n;
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(acr_lds);               // [e][tid] staging of the cross-wave exchanges
+    uint32_t* lidx = reinterpret_cast<uint32_t*>(acr_lds + (size_t)P * 8);
+    __shared__ double s_nfa[1024 / 64], s_ek[1024 / 64];
+    __shared__ int s_k[1024 / 64], s_cnt[1024 / 64];
+    __shared__ uint64_t s_edge_key[1024 / 64];
+    __shared__ uint32_t s_edge_idx[1024 / 64];
     const double* model = models + (size_t)slot * pb.model_doubles;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
     // an empty slot (the solver marks it with NaNs) never improves anything
     if (model[0] != model[0]) {
-        if (tid == 0) { hyp[slot].nfa = __longlong_as_double(0x7ff0000000000000LL); hyp[slot].e_k = 0.0; hyp[slot].k = 0; hyp[slot].n_le = 0; }
+        if (tid == 0) { hyp[slot].nfa = inf; hyp[slot].e_k = 0.0; hyp[slot].k = 0; hyp[slot].n_le = 0; }
         return;
     }
+    auto residual = [&](const int i) -> double {
+        return pb.kind == 0
+            ? acr_err_resection(model, pb.K1, pb.norm, pb.a[3 * i], pb.a[3 * i + 1], pb.a[3 * i + 2], pb.b[2 * i], pb.b[2 * i + 1])
+            : acr_err_epipolar(model, pb.a[2 * i], pb.a[2 * i + 1], pb.b[2 * i], pb.b[2 * i + 1]);
+    };
+    uint64_t key[E];
+    uint32_t idx[E];
+    double c[E];
     int cnt = 0;
-    for (int i = tid; i < P; i += T) {
-        uint64_t kb = 0x7ff0000000000000ull;                             // padding: +inf, behind every real residual
-        uint32_t ib = 0xFFFFFFFFu;
+    const uint64_t kMaxFinite = 0x7fefffffffffffffull;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e;
+        uint64_t bits = kMaxFinite;                                       // padding (and inf / NaN residuals) sort behind every finite one
         if (i < n) {
-            const double e = pb.kind == 0
-                ? acr_err_resection(model, pb.K1, pb.norm, pb.a[3 * i], pb.a[3 * i + 1], pb.a[3 * i + 2], pb.b[2 * i], pb.b[2 * i + 1])
-                : acr_err_epipolar(model, pb.a[2 * i], pb.a[2 * i + 1], pb.b[2 * i], pb.b[2 * i + 1]);
-            kb = (uint64_t)__double_as_longlong(e);
-            ib = (uint32_t)i;
-            cnt += e <= pb.max_threshold ? 1 : 0;
+            const double r = residual(i);
+            cnt += r <= pb.max_threshold ? 1 : 0;
+            const uint64_t rb = (uint64_t)__double_as_longlong(r);
+            bits = rb < kMaxFinite ? rb : kMaxFinite;
         }
-        key[i] = kb;
-        idx[i] = ib;
+        c[e] = __longlong_as_double((long long)((bits & ~0x1FFFull) | (uint64_t)i));
     }
-    __syncthreads();
-    // bitonic sort, ascending in (residual, index): std::sort on pair<double, uint32_t>
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (P >> 1); t += T) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const uint64_t ka = key[i], kb = key[l];
-                const uint32_t ia = idx[i], ib = idx[l];
-                const bool gt = ka > kb || (ka == kb && ia > ib);
-                if (gt == ((i & k) == 0)) { key[i] = kb; key[l] = ka; idx[i] = ib; idx[l] = ia; }
-            }
-            __syncthreads();
+    acr_bitonic<E, false>(key, idx, c, P, tid, T, lkey, lidx);
+    // exact keys of the elements as they stand now, then the neighbour check
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)((uint64_t)__double_as_longlong(c[e]) & 0x1FFFull);
+        if ((int)i < n) { idx[e] = i; key[e] = (uint64_t)__double_as_longlong(residual((int)i)); }
+        else { idx[e] = 0xFFFFFFFFu; key[e] = 0x7ff0000000000000ull; }   // padding: +inf, index above every real one
+    }
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e + 1 < E; ++e) bad = bad || acr_gt(key[e], idx[e], key[e + 1], idx[e + 1]);
+    {
+        // my last element against the next thread's first: inside the wave by lane shift, across waves through LDS
+        const uint32_t nlo = __shfl_down((uint32_t)key[0], 1), nhi = __shfl_down((uint32_t)(key[0] >> 32), 1);
+        const uint32_t nidx = __shfl_down(idx[0], 1);
+        if ((tid & 63) == 0) { s_edge_key[tid >> 6] = key[0]; s_edge_idx[tid >> 6] = idx[0]; }
+        __syncthreads();
+        uint64_t nk = ((uint64_t)nhi << 32) | nlo;
+        uint32_t ni = nidx;
+        if ((tid & 63) == 63) {
+            if (tid + 1 < T) { nk = s_edge_key[(tid >> 6) + 1]; ni = s_edge_idx[(tid >> 6) + 1]; }
+            else { nk = ~0ull; ni = ~0u; }
         }
+        bad = bad || acr_gt(key[E - 1], idx[E - 1], nk, ni);
     }
-    // NFA(k), k = m + 1 .. n while e_(k) <= max_threshold; strict '<' keeps the first k
-    double best = __longlong_as_double(0x7ff0000000000000LL);
+    if (__syncthreads_or(bad ? 1 : 0)) acr_bitonic<E, true>(key, idx, c, P, tid, T, lkey, lidx);
+    // NFA(k) of this thread's own positions k = tid E + e + 1, for m + 1 <= k <= n and e_(k) <= max_threshold; strict '<'
+    // keeps the first k
+    double best = inf, bek = 0.0;
     int bk = pb.m;
-    for (int kk = pb.m + 1 + tid; kk <= n; kk += T) {
-        const double e = __longlong_as_double((long long)key[kk - 1]);
-        if (!(e <= pb.max_threshold)) break;                              // sorted: nothing further qualifies either
-        const double v = clc_acr_nfa(pb.loge0, pb.logalpha0, pb.mult, e, kk, pb.m, pb.logc_n[kk], pb.logc_k[kk]);
-        if (v < best) { best = v; bk = kk; }
+    uint32_t* out_idx = sorted_idx + (size_t)slot * n;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int kk = tid * E + e + 1;
+        if (kk <= n) out_idx[kk - 1] = idx[e];
+        if (kk > pb.m && kk <= n) {
+            const double r = __longlong_as_double((long long)key[e]);
+            if (r <= pb.max_threshold) {
+                const double v = clc_acr_nfa(pb.loge0, pb.logalpha0, pb.mult, r, kk, pb.m, pb.logc_n[kk], pb.logc_k[kk]);
+                if (v < best) { best = v; bk = kk; bek = r; }
+            }
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(best, off);
+        const double ov = __shfl_xor(best, off), oe = __shfl_xor(bek, off);
         const int ok = __shfl_xor(bk, off);
-        if (ov < best || (ov == best && ok < bk)) { best = ov; bk = ok; }
+        if (ov < best || (ov == best && ok < bk)) { best = ov; bk = ok; bek = oe; }
         cnt += __shfl_xor(cnt, off);
     }
-    if ((tid & 63) == 0) { s_nfa[tid >> 6] = best; s_k[tid >> 6] = bk; s_cnt[tid >> 6] = cnt; }
-    uint32_t* out_idx = sorted_idx + (size_t)slot * n;
-    for (int i = tid; i < n; i += T) out_idx[i] = idx[i];
+    if ((tid & 63) == 0) { s_nfa[tid >> 6] = best; s_k[tid >> 6] = bk; s_ek[tid >> 6] = bek; s_cnt[tid >> 6] = cnt; }
     __syncthreads();
     if (tid == 0) {
         int total = 0;
+        best = inf; bk = pb.m; bek = 0.0;
         for (int w = 0; w < (T + 63) / 64; ++w) {
-            if (s_nfa[w] < best || (s_nfa[w] == best && s_k[w] < bk)) { best = s_nfa[w]; bk = s_k[w]; }
+            if (s_nfa[w] < best || (s_nfa[w] == best && s_k[w] < bk)) { best = s_nfa[w]; bk = s_k[w]; bek = s_ek[w]; }
             total += s_cnt[w];
         }
         hyp[slot].nfa = best;
         hyp[slot].k = bk;
-        hyp[slot].e_k = bk > pb.m ? __longlong_as_double((long long)key[bk - 1]) : 0.0;
+        hyp[slot].e_k = bek;
         hyp[slot].n_le = total;
     }
 }
@@ -187,7 +307,10 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
 {
     __shared__ AcrState s;
     __shared__ int s_best_h, s_copy_index;
+    __shared__ AcrHyp s_hyp[kAcrMaxBatch * 10];
     const int tid = threadIdx.x, T = blockDim.x;
+    for (int h = tid; h < B * pb.max_models; h += T) s_hyp[h] = hyp[h];      // parallel loads; the scan below is sequential
+    __syncthreads();
     if (tid == 0) {
         s = *state;
         int best_h = -1, copy_index = 0, consumed = B;
@@ -195,7 +318,7 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
             bool better = false;
             for (int k = 0; k < pb.max_models; ++k) {
                 const int h = it * pb.max_models + k;
-                const AcrHyp hy = hyp[h];
+                const AcrHyp hy = s_hyp[h];
                 if (!s.ac_mode) { if ((double)hy.n_le > 2.5 * (double)pb.m) s.ac_mode = 1; }
                 if (!s.ac_mode) continue;
                 if (hy.nfa < s.min_nfa) {
@@ -285,24 +408,36 @@ hipError_t launch_acr_init(const AcrProblem& pb, int max_iteration, AcrState* d_
     return hipGetLastError();
 }
 
+template <int E>
+static hipError_t acr_launch_nfa(const AcrProblem& pb, int B, int P, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, hipStream_t stream)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)acr_nfa_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcrMaxLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const int T = P / E;
+    // LDS is only touched by exchanges that cross waves
+    const size_t lds = T > 64 ? (size_t)P * 12 : 0;
+    hipLaunchKernelGGL(acr_nfa_kernel<E>, dim3(B * pb.max_models), dim3(T), lds, stream, pb, P, d_models, d_hyp, d_sorted);
+    return hipGetLastError();
+}
+
 hipError_t launch_acr_round(const AcrProblem& pb, int B, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
                             uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, AcrState* h_state, hipStream_t stream)
 {
     int P = 64;
     while (P < pb.n) P <<= 1;
-    int T = P / 2;
-    if (T < 64) T = 64;
-    if (T > 1024) T = 1024;
-    const size_t lds = (size_t)P * 12;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr_set[dev]) {
-        const hipError_t e = hipFuncSetAttribute((const void*)acr_nfa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcrMaxLds);
-        if (e != hipSuccess) return e;
-        attr_set[dev] = true;
-    }
-    hipLaunchKernelGGL(acr_nfa_kernel, dim3(B * pb.max_models), dim3(T), lds, stream, pb, P, d_models, d_hyp, d_sorted);
+    // elements per thread: 64 .. 4096 elements on 64 .. 1024 threads, 8192 on 1024 x 8
+    hipError_t e;
+    if (P == 64) e = acr_launch_nfa<1>(pb, B, P, d_models, d_hyp, d_sorted, stream);
+    else if (P == 128) e = acr_launch_nfa<2>(pb, B, P, d_models, d_hyp, d_sorted, stream);
+    else if (P <= 4096) e = acr_launch_nfa<4>(pb, B, P, d_models, d_hyp, d_sorted, stream);
+    else e = acr_launch_nfa<8>(pb, B, P, d_models, d_hyp, d_sorted, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(acr_select_kernel, dim3(1), dim3(256), 0, stream, pb, B, d_models, (const AcrHyp*)d_hyp, (const uint32_t*)d_sorted,
                        d_state, d_best_inliers, d_index_set, d_samples, h_state);
     return hipGetLastError();

@@ -64,6 +64,23 @@ def test_pose_other_shapes_and_outlier_rates(gpu_ctx, oracle, n, outl, max_it, s
     _check_pose(gpu_ctx, oracle, sc, max_it, seed)
 
 
+def test_pose_duplicate_and_nearly_equal_residuals(gpu_ctx, oracle):
+    """The GPU sorts 64-bit words made of the top 51 residual bits + the index and repairs the order exactly afterwards.
+    Duplicated correspondences (equal residuals: index decides) and copies whose pixel differs by one ulp (residuals
+    that agree in their top bits but not exactly: the repair path) must still give the oracle's order."""
+    sc = synth.pnp_scene(400, seed=4242, outlier_frac=0.3)
+    X, x = sc["X"].copy(), sc["x"].copy()
+    inl = np.flatnonzero(sc["inliers"])
+    for k in range(60):                                        # exact duplicates, scattered over the index range
+        X[399 - k] = X[inl[k]]; x[399 - k] = x[inl[k]]
+    for k in range(60, 120):                                   # one-ulp copies in both directions
+        X[399 - k] = X[inl[k]]
+        x[399 - k] = np.nextafter(x[inl[k]], np.inf if k % 2 else -np.inf)
+    sc2 = dict(sc, X=X, x=x)
+    got, want = _check_pose(gpu_ctx, oracle, sc2, 64, seed=12)
+    assert want["found"]
+
+
 def test_pose_no_model_cases(gpu_ctx, oracle):
     sc = synth.pnp_scene(3, seed=1, outlier_frac=0.0)
     got = gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"])
