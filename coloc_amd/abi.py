@@ -46,7 +46,7 @@ EXPORTS = [
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
-    "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac",
+    "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -139,6 +139,7 @@ def load_library():
     lib.clc_pnp_acransac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, vp, vp, vp, ip, dp, dp, ip]
     lib.clc_pnp_localize_ac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, vp, ip, dp, dp]
     lib.clc_essential_acransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, ip, dp, dp, ip]
+    lib.clc_k2nn_clock_check.argtypes = [vp, vp, ci, vp, ci, vp, vp, dp, dp, dp, ip]
     lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
     lib.clc_k2nn_queries_per_block.argtypes = [vp]
     _lib = lib
@@ -309,6 +310,12 @@ class Context:
     @property
     def k2nn_queries_per_block(self):
         return int(self.lib.clc_k2nn_queries_per_block(self.h))
+
+    def k2nn_clock_check(self, d_q, nq, d_t, nt, d_match, stream=None):
+        """In-kernel shader clock of one (diagnostic, stamped) sweep: (median GHz, min, max, workgroups)."""
+        med, lo, hi, n = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        self._chk(self.lib.clc_k2nn_clock_check(self.h, d_q, nq, d_t, nt, d_match, stream, C.byref(med), C.byref(lo), C.byref(hi), C.byref(n)))
+        return med.value, lo.value, hi.value, n.value
 
     def match_2nn(self, Q, T, threshold=40, want_dist=False):
         Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)

@@ -10,6 +10,7 @@
 #include "../host/HIPCovIntersection.hpp"
 #include "clc_acr.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -614,6 +615,51 @@ int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation)
 int clc_k2nn_queries_per_block(const clc_ctx* ctx)
 {
     return k2nn_queries_per_block(ctx ? ctx->formulation : K2NN_MATRIX);
+}
+
+int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int32_t* d_match, void* stream,
+                         double* ghz_median, double* ghz_min, double* ghz_max, int* workgroups)
+{
+    if (!ctx || nq <= 0 || nt <= 0 || !d_q || !d_t || !d_match) return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_clock_check: bad argument");
+    if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 15u)) return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_clock_check: misaligned device pointer");
+    if (ctx->formulation != K2NN_MATRIX) return fail(ctx, CLC_ERR_STATE, "k2nn_clock_check: matrix formulation only");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    std::vector<K2nnJobDev> jobs(1);
+    jobs[0] = K2nnJobDev{};
+    jobs[0].q = (const uint4*)d_q; jobs[0].t = (const uint4*)d_t; jobs[0].out = d_match;
+    jobs[0].nq = (uint32_t)nq; jobs[0].nt = (uint32_t)nt; jobs[0].thr = 40u;
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), 1, target, ctx->xcd_map, ctx->formulation);
+    if (!plan.atomic_merge) return fail(ctx, CLC_ERR_CAPACITY, "k2nn_clock_check: train set too large");
+    int rc = ensure_partial(ctx, plan.partial_elems);
+    if (rc != CLC_OK) return rc;
+    if (ctx->partial_dirty) {
+        CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
+        ctx->partial_dirty = false;
+    }
+    const size_t nwg = (size_t)jobs[0].qblocks * jobs[0].splits;
+    uint64_t* d_stamps = nullptr;
+    CLC_HIP(ctx, hipMalloc((void**)&d_stamps, nwg * 4 * sizeof(uint64_t)));
+    std::vector<uint64_t> h(nwg * 4);
+    hipError_t e = hipMemsetAsync(d_stamps, 0, nwg * 4 * sizeof(uint64_t), st);
+    if (e == hipSuccess) e = launch_k2nn(jobs.data(), 1, ctx->d_partial, st, nullptr, ctx->formulation, d_stamps);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_stamps, nwg * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_stamps);
+    if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "k2nn_clock_check", e);
+    std::vector<double> ghz;
+    for (size_t w = 0; w < nwg; ++w) {
+        const uint64_t dc = h[4 * w + 2] - h[4 * w], dr = h[4 * w + 3] - h[4 * w + 1];
+        if (dr > 20) ghz.push_back((double)dc / (double)dr * 0.1);       // s_memrealtime ticks at 100 MHz
+    }
+    if (ghz.empty()) return fail(ctx, CLC_ERR_STATE, "k2nn_clock_check: sweep too short to stamp");
+    std::sort(ghz.begin(), ghz.end());
+    if (ghz_median) *ghz_median = ghz[ghz.size() / 2];
+    if (ghz_min) *ghz_min = ghz.front();
+    if (ghz_max) *ghz_max = ghz.back();
+    if (workgroups) *workgroups = (int)ghz.size();
+    return CLC_OK;
 }
 
 int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int threshold,

@@ -93,8 +93,10 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map 
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
 // In atomic mode d_partial must hold 0xFF bytes in every entry the jobs use (top-2 rows and arrival counters);
 // the workgroup that completes a query block leaves it that way again (self re-arming workspace).
+// d_stamps (matrix formulation only, nullable): run the diagnostic build whose workgroups record their shader-clock /
+// real-time stamps, 4 uint64 per workgroup of the launch grid
 hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream,
-                       Profiler* prof = nullptr, int formulation = K2NN_MATRIX);
+                       Profiler* prof = nullptr, int formulation = K2NN_MATRIX, uint64_t* d_stamps = nullptr);
 int k2nn_queries_per_block(int formulation);
 
 // ---- PnP -------------------------------------------------------------------------------------

@@ -306,7 +306,12 @@ __device__ __forceinline__ uint32_t mx_decode(const uint32_t bits, const uint32_
     return (d << kKeyShift) | (t0 + (rel & (kMxMaxSplit - 1u)));
 }
 
-__global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial)
+// STAMP: diagnostic build for the clock check (MI355X guide, DVFS item 6): lane 0 of every workgroup brackets its tile loop
+// with s_memtime (shader clock) / s_memrealtime (constant 100 MHz) and stores the four values in a buffer nothing else
+// reads.  The product kernel (STAMP = false) contains no stamp.
+template <bool STAMP>
+__global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial,
+                                                                      uint64_t* __restrict__ stamps)
 {
     constexpr int QT = kMxQT;
     constexpr int kStride = 65;      // uint4 per k-step of a train tile in LDS: 64 lanes + 1 pad, so that the 8 k-steps
@@ -362,6 +367,8 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
         return tbase[(size_t)row * 8u];
     };
     u32x2 r0 = load_bits(0u), r1 = load_bits(min(1u, ntiles - 1u));
+    uint64_t st_clk = 0, st_real = 0;
+    if (STAMP) { st_clk = __builtin_amdgcn_s_memtime(); st_real = __builtin_amdgcn_s_memrealtime(); }
     for (uint32_t t = 0; t < ntiles; ++t) {
         const uint32_t buf = t & 1u;
         s_a[buf][dst] = mx_expand(~r0.x);
@@ -404,6 +411,13 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
         for (int i = 0; i < 16; ++i) cinit[i] += 32.0f;
     }
 
+    if (STAMP) {
+        const uint64_t en_clk = __builtin_amdgcn_s_memtime(), en_real = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            uint64_t* o = stamps + 4u * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = st_clk; o[1] = st_real; o[2] = en_clk; o[3] = en_real;
+        }
+    }
     // lanes l and l ^ 32 hold the same query column (different train rows): fold them, decode to canonical keys with the
     // index relative to s0 (slab mode) or global (atomic mode), and hand the workgroup's 256 results over through LDS so
     // that thread i finishes query i of the block with coalesced rows
@@ -583,7 +597,8 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
     return plan;
 }
 
-hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream, Profiler* prof, int formulation)
+hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream, Profiler* prof, int formulation,
+                       uint64_t* d_stamps)
 {
     for (int base = 0; base < njobs; base += kK2nnJobsPerLaunch) {
         const int cnt = njobs - base < kK2nnJobsPerLaunch ? njobs - base : kK2nnJobsPerLaunch;
@@ -602,8 +617,11 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, true, stream);
             if (formulation == K2NN_POPCOUNT)
                 hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
+            else if (d_stamps)
+                hipLaunchKernelGGL(k2nn_sweep_mx_kernel<true>, dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
             else
-                hipLaunchKernelGGL(k2nn_sweep_mx_kernel, dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial);
+                hipLaunchKernelGGL(k2nn_sweep_mx_kernel<false>, dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                                   (uint64_t*)nullptr);
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, false, stream);
         }
         if (list.j[0].atomic_merge) {

@@ -15,7 +15,11 @@ The planning functions are pure Python (tested on CPU); the collective is torch.
 from dataclasses import dataclass
 from typing import List, Tuple
 
-QBLOCK = 512   # queries per K2NN workgroup (coloc_amd/csrc/k2nn.hip kQPerBlock): shares are cut on this grain
+# Default grain of a share, in queries.  A K2NN sweep workgroup covers clc_k2nn_queries_per_block() queries (256 for the
+# matrix formulation, 128 for the popcount one, coloc_amd/csrc/k2nn.hip); cutting shares on a multiple of it means no
+# workgroup straddles two ranks.  Callers that hold a context pass grain=ctx.k2nn_queries_per_block; the default is a
+# multiple of both (tests/test_abi.py checks that).
+QBLOCK = 256
 
 
 def exhaustive_pairs(n: int) -> List[Tuple[int, int]]:
@@ -31,9 +35,11 @@ class Job:
     out_offset: int         # first int32 of this job's results inside the rank-local result buffer
 
 
-def shard_pairs(counts: List[int], world: int, rank: int, qblock: int = QBLOCK) -> List[Job]:
+def shard_pairs(counts: List[int], world: int, rank: int, qblock: int = QBLOCK, grain: int = 0) -> List[Job]:
     """Jobs of `rank`: a contiguous share of the (pair, query-block) sequence, split as evenly as the
-    block grain allows.  counts[c] = number of descriptors of camera c."""
+    block grain allows.  counts[c] = number of descriptors of camera c.  grain (if given) overrides qblock."""
+    if grain > 0:
+        qblock = grain
     pairs = exhaustive_pairs(len(counts))
     blocks = []                                    # (pair index, block index) flattened
     for p, (i, j) in enumerate(pairs):

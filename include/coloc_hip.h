@@ -208,6 +208,14 @@ int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation);
  * to several GPUs (clc_match_job.q_offset / nq) should cut them, so that no workgroup is split between two jobs. */
 int clc_k2nn_queries_per_block(const clc_ctx* ctx);
 
+/* Measurement aid (replaces nothing in the reference): runs ONE sweep of d_q x d_t with the diagnostic build of the
+ * matrix-formulation kernel, whose workgroups bracket their tile loop with the shader-clock and the constant 100 MHz
+ * real-time counters, and returns the clock the chip actually held inside the kernel (median / min / max over the
+ * workgroups, GHz).  Call it straight after a sustained run: peaks quoted at 2.4 GHz are only reached if this says so.
+ * The results in d_match are the normal ones (threshold 40). */
+int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int32_t* d_match, void* stream,
+                         double* ghz_median, double* ghz_min, double* ghz_max, int* workgroups);
+
 /* The all-pairs loop of GPUMatcher::computeMatches (GPUMatcher.hpp:143-155) on host buffers: uploads
  * each camera's descriptors once (the reference re-uploads both sides for every pair,
  * GPUMatcher.hpp:188-196), sweeps every listed (first, second) pair in one launch group (Q = first,

@@ -60,3 +60,12 @@ def test_keypoints_to_features_is_host_only(oracle):
     from coloc_amd import keypoints_to_features
     kps = synth.random_keypoints(64, 640, 480, seed=1)
     assert np.array_equal(keypoints_to_features(kps), oracle.features_from_kps(kps))
+
+
+def test_share_grain_is_a_multiple_of_every_sweep_workgroup():
+    """multicam cuts rank shares on QBLOCK queries; a sweep workgroup covers clc_k2nn_queries_per_block() queries
+    (both formulations; callable without a context, hence without a GPU)."""
+    from coloc_amd import abi, multicam
+    lib = abi.load_library()
+    grain = lib.clc_k2nn_queries_per_block(None)
+    assert grain in (128, 256) and multicam.QBLOCK % grain == 0 and multicam.QBLOCK % 128 == 0

@@ -32,9 +32,16 @@ def test_default_line_has_contract_fields():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["valu"]["frac"] > 0.3
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0.1 < r["frac"] < 1.0
+    assert r["traffic"] is None or "traffic_source" in r
+    assert 1.0 < r["clock_ghz_in_kernel"]["median"] <= 2.5          # the chip's real in-kernel clock, not an assumed 2.4
+    assert d["sustained"]["seconds"] >= 1.0 and d["sustained"]["steps"] >= 20 and d["sustained_value"] > 0
+    assert d["stages"]["k2nn_other_formulation"]["identical_results"] is True
+    assert d["accepted_matches_per_step"] > 5000                     # the two cameras see the same scene
+    assert "acransac" in d["pose_solve"]["rule"].lower() or "a-contrario" in d["pose_solve"]["rule"]
+    assert d["pose_solve_p50_ms"] > 0 and "section_errors" not in d
     c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["openmvg_ratio_rule"]["value"] > 0
     assert d["value"] > 10 * c["value"]          # north-star target: >= 10x the host-CPU matcher
 
 
