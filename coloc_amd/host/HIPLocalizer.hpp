@@ -1,0 +1,189 @@
+// HIPLocalizer.hpp -- drop-in for coloc::Localizer (reference include/coloc/Localizer.hpp:19-177) over the C ABI of
+// libcoloc_hip.so (include/coloc_hip.h).
+//
+// Same public surface, argument meaning and status convention:
+//   Localizer(colocParams&)                                                               :22-32
+//   bool setupTracks(cam*, data, queryRegions, trackedFeatures, trackPtr)                 :59-75
+//        pt3D.col(i) = landmark X of data.mapRegionIdx[m.i_], pt2D.col(i) = position of query feature m.j_, passed
+//        through cam->get_ud_pixel() (Pinhole_Intrinsic_Radial_K3: have_disto() is always true)
+//   bool localizeImage(idx, pose, data, covariance, rmse, trackedFeatures, inliers)       :77-108
+//        SfM_Localizer::Localize(P3P_KE_CVPR17, imageSize, &cam, {error_max = +inf, max_iteration = 256}, pose)
+//        = a-contrario RANSAC over P3P  ->  clc_pnp_acransac;  success iff inliers > 2.5 x 3 (SfM_Localizer::Localize);
+//        then refine()
+//   bool refine(idx, pose, matchData, poseCovariance, rmse)                               :110-177
+//        PoseRefiner::refinePose (Ceres, Huber(4^2), pose only) + 6x6 covariance  ->  clc_pnp_refine;
+//        rmse = mean pixel distance between the observations and the reprojected inliers (the value the reference
+//        leaves in rmse after cv::projectPoints with zero distortion and fy = fx, :141-170)
+// Functions return EXIT_SUCCESS / EXIT_FAILURE through bool, i.e. FALSE MEANS SUCCESS (coloc.hpp:241,338), except
+// refine(), which like the reference returns the refiner's own status (true = refined).
+// What differs underneath: the random samples (OpenMVG's std::mt19937 stream is unpinned -- `seed` below selects
+// the documented counter-based sampler of clc_acr.h), the P3P root order and Ceres' iterates (absent submodules).
+#pragma once
+
+#include <cmath>
+#include <cstdlib>
+#include <iostream>
+#include <limits>
+#include <vector>
+
+#include "coloc_hip.h"
+#include "coloc_hip_geometry.hpp"
+
+namespace coloc {
+
+class HIPLocalizer {
+public:
+    uint64_t seed = 1;                        // sampler seed of the next localizeImage call (incremented per call)
+
+    explicit HIPLocalizer(colocParams& params)
+        : imageSize(&params.imageSize), K(&params.K), dist(&params.dist), rootFolder(&params.imageFolder)
+    {
+        const int rc = clc_ctx_create(0, nullptr, nullptr, &ctx_);
+        if (rc != CLC_OK) {
+            std::cerr << "HIPLocalizer: clc_ctx_create failed: " << clc_status_string(rc) << std::endl;
+            ctx_ = nullptr;
+        }
+    }
+    HIPLocalizer(const HIPLocalizer&) = delete;
+    HIPLocalizer& operator=(const HIPLocalizer&) = delete;
+    ~HIPLocalizer() { if (ctx_) clc_ctx_destroy(ctx_); }
+
+    bool setupTracks(openMVG::cameras::Pinhole_Intrinsic_Radial_K3* cam, colocData& data,
+                     const openMVG::features::AKAZE_Binary_Regions& queryRegions, openMVG::matching::IndMatches& trackedFeatures,
+                     openMVG::sfm::Image_Localizer_Match_Data* trackPtr)
+    {
+        trackPtr->pt3D.resize(3, trackedFeatures.size());
+        trackPtr->pt2D.resize(2, trackedFeatures.size());
+        for (size_t i = 0; i < trackedFeatures.size(); ++i) {
+            const auto& X = data.scene.GetLandmarks().at(data.mapRegionIdx[trackedFeatures[i].i_]).X;
+            for (int r = 0; r < 3; ++r) trackPtr->pt3D(r, i) = X[r];
+            const auto p = queryRegions.GetRegionPosition(trackedFeatures[i].j_);
+            openMVG::Vec2 px(static_cast<double>(p[0]), static_cast<double>(p[1]));
+            if (cam && cam->have_disto()) px = cam->get_ud_pixel(px);
+            trackPtr->pt2D(0, i) = px[0];
+            trackPtr->pt2D(1, i) = px[1];
+        }
+        return EXIT_SUCCESS;
+    }
+
+    bool localizeImage(int& idx, openMVG::geometry::Pose3& pose, colocData& data, Cov6& covariance, float& rmse,
+                       openMVG::matching::IndMatches& trackedFeatures, std::vector<uint32_t>& inliers)
+    {
+        openMVG::cameras::Pinhole_Intrinsic_Radial_K3 cam = camera(idx);
+        openMVG::sfm::Image_Localizer_Match_Data matching_data;
+        matching_data.error_max = std::numeric_limits<double>::infinity();
+        matching_data.max_iteration = 256;
+        if (setupTracks(&cam, data, *data.regions.at(idx).get(), trackedFeatures, &matching_data) == EXIT_FAILURE) {
+            std::cout << "Failure while setting up 2D-3D correspondences" << std::endl;
+            return EXIT_FAILURE;
+        }
+        if (!localize(cam, matching_data, pose)) {
+            std::cout << "Localization unsuccessful" << std::endl;
+            return EXIT_FAILURE;
+        }
+        std::cout << "Localization successful" << std::endl;
+        inliers = matching_data.vec_inliers;
+        if (!this->refine(idx, pose, matching_data, covariance, rmse)) std::cerr << "Refining pose for image failed." << std::endl;
+        return EXIT_SUCCESS;
+    }
+
+    // SfM_Localizer::Localize(P3P_KE_CVPR17, ...): true = a pose supported by more than 2.5 x 3 points was found;
+    // matching_data.vec_inliers / error_max are updated like Localize does
+    bool localize(const openMVG::cameras::Pinhole_Intrinsic_Radial_K3& cam, openMVG::sfm::Image_Localizer_Match_Data& matching_data,
+                  openMVG::geometry::Pose3& pose)
+    {
+        const int n = static_cast<int>(matching_data.pt3D.cols());
+        matching_data.vec_inliers.clear();
+        if (!ctx_ || n == 0) return false;
+        std::vector<double> X(3 * static_cast<size_t>(n)), x(2 * static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            for (int r = 0; r < 3; ++r) X[3 * i + r] = matching_data.pt3D(r, i);
+            x[2 * i] = matching_data.pt2D(0, i);
+            x[2 * i + 1] = matching_data.pt2D(1, i);
+        }
+        double Kd[9];
+        intrinsics(cam, Kd);
+        const double precision = std::isinf(matching_data.error_max) ? matching_data.error_max : matching_data.error_max * matching_data.error_max;
+        double Rt[12], emax = 0.0, nfa = 0.0;
+        std::vector<int32_t> inl(static_cast<size_t>(n));
+        int n_inl = 0, its = 0;
+        const int rc = clc_pnp_acransac(ctx_, X.data(), x.data(), n, Kd, static_cast<int>(matching_data.max_iteration), seed++, precision, Rt,
+                                        nullptr, inl.data(), &n_inl, &emax, &nfa, &its);
+        if (rc != CLC_OK) {
+            std::cerr << "HIPLocalizer: clc_pnp_acransac: " << clc_last_error_string(ctx_) << std::endl;
+            return false;
+        }
+        matching_data.vec_inliers.assign(inl.begin(), inl.begin() + n_inl);
+        if (n_inl > 0) matching_data.error_max = emax;
+        if (!(n_inl > 2.5 * 3)) return false;                    // bResection = inliers > 2.5 * MINIMUM_SAMPLES
+        pose = pose_from_Rt(Rt);
+        return true;
+    }
+
+    bool refine(int& idx, openMVG::geometry::Pose3& pose, openMVG::sfm::Image_Localizer_Match_Data& matchData, Cov6& poseCovariance,
+                float& rmse)
+    {
+        const openMVG::cameras::Pinhole_Intrinsic_Radial_K3 cam = camera(idx);
+        const size_t n = matchData.vec_inliers.size();
+        if (!ctx_ || n < 3) return false;
+        std::vector<double> X(3 * n), x(2 * n);
+        for (size_t i = 0; i < n; ++i) {
+            const size_t c = matchData.vec_inliers[i];
+            for (int r = 0; r < 3; ++r) X[3 * i + r] = matchData.pt3D(r, c);
+            x[2 * i] = matchData.pt2D(0, c);
+            x[2 * i + 1] = matchData.pt2D(1, c);
+        }
+        double Kd[9], Rt0[12], Rt[12], cov[36], r = 0.0;
+        intrinsics(cam, Kd);
+        const openMVG::Vec3 t = pose.translation();
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Rt0[4 * i + j] = pose.rotation()(i, j); Rt0[4 * i + 3] = t[i]; }
+        int its = 0;
+        const int rc = clc_pnp_refine(ctx_, X.data(), x.data(), static_cast<int>(n), Kd, nullptr, Rt0, 16.0, 50, Rt, cov, &r, &its);
+        const bool refineStatus = rc == CLC_OK;
+        if (refineStatus) {
+            pose = pose_from_Rt(Rt);
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) poseCovariance(i, j) = cov[6 * i + j];
+        }
+        // mean pixel distance of the reprojected inliers (Localizer.hpp:141-170: zero distortion, fy = fx)
+        const openMVG::Vec3 tt = pose.translation();
+        double error = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            double pc[3];
+            for (int a = 0; a < 3; ++a)
+                pc[a] = pose.rotation()(a, 0) * X[3 * i] + pose.rotation()(a, 1) * X[3 * i + 1] + pose.rotation()(a, 2) * X[3 * i + 2] + tt[a];
+            const double u = Kd[0] * pc[0] / pc[2] + Kd[2], v = Kd[0] * pc[1] / pc[2] + Kd[5];
+            error += std::sqrt((x[2 * i] - u) * (x[2 * i] - u) + (x[2 * i + 1] - v) * (x[2 * i + 1] - v));
+        }
+        rmse = static_cast<float>(error / static_cast<double>(n));
+        return refineStatus;
+    }
+
+private:
+    openMVG::cameras::Pinhole_Intrinsic_Radial_K3 camera(int idx) const
+    {
+        return openMVG::cameras::Pinhole_Intrinsic_Radial_K3(imageSize->first, imageSize->second, (*K)[idx](0, 0), (*K)[idx](0, 2),
+                                                             (*K)[idx](1, 2), (*dist)[idx](0), (*dist)[idx](1), (*dist)[idx](2));
+    }
+    static void intrinsics(const openMVG::cameras::Pinhole_Intrinsic_Radial_K3& cam, double* Kd)
+    {
+        const openMVG::Vec2 pp = cam.principal_point();
+        const double k[9] = { cam.focal(), 0.0, pp[0], 0.0, cam.focal(), pp[1], 0.0, 0.0, 1.0 };
+        for (int i = 0; i < 9; ++i) Kd[i] = k[i];
+    }
+    static openMVG::geometry::Pose3 pose_from_Rt(const double* Rt)     // Pose3(R, -R^T t): KRt_From_P + Localize
+    {
+        openMVG::Mat3 R;
+        openMVG::Vec3 C;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = Rt[4 * i + j];
+        for (int i = 0; i < 3; ++i) C[i] = -(R(0, i) * Rt[3] + R(1, i) * Rt[7] + R(2, i) * Rt[11]);
+        return openMVG::geometry::Pose3(R, C);
+    }
+
+    clc_ctx* ctx_ = nullptr;
+    std::pair<int, int>* imageSize;
+    std::vector<openMVG::Mat3>* K;
+    std::vector<openMVG::Vec3>* dist;
+    std::string* rootFolder;
+};
+
+} // namespace coloc

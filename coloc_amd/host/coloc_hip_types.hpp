@@ -8,7 +8,8 @@
 //   openMVG::matching::IndMatch{i_, j_}, IndMatches, PairWiseMatches; openMVG::Pair, Pair_Set;
 //   openMVG::features::AKAZE_Binary_Regions with Features() / Descriptors() / DescriptorRawData() /
 //   RegionCount() / GetRegionPosition(); coloc::FeatureMap, DetectorOptions, MatcherOptions
-//   (include/coloc/colocData.hpp:20-42) and the slice of coloc::colocData that matchSceneWithMap reads.
+//   (include/coloc/colocData.hpp:20-42) and the slice of coloc::colocData that matchSceneWithMap / setupTracks read
+//   (regions, mapRegions, scene landmarks, mapRegionIdx); openMVG::Vec2 / Vec3.
 #pragma once
 
 #include <array>
@@ -80,8 +81,35 @@ private:
 } // namespace features
 } // namespace openMVG
 
+namespace openMVG {
+// fixed-size vectors and the landmark container: what colocData::scene exposes to Localizer::setupTracks
+// (sfm::SfM_Data::GetLandmarks().at(id).X, include/coloc/Localizer.hpp:66)
+template <size_t N>
+struct VecN {
+    std::array<double, N> v{};
+    VecN() = default;
+    VecN(double a, double b) { static_assert(N == 2, "Vec2"); v = { a, b }; }
+    VecN(double a, double b, double c) { static_assert(N == 3, "Vec3"); v = { a, b, c }; }
+    double& operator()(size_t i) { return v[i]; }
+    double operator()(size_t i) const { return v[i]; }
+    double& operator[](size_t i) { return v[i]; }
+    double operator[](size_t i) const { return v[i]; }
+};
+using Vec2 = VecN<2>;
+using Vec3 = VecN<3>;
+namespace sfm {
+struct Landmark { Vec3 X; };
+using Landmarks = std::map<IndexT, Landmark>;
+struct SfM_Data {
+    Landmarks structure;
+    const Landmarks& GetLandmarks() const { return structure; }
+};
+} // namespace sfm
+} // namespace openMVG
+
 namespace coloc {
 using FeatureMap = std::map<openMVG::IndexT, std::unique_ptr<openMVG::features::AKAZE_Binary_Regions>>;
+using Scene = openMVG::sfm::SfM_Data;
 
 struct DetectorOptions {   // include/coloc/colocData.hpp:29-36
     float scale_factor;
@@ -96,10 +124,12 @@ struct MatcherOptions {    // include/coloc/colocData.hpp:38-42
     int thresh;
     unsigned int maxkp;
 };
-// the members GPUMatcher::matchSceneWithMap reads (include/coloc/colocData.hpp:47,53)
+// the members GPUMatcher::matchSceneWithMap and Localizer::setupTracks read (include/coloc/colocData.hpp:47-56)
 struct colocData {
     FeatureMap regions;
+    Scene scene;
     std::unique_ptr<openMVG::features::AKAZE_Binary_Regions> mapRegions;
+    std::vector<openMVG::IndexT> mapRegionIdx;
 };
 namespace Utils {
 inline openMVG::Pair_Set handlePairs(int numImages) { return openMVG::exhaustivePairs(numImages); }

@@ -1,0 +1,98 @@
+// localizer_driver.cpp -- exercises HIPLocalizer / HIPRobustMatcher the way ColoC drives Localizer / RobustMatcher
+// (reference include/coloc/coloc.hpp:219-225 intraPoseEstimator, :296 filterMatchesPair -> computeRelativePose ->
+// filterEssential) and dumps the results as raw doubles for tests/test_gpu_localizer.py.
+// usage: localizer_driver <dir>    reads <dir>/loc.bin, <dir>/twoview.bin; writes <dir>/loc_out.bin, <dir>/twoview_out.bin
+#include <cstdio>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "HIPLocalizer.hpp"
+#include "HIPRobustMatcher.hpp"
+
+using namespace openMVG;
+
+static std::vector<double> slurp(const std::string& path)
+{
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    std::vector<double> v(static_cast<size_t>(f.tellg()) / 8);
+    f.seekg(0);
+    f.read(reinterpret_cast<char*>(v.data()), static_cast<std::streamsize>(v.size() * 8));
+    return v;
+}
+static void dump(const std::string& path, const std::vector<double>& v)
+{
+    std::ofstream f(path, std::ios::binary);
+    f.write(reinterpret_cast<const char*>(v.data()), static_cast<std::streamsize>(v.size() * 8));
+}
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) { std::fprintf(stderr, "usage: %s dir\n", argv[0]); return 2; }
+    const std::string dir = argv[1];
+    // ---- loc.bin: [w, h, f, ppx, ppy, k1, k2, k3, n_map, n_feat, n_match, map X (3 n_map), feature xy (2 n_feat), matches (2 n_match: map idx, feat idx)]
+    {
+        const std::vector<double> in = slurp(dir + "/loc.bin");
+        const int w = (int)in[0], h = (int)in[1];
+        Mat3 K; K(0, 0) = in[2]; K(1, 1) = in[2]; K(0, 2) = in[3]; K(1, 2) = in[4]; K(2, 2) = 1.0;
+        const Vec3 dist(in[5], in[6], in[7]);
+        const size_t n_map = (size_t)in[8], n_feat = (size_t)in[9], n_match = (size_t)in[10];
+        const double* p = in.data() + 11;
+        coloc::colocParams params({ K }, { dist }, 'E', { (size_t)w, (size_t)h }, ".", coloc::DetectorOptions{}, coloc::MatcherOptions{});
+        coloc::colocData data;
+        for (size_t i = 0; i < n_map; ++i) {
+            data.scene.structure[(IndexT)(1000 + i)].X = Vec3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);     // landmark ids are not row numbers
+            data.mapRegionIdx.push_back((IndexT)(1000 + i));
+        }
+        p += 3 * n_map;
+        data.regions[0].reset(new features::AKAZE_Binary_Regions);
+        for (size_t i = 0; i < n_feat; ++i) data.regions[0]->Features().emplace_back((float)p[2 * i], (float)p[2 * i + 1], 7.0f, 0.0f);
+        p += 2 * n_feat;
+        matching::IndMatches tracked;
+        for (size_t i = 0; i < n_match; ++i) tracked.emplace_back((IndexT)p[2 * i], (IndexT)p[2 * i + 1]);
+        coloc::HIPLocalizer localizer(params);
+        int idx = 0;
+        geometry::Pose3 pose;
+        coloc::Cov6 cov;
+        float rmse = -1.0f;
+        std::vector<uint32_t> inliers;
+        const bool status = localizer.localizeImage(idx, pose, data, cov, rmse, tracked, inliers);   // false = success
+        std::vector<double> out;
+        out.push_back(status ? 1.0 : 0.0);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out.push_back(pose.rotation()(i, j));
+        for (int i = 0; i < 3; ++i) out.push_back(pose.center()[i]);
+        for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) out.push_back(cov(i, j));
+        out.push_back(rmse);
+        out.push_back((double)inliers.size());
+        for (uint32_t v : inliers) out.push_back(v);
+        dump(dir + "/loc_out.bin", out);
+    }
+    // ---- twoview.bin: [w, h, f, ppx, ppy, n, x1 (2 n), x2 (2 n)]  (undistorted pixels)
+    {
+        const std::vector<double> in = slurp(dir + "/twoview.bin");
+        const int w = (int)in[0], h = (int)in[1];
+        const size_t n = (size_t)in[5];
+        Mat3 K; K(0, 0) = in[2]; K(1, 1) = in[2]; K(0, 2) = in[3]; K(1, 2) = in[4]; K(2, 2) = 1.0;
+        coloc::colocParams params({ K, K }, { Vec3(0, 0, 0), Vec3(0, 0, 0) }, 'E', { (size_t)w, (size_t)h }, ".", coloc::DetectorOptions{},
+                                  coloc::MatcherOptions{});
+        const cameras::Pinhole_Intrinsic_Radial_K3 camL(w, h, in[2], in[3], in[4], 0, 0, 0), camR(w, h, in[2], in[3], in[4], 0, 0, 0);
+        Mat xL(2, n), xR(2, n);
+        for (size_t i = 0; i < n; ++i) {
+            xL(0, i) = in[6 + 2 * i]; xL(1, i) = in[6 + 2 * i + 1];
+            xR(0, i) = in[6 + 2 * n + 2 * i]; xR(1, i) = in[6 + 2 * n + 2 * i + 1];
+        }
+        coloc::HIPRobustMatcher robust(params);
+        sfm::RelativePose_Info info;
+        const bool status = robust.filterEssential(&camL, &camR, xL, xR, info, params, true);
+        std::vector<double> out;
+        out.push_back(status ? 1.0 : 0.0);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out.push_back(info.essential_matrix(i, j));
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out.push_back(info.relativePose.rotation()(i, j));
+        for (int i = 0; i < 3; ++i) out.push_back(info.relativePose.center()[i]);
+        out.push_back(info.found_residual_precision);
+        out.push_back((double)info.vec_inliers.size());
+        for (uint32_t v : info.vec_inliers) out.push_back(v);
+        dump(dir + "/twoview_out.bin", out);
+    }
+    return 0;
+}

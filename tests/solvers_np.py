@@ -32,3 +32,33 @@ def numpy_p3p(Xs, xs, K):
         R = U @ np.diag([1, 1, np.sign(np.linalg.det(U @ Vt))]) @ Vt
         sols.append(np.concatenate([R, (mq - R @ mx)[:, None]], 1))
     return sols
+
+
+def undistort_k3(x, K, k, eps=1e-10):
+    """OpenMVG Pinhole_Intrinsic_Radial_K3::get_ud_pixel: bisection on r^2 (1 + k1 r^2 + k2 r^4 + k3 r^6)^2."""
+    f, pp = K[0, 0], np.array([K[0, 2], K[1, 2]])
+    out = np.zeros_like(x, dtype=np.float64)
+
+    def functor(r2):
+        t = 1.0 + r2 * (k[0] + r2 * (k[1] + r2 * k[2]))
+        return r2 * t * t
+
+    for i, p in enumerate(x):
+        c = (p - pp) / f
+        r2 = float(c @ c)
+        if r2 == 0.0:
+            out[i] = p
+            continue
+        lo = hi = r2
+        while functor(lo) > r2:
+            lo /= 1.05
+        while functor(hi) < r2:
+            hi *= 1.05
+        while eps < hi - lo:
+            mid = 0.5 * (lo + hi)
+            if functor(mid) > r2:
+                hi = mid
+            else:
+                lo = mid
+        out[i] = c * np.sqrt(0.5 * (lo + hi) / r2) * f + pp
+    return out

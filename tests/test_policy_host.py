@@ -7,11 +7,11 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_driver(out):
+def build_driver(out, source="policy_driver.cpp"):
     from coloc_amd import build
     lib = build.build()
     cmd = ["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "coloc_amd", "host"),
-           os.path.join(ROOT, "tests", "host", "policy_driver.cpp"), "-o", out, "-L", os.path.dirname(lib), "-lcoloc_hip",
+           os.path.join(ROOT, "tests", "host", source), "-o", out, "-L", os.path.dirname(lib), "-lcoloc_hip",
            "-Wl,-rpath," + os.path.dirname(lib)]
     subprocess.check_call(cmd)
     return out
@@ -19,4 +19,9 @@ def build_driver(out):
 
 def test_policy_classes_compile_and_link(tmp_path):
     exe = build_driver(str(tmp_path / "policy_driver"))
+    assert os.path.exists(exe)
+
+
+def test_localizer_and_robust_matcher_compile_and_link(tmp_path):
+    exe = build_driver(str(tmp_path / "localizer_driver"), "localizer_driver.cpp")
     assert os.path.exists(exe)
