@@ -2,7 +2,9 @@
 // over the C ABI of libcoloc_hip.so (include/coloc_hip.h).
 //
 // Same public surface: HIPDetector(DetectorOptions), detectFeaturesFile(idx, regions, imageName),
-// [USE_STREAM] detectFeaturesTopic, freeGPUMemory(), public `kps`, `desc`, `receivedImg`.
+// detectFeaturesTopic(idx, regions, imagePtr) (USE_STREAM in the reference, :188-212; here a template on the image
+// pointer type, so it compiles with cv_bridge::CvImagePtr where ROS exists and with any `->image.data / .cols / .rows`
+// holder elsewhere), freeGPUMemory(), public `kps`, `desc`, `receivedImg`, `converted_kps` (:32-35).
 // Same conventions: returns EXIT_SUCCESS / EXIT_FAILURE through T (so `false` == success, reference
 // :183); Features()[i] = {s*x, s*y, 7*s, angle} with s = pow(1.2f, scale) (:172-179; the 1.2f is
 // hard-coded in the reference independently of scale_factor and is kept); Descriptors()[i] = the 64
@@ -65,6 +67,11 @@ public:
     std::vector<Keypoint> kps;
     std::vector<uint64_t> desc;
     bool receivedImg = false;
+#ifdef COLOC_HIP_WITH_OPENCV
+    std::vector<cv::KeyPoint> converted_kps;       // GPUDetector.hpp:35 (cleared per topic frame, never filled there either)
+#else
+    std::vector<HipKeyPoint> converted_kps;
+#endif
 
     explicit HIPDetector(DetectorOptions opts) : opts_(opts)
     {
@@ -125,6 +132,16 @@ public:
             std::memcpy(&(regions[idx]->Descriptors()[i]), &(desc[i * 8]), 8 * sizeof(uint64_t));
         }
         return EXIT_SUCCESS;
+    }
+
+    // Process an image obtained from a ROS topic (GPUDetector.hpp:188-212).  ImagePtr = cv_bridge::CvImagePtr or any
+    // pointer-like whose ->image has .data / .cols / .rows (8-bit grey).  The reference's version stores x in BOTH
+    // feature coordinates (:204-205, a typo of the file variant :174-175); y is stored here.
+    template <typename ImagePtr>
+    void detectFeaturesTopic(uint8_t idx, coloc::FeatureMap& regions, ImagePtr imagePtr)
+    {
+        converted_kps.clear();
+        (void)detectFeaturesImage(idx, regions, imagePtr->image.data, imagePtr->image.cols, imagePtr->image.rows);
     }
 
     const char* lastError() const { return ctx_ ? clc_last_error_string(ctx_) : "no context"; }

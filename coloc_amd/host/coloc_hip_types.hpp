@@ -152,6 +152,11 @@ struct Keypoint {
 #endif
 
 namespace coloc {
+// cv::KeyPoint stand-in for GPUDetector::converted_kps (GPUDetector.hpp:35) when OpenCV is absent
+struct HipKeyPoint {
+    float x = 0, y = 0, size = 0, angle = -1, response = 0;
+    int octave = 0, class_id = -1;
+};
 // cv::DMatch(queryIdx, trainIdx, distance) as filled at GPUMatcher.hpp:218 when OpenCV is absent
 struct HipDMatch {
     int queryIdx, trainIdx;

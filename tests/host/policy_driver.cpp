@@ -3,6 +3,8 @@
 // InterfaceDisk.hpp:15) and dumps the results as raw files for tests/test_gpu_policy.py to compare
 // with the oracle.  usage: policy_driver <dir> <ncams> <width> <height> <maxkp>
 #include <cstdio>
+#include <cstring>
+#include <vector>
 #include <fstream>
 #include <string>
 
@@ -61,6 +63,24 @@ int main(int argc, char** argv)
         dump(dir + "/kps" + std::to_string(c) + ".bin", detector.kps.data(), detector.kps.size() * sizeof(Keypoint));
         dump(dir + "/desc" + std::to_string(c) + ".bin", data.regions[c]->DescriptorRawData(), data.regions[c]->RegionCount() * 64);
         dump(dir + "/feat" + std::to_string(c) + ".bin", data.regions[c]->Features().data(), data.regions[c]->RegionCount() * 16);
+    }
+    // the topic entry (GPUDetector.hpp:188-212) with a cv_bridge-shaped holder: same regions as the file entry
+    {
+        struct Img { unsigned char* data; int cols, rows; };
+        struct Holder { Img image; };
+        std::vector<uint8_t> pix;
+        int w = 0, h = 0;
+        std::string name = dir + "/img0.pgm";
+        if (!coloc::hip_detail::read_pgm(name, pix, w, h)) return 1;
+        Holder holder{ { pix.data(), w, h } };
+        coloc::FeatureMap topic;
+        detector.detectFeaturesTopic(0, topic, &holder);
+        if (topic.count(0) == 0 || topic[0]->RegionCount() != data.regions[0]->RegionCount() || !detector.converted_kps.empty() ||
+            std::memcmp(topic[0]->DescriptorRawData(), data.regions[0]->DescriptorRawData(), topic[0]->RegionCount() * 64) != 0 ||
+            std::memcmp(topic[0]->Features().data(), data.regions[0]->Features().data(), topic[0]->RegionCount() * 16) != 0) {
+            std::fprintf(stderr, "detectFeaturesTopic differs from detectFeaturesFile\n");
+            return 1;
+        }
     }
     // bad file -> EXIT_FAILURE (true), nothing inserted
     {
