@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--per-camera-launches", action="store_true",
                     help="describe each camera with its own pyramid + CLATCH launch pair (the reference's call pattern) "
                          "instead of the batched entry point")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "clc-rccl", "clc-peer"],
+                    help="N > 1 only. torch = torch.distributed all_gather_into_tensor (default). clc-rccl / clc-peer = the C entry points "
+                         "clc_mc_gather_dev + clc_mc_match_dev (ncclAllGather, or IPC peer copies + a 4-byte fence collective); the "
+                         "rendezvous id travels through torch.distributed.  Not exercised on hardware yet: no multi-GPU box in the build loop")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events)")
     args = ap.parse_args()
 
@@ -149,7 +153,20 @@ def main():
     kp_ptrs = [t.data_ptr() for t in kps]
     desc_ptrs = [(arena[c] if world == 1 else mine).data_ptr() for c in cams]
 
+    mc = None
+    if world > 1 and args.exchange != "torch" and args.backend == "nccl":
+        from coloc_amd import MultiCam
+        box = [MultiCam.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        mc = MultiCam(ctx, world=world, rank=rank, maxkp=NKP, unique_id=box[0])
+        mc_mode = 0 if args.exchange == "clc-rccl" else 1
+
     def step():
+        if mc is not None:
+            ctx.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP], [mine.data_ptr()], sptr)
+            mc.gather_dev(mine.data_ptr(), NKP, mode=mc_mode, stream=sptr)
+            mc.match_dev(THR, d_match.data_ptr(), d_match.numel(), stream=sptr)
+            return
         if args.per_camera_launches:
             for k, c in enumerate(cams):
                 ctx.pyramid_build_dev(img_ptrs[k], W, H, W, sptr)
@@ -325,8 +342,9 @@ def main():
                        "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6},
             "roofline": roof,
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
-            "collective": ("none" if world == 1 else ("RCCL all_gather_into_tensor" if args.backend == "nccl"
-                                                      else "REHEARSAL: gloo all_gather staged through host memory")),
+            "collective": ("none" if world == 1 else (("RCCL all_gather_into_tensor" if mc is None else
+                                                       "clc_mc_gather_dev: " + ("ncclAllGather" if mc_mode == 0 else "IPC peer copies + 4-byte fence all-gather"))
+                                                      if args.backend == "nccl" else "REHEARSAL: gloo all_gather staged through host memory")),
             "allgather_us_rank0": allgather_us,
         }
         # Everything below is reported next to the headline line and never takes it down: each section runs guarded, a

@@ -7,7 +7,7 @@ orchestration (torch.distributed is plumbing only).  There is NO CPU fallback: l
 loudly when the HIP library is missing.
 """
 from .abi import (CLCError, Context, DetectorOptions, MatcherOptions, KP_DTYPE, lib_path, load_library,  # noqa: F401
-                  keypoints_to_features, cov_intersection)
+                  keypoints_to_features, cov_intersection, MultiCam, mc_plan)
 
 __all__ = ["CLCError", "Context", "DetectorOptions", "MatcherOptions", "KP_DTYPE", "lib_path",
-           "load_library", "keypoints_to_features", "cov_intersection"]
+           "load_library", "keypoints_to_features", "cov_intersection", "MultiCam", "mc_plan"]

@@ -32,6 +32,10 @@ class MatcherOptions(C.Structure):    # coloc::MatcherOptions, colocData.hpp:38-
     _fields_ = [("distRatio", C.c_float), ("thresh", C.c_int), ("maxkp", C.c_uint32)]
 
 
+class McShare(C.Structure):           # clc_mc_share
+    _fields_ = [("first", C.c_int32), ("second", C.c_int32), ("q_begin", C.c_uint32), ("nq", C.c_uint32), ("out_offset", C.c_uint32)]
+
+
 class MatchJob(C.Structure):          # clc_match_job
     _fields_ = [("q_offset", C.c_uint32), ("nq", C.c_uint32), ("t_offset", C.c_uint32), ("nt", C.c_uint32),
                 ("out_offset", C.c_uint32), ("threshold", C.c_uint32)]
@@ -46,7 +50,8 @@ EXPORTS = [
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
-    "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check",
+    "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
+    "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -139,6 +144,16 @@ def load_library():
     lib.clc_pnp_acransac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, vp, vp, vp, ip, dp, dp, ip]
     lib.clc_pnp_localize_ac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, vp, ip, dp, dp]
     lib.clc_essential_acransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, ip, dp, dp, ip]
+    lib.clc_mc_plan.argtypes = [vp, ci, ci, ci, ci, vp, ci, ip]
+    lib.clc_mc_unique_id.argtypes = [vp]
+    lib.clc_mc_create.argtypes = [vp, vp, ci, ci, ci, C.POINTER(vp)]
+    lib.clc_mc_destroy.argtypes = [vp]
+    lib.clc_mc_last_error_string.argtypes = [vp]
+    lib.clc_mc_last_error_string.restype = C.c_char_p
+    lib.clc_mc_arena.argtypes = [vp, C.POINTER(vp), ip, ip]
+    lib.clc_mc_gather_dev.argtypes = [vp, vp, ci, ci, vp, vp]
+    lib.clc_mc_virtual_put.argtypes = [vp, ci, vp, ci, vp]
+    lib.clc_mc_match_dev.argtypes = [vp, ci, vp, ci, vp, ci, ip, vp]
     lib.clc_k2nn_clock_check.argtypes = [vp, vp, ci, vp, ci, vp, vp, dp, dp, dp, ip]
     lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
     lib.clc_k2nn_queries_per_block.argtypes = [vp]
@@ -161,6 +176,70 @@ def cov_intersection(CA, CB, ca, cb):
     if rc != CLC_OK:
         raise CLCError(rc, lib.clc_status_string(rc).decode())
     return om.value, cov.reshape(3, 3), pos
+
+
+def mc_plan(counts, world, rank, grain):
+    """clc_mc_plan: the shares of `rank` as a list of (first, second, q_begin, nq, out_offset)."""
+    lib = load_library()
+    cnt = (C.c_int * len(counts))(*[int(c) for c in counts])
+    cap = len(counts) * len(counts) + 2
+    out = (McShare * cap)()
+    n = C.c_int()
+    rc = lib.clc_mc_plan(cnt, len(counts), int(world), int(rank), int(grain), out, cap, C.byref(n))
+    if rc != CLC_OK:
+        raise CLCError(rc, lib.clc_status_string(rc).decode())
+    return [(s.first, s.second, s.q_begin, s.nq, s.out_offset) for s in out[:n.value]]
+
+
+class MultiCam:
+    """clc_mc handle: one rank of the multi-camera exchange + match step (world = 1: no RCCL needed)."""
+
+    def __init__(self, ctx, world=1, rank=0, maxkp=10000, unique_id=None):
+        self.lib, self.ctx = load_library(), ctx
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * 128)(*unique_id) if unique_id is not None else None
+        rc = self.lib.clc_mc_create(ctx.h, idbuf, world, rank, maxkp, C.byref(h))
+        if rc != CLC_OK:
+            raise CLCError(rc, "clc_mc_create: " + self.lib.clc_status_string(rc).decode())
+        self.h, self.world, self.maxkp = h, world, maxkp
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.clc_mc_unique_id(buf)
+        if rc != CLC_OK:
+            raise CLCError(rc, "clc_mc_unique_id: " + lib.clc_status_string(rc).decode())
+        return bytes(buf)
+
+    def _chk(self, rc):
+        if rc != CLC_OK:
+            raise CLCError(rc, "%s: %s" % (self.lib.clc_status_string(rc).decode(), self.lib.clc_mc_last_error_string(self.h).decode()))
+
+    def arena(self):
+        p = C.c_void_p()
+        self._chk(self.lib.clc_mc_arena(self.h, C.byref(p), None, None))
+        return p.value
+
+    def gather_dev(self, d_my_desc, my_count, mode=0, stream=None):
+        cnt = (C.c_int * self.world)()
+        self._chk(self.lib.clc_mc_gather_dev(self.h, d_my_desc, int(my_count), int(mode), cnt, stream))
+        return [int(c) for c in cnt]
+
+    def virtual_put(self, other_rank, d_desc, count, stream=None):
+        self._chk(self.lib.clc_mc_virtual_put(self.h, int(other_rank), d_desc, int(count), stream))
+
+    def match_dev(self, threshold, d_match, capacity, stream=None):
+        cap = self.world * self.world + 2
+        sh = (McShare * cap)()
+        n = C.c_int()
+        self._chk(self.lib.clc_mc_match_dev(self.h, int(threshold), d_match, int(capacity), sh, cap, C.byref(n), stream))
+        return [(s.first, s.second, s.q_begin, s.nq, s.out_offset) for s in sh[:n.value]]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.clc_mc_destroy(self.h)
+            self.h = None
 
 
 def keypoints_to_features(kps):

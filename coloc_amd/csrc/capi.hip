@@ -333,6 +333,8 @@ int clc_sync(clc_ctx* ctx)
 
 void* clc_stream(clc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int clc_ctx_device(const clc_ctx* ctx) { return ctx ? ctx->device : -1; }
+
 int clc_profile_enable(clc_ctx* ctx, int on)
 {
     if (!ctx) return CLC_ERR_BAD_ARG;

@@ -1,0 +1,313 @@
+// multicam.hip -- the multi-camera step behind the C ABI: one camera per GPU (one process per GPU), exchange of the
+// 512-bit descriptors over xGMI, then every rank sweeps its share of the all-pairs matching.
+//
+// The reference has no multi-GPU path: the all-pairs loop is serial over Utils::handlePairs(n) = exhaustivePairs in
+// one process (include/coloc/GPUMatcher.hpp:143-155, colocUtils.hpp:58-61).  This keeps that loop's RESULT (per
+// (first < second) pair: Q = descriptors of `first`, T = of `second`, GPUMatcher.hpp:165-172) and re-cuts the work
+// (SURVEY.md 8e): after the exchange every rank holds every camera's descriptors, so the flattened
+// (pair, query-block) sequence is dealt out in equal contiguous shares -- no second data-path collective.
+//
+// Two exchange forms, selectable per call (the payload is 640 KB per rank at 10k keypoints: latency-bound, every peer
+// block crosses exactly one xGMI link of the full mesh):
+//   CLC_MC_RCCL      ncclAllGather of the fixed-capacity block (+ a 4-byte all-gather of the counts);
+//   CLC_MC_PEER_COPY one-shot fan-out: every rank writes its block straight into each peer's arena through IPC-mapped
+//                    pointers (hipMemcpyAsync device-to-device, one xGMI hop each), and the counts' all-gather that
+//                    follows on the same stream is the fence -- a rank contributes only after its copies have drained.
+// RCCL is resolved at run time (dlopen "librccl.so.1": the copy the process already has, e.g. PyTorch's, or the
+// system one), so libcoloc_hip.so has no link-time dependency on it and single-GPU hosts never load it.
+//
+// Written against the public C ABI + the HIP runtime only.  The planner (clc_mc_plan) is pure host arithmetic and is
+// the C twin of coloc_amd/multicam.py shard_pairs (tests/test_multicam.py checks them against each other).
+#include "clc_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+extern "C" int clc_ctx_device(const clc_ctx* ctx);
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl& rccl()
+{
+    static Rccl r;
+    if (r.lib) return r;
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+    return r;
+}
+
+} // namespace
+
+struct clc_mc {
+    clc_ctx* ctx = nullptr;
+    int world = 1, rank = 0, cap = 0, device = 0;
+    ncclComm_t comm = nullptr;
+    uint8_t* d_arena = nullptr;            // [world][cap][64]
+    int32_t* d_counts = nullptr;           // [world] + my count at [world]
+    int32_t* h_counts = nullptr;           // pinned, [world] + staging slot
+    std::vector<uint8_t*> peer_arena;      // IPC-mapped arenas of the peers (own pointer at [rank]); empty until first used
+    bool peers_tried = false;
+    bool is_virtual = false;
+    std::string err;
+};
+
+namespace {
+
+int mc_fail(clc_mc* mc, int code, const char* what, hipError_t e = hipSuccess, ncclResult_t n = ncclSuccess)
+{
+    if (mc) {
+        char buf[384];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else if (n != ncclSuccess) snprintf(buf, sizeof buf, "%s: rccl error %d (%s)", what, (int)n, rccl().GetErrorString ? rccl().GetErrorString(n) : "?");
+        else snprintf(buf, sizeof buf, "%s", what);
+        mc->err = buf;
+    }
+    return code;
+}
+#define MC_HIP(mc, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return mc_fail((mc), CLC_ERR_HIP, #call, e__); } while (0)
+#define MC_NCCL(mc, call) do { ncclResult_t n__ = (call); if (n__ != ncclSuccess) return mc_fail((mc), CLC_ERR_HIP, #call, hipSuccess, n__); } while (0)
+
+// exchange the arenas' IPC handles once (through the communicator itself) and map the peers' arenas
+int open_peers(clc_mc* mc, hipStream_t st)
+{
+    if (!mc->peer_arena.empty()) return CLC_OK;
+    if (mc->peers_tried) return mc_fail(mc, CLC_ERR_STATE, "peer copy: mapping the peers' arenas failed earlier");
+    mc->peers_tried = true;
+    std::vector<uint8_t*> peers((size_t)mc->world, nullptr);
+    peers[(size_t)mc->rank] = mc->d_arena;
+    if (mc->world > 1) {
+        hipIpcMemHandle_t mine;
+        MC_HIP(mc, hipIpcGetMemHandle(&mine, mc->d_arena));
+        hipIpcMemHandle_t* d_h = nullptr;
+        MC_HIP(mc, hipMalloc((void**)&d_h, sizeof(hipIpcMemHandle_t) * (size_t)(mc->world + 1)));
+        std::vector<hipIpcMemHandle_t> all((size_t)mc->world);
+        hipError_t e = hipMemcpyAsync(d_h + mc->world, &mine, sizeof mine, hipMemcpyHostToDevice, st);
+        ncclResult_t n = ncclSuccess;
+        if (e == hipSuccess) n = rccl().AllGather(d_h + mc->world, d_h, sizeof(hipIpcMemHandle_t), ncclUint8, mc->comm, st);
+        if (e == hipSuccess && n == ncclSuccess) e = hipMemcpyAsync(all.data(), d_h, sizeof(hipIpcMemHandle_t) * (size_t)mc->world, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && n == ncclSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(d_h);
+        if (e != hipSuccess || n != ncclSuccess) return mc_fail(mc, CLC_ERR_HIP, "peer copy: IPC handle exchange", e, n);
+        for (int p = 0; p < mc->world; ++p) {
+            if (p == mc->rank) continue;
+            void* ptr = nullptr;
+            MC_HIP(mc, hipIpcOpenMemHandle(&ptr, all[(size_t)p], hipIpcMemLazyEnablePeerAccess));
+            peers[(size_t)p] = (uint8_t*)ptr;
+        }
+    }
+    mc->peer_arena.swap(peers);
+    return CLC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int clc_mc_plan(const int* counts, int ncams, int world, int rank, int grain, clc_mc_share* out, int capacity, int* n_out)
+{
+    if (!counts || ncams < 0 || world < 1 || rank < 0 || rank >= world || grain < 1 || capacity < 0 || (capacity > 0 && !out) || !n_out)
+        return CLC_ERR_BAD_ARG;
+    // flattened (pair, query block) sequence of the pairs whose two sides are non-empty, pairs in exhaustivePairs order
+    struct Blk { int32_t first, second; uint32_t blocks; };
+    std::vector<Blk> pairs;
+    uint64_t total = 0;
+    for (int i = 0; i < ncams; ++i)
+        for (int j = i + 1; j < ncams; ++j) {
+            if (counts[i] < 0 || counts[j] < 0) return CLC_ERR_BAD_ARG;
+            if (counts[i] == 0 || counts[j] == 0) continue;        // an empty side yields no matches (GPUMatcher.hpp:150)
+            const uint32_t nb = ((uint32_t)counts[i] + (uint32_t)grain - 1u) / (uint32_t)grain;
+            pairs.push_back({ i, j, nb });
+            total += nb;
+        }
+    const uint64_t lo = total * (uint64_t)rank / (uint64_t)world, hi = total * (uint64_t)(rank + 1) / (uint64_t)world;
+    int n = 0;
+    uint32_t out_off = 0;
+    uint64_t base = 0;
+    for (const Blk& p : pairs) {
+        const uint64_t b0 = lo > base ? lo - base : 0, b1 = hi - base < p.blocks ? hi - base : p.blocks;   // [b0, b1) of this pair
+        if (hi > base && b0 < b1) {
+            const uint32_t q_begin = (uint32_t)b0 * (uint32_t)grain;
+            const uint32_t q_end = (uint32_t)b1 * (uint32_t)grain < (uint32_t)counts[p.first] ? (uint32_t)b1 * (uint32_t)grain : (uint32_t)counts[p.first];
+            if (n >= capacity) return CLC_ERR_CAPACITY;
+            out[n].first = p.first; out[n].second = p.second;
+            out[n].q_begin = q_begin; out[n].nq = q_end - q_begin; out[n].out_offset = out_off;
+            out_off += q_end - q_begin;
+            ++n;
+        }
+        base += p.blocks;
+        if (base >= hi) break;
+    }
+    *n_out = n;
+    return CLC_OK;
+}
+
+int clc_mc_unique_id(uint8_t id[CLC_MC_ID_BYTES])
+{
+    if (!id) return CLC_ERR_BAD_ARG;
+    static_assert(CLC_MC_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    if (!rccl().ok) return CLC_ERR_STATE;
+    ncclUniqueId u;
+    if (rccl().GetUniqueId(&u) != ncclSuccess) return CLC_ERR_HIP;
+    memcpy(id, u.internal, CLC_MC_ID_BYTES);
+    return CLC_OK;
+}
+
+int clc_mc_create(clc_ctx* ctx, const uint8_t id[CLC_MC_ID_BYTES], int world, int rank, int maxkp, clc_mc** out)
+{
+    if (!ctx || !out || world < 1 || rank < 0 || rank >= world || maxkp < 1) return CLC_ERR_BAD_ARG;
+    *out = nullptr;
+    clc_mc* mc = new (std::nothrow) clc_mc;
+    if (!mc) return CLC_ERR_HIP;
+    mc->ctx = ctx; mc->world = world; mc->rank = rank; mc->cap = maxkp; mc->device = clc_ctx_device(ctx);
+    auto bail = [&](int code) { clc_mc_destroy(mc); return code; };
+    if (hipSetDevice(mc->device) != hipSuccess) return bail(CLC_ERR_HIP);
+    mc->is_virtual = world > 1 && !id;      // rehearsal group: no communicator, the caller plays the other ranks (clc_mc_virtual_put)
+    if (world > 1 && id) {
+        if (!rccl().ok) return bail(CLC_ERR_STATE);                 // no RCCL in this process / on this machine
+        ncclUniqueId u;
+        memcpy(u.internal, id, CLC_MC_ID_BYTES);
+        if (rccl().CommInitRank(&mc->comm, world, u, rank) != ncclSuccess) return bail(CLC_ERR_HIP);
+    }
+    if (hipMalloc((void**)&mc->d_arena, (size_t)world * (size_t)maxkp * CLC_DESC_BYTES) != hipSuccess) return bail(CLC_ERR_HIP);
+    if (hipMalloc((void**)&mc->d_counts, sizeof(int32_t) * (size_t)(world + 1)) != hipSuccess) return bail(CLC_ERR_HIP);
+    if (hipHostMalloc((void**)&mc->h_counts, sizeof(int32_t) * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess) return bail(CLC_ERR_HIP);
+    *out = mc;
+    return CLC_OK;
+}
+
+int clc_mc_destroy(clc_mc* mc)
+{
+    if (!mc) return CLC_ERR_BAD_ARG;
+    (void)hipSetDevice(mc->device);
+    for (int p = 0; p < (int)mc->peer_arena.size(); ++p)
+        if (p != mc->rank && mc->peer_arena[(size_t)p]) (void)hipIpcCloseMemHandle(mc->peer_arena[(size_t)p]);
+    if (mc->comm && rccl().ok) (void)rccl().CommDestroy(mc->comm);
+    if (mc->d_arena) (void)hipFree(mc->d_arena);
+    if (mc->d_counts) (void)hipFree(mc->d_counts);
+    if (mc->h_counts) (void)hipHostFree(mc->h_counts);
+    delete mc;
+    return CLC_OK;
+}
+
+const char* clc_mc_last_error_string(const clc_mc* mc) { return mc ? mc->err.c_str() : "null handle"; }
+
+int clc_mc_arena(const clc_mc* mc, void** d_arena, int* world, int* maxkp)
+{
+    if (!mc) return CLC_ERR_BAD_ARG;
+    if (d_arena) *d_arena = mc->d_arena;
+    if (world) *world = mc->world;
+    if (maxkp) *maxkp = mc->cap;
+    return CLC_OK;
+}
+
+int clc_mc_gather_dev(clc_mc* mc, const void* d_my_desc, int my_count, int mode, int* h_counts_out, void* stream)
+{
+    if (!mc || my_count < 0 || my_count > mc->cap || (my_count > 0 && !d_my_desc) || (mode != CLC_MC_RCCL && mode != CLC_MC_PEER_COPY))
+        return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_gather: bad argument");
+    MC_HIP(mc, hipSetDevice(mc->device));
+    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
+    const size_t block = (size_t)mc->cap * CLC_DESC_BYTES;
+    mc->h_counts[mc->world] = my_count;
+    MC_HIP(mc, hipMemcpyAsync(mc->d_counts + mc->world, mc->h_counts + mc->world, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (mc->world == 1 || mc->is_virtual) {
+        uint8_t* slot = mc->d_arena + (size_t)mc->rank * block;
+        if (my_count > 0 && d_my_desc != slot)
+            MC_HIP(mc, hipMemcpyAsync(slot, d_my_desc, (size_t)my_count * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
+        MC_HIP(mc, hipMemcpyAsync(mc->d_counts + mc->rank, mc->d_counts + mc->world, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    } else if (mode == CLC_MC_RCCL) {
+        // the block is gathered at its fixed capacity (rows >= my_count are padding): d_my_desc must hold maxkp rows
+        MC_NCCL(mc, rccl().AllGather(d_my_desc, mc->d_arena, block, ncclUint8, mc->comm, st));
+        MC_NCCL(mc, rccl().AllGather(mc->d_counts + mc->world, mc->d_counts, sizeof(int32_t), ncclUint8, mc->comm, st));
+    } else {
+        const int rc = open_peers(mc, st);
+        if (rc != CLC_OK) return rc;
+        for (int k = 0; k < mc->world; ++k) {                    // start with the right-hand neighbour: every link busy at once
+            const int p = (mc->rank + k) % mc->world;
+            if (my_count > 0)
+                MC_HIP(mc, hipMemcpyAsync(mc->peer_arena[(size_t)p] + (size_t)mc->rank * block, d_my_desc, (size_t)my_count * CLC_DESC_BYTES,
+                                          hipMemcpyDeviceToDevice, st));
+        }
+        // fence: a rank's contribution to this collective is enqueued behind its copies on the same stream
+        MC_NCCL(mc, rccl().AllGather(mc->d_counts + mc->world, mc->d_counts, sizeof(int32_t), ncclUint8, mc->comm, st));
+    }
+    MC_HIP(mc, hipMemcpyAsync(mc->h_counts, mc->d_counts, sizeof(int32_t) * (size_t)mc->world, hipMemcpyDeviceToHost, st));
+    MC_HIP(mc, hipStreamSynchronize(st));                          // the shares below are planned from the counts
+    if (h_counts_out) for (int c = 0; c < mc->world; ++c) h_counts_out[c] = mc->h_counts[c];
+    return CLC_OK;
+}
+
+int clc_mc_virtual_put(clc_mc* mc, int other_rank, const void* d_desc, int count, void* stream)
+{
+    if (!mc || !mc->is_virtual || other_rank < 0 || other_rank >= mc->world || count < 0 || count > mc->cap || (count > 0 && !d_desc))
+        return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_virtual_put: bad argument (only for handles created without an id)");
+    MC_HIP(mc, hipSetDevice(mc->device));
+    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
+    if (count > 0)
+        MC_HIP(mc, hipMemcpyAsync(mc->d_arena + (size_t)other_rank * (size_t)mc->cap * CLC_DESC_BYTES, d_desc, (size_t)count * CLC_DESC_BYTES,
+                                  hipMemcpyDeviceToDevice, st));
+    mc->h_counts[mc->world] = count;
+    MC_HIP(mc, hipMemcpyAsync(mc->d_counts + other_rank, mc->h_counts + mc->world, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MC_HIP(mc, hipStreamSynchronize(st));
+    return CLC_OK;
+}
+
+int clc_mc_match_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares, int share_capacity,
+                     int* n_shares, void* stream)
+{
+    if (!mc || !n_shares || match_capacity < 0 || (match_capacity > 0 && !d_match) || share_capacity < 0 || (share_capacity > 0 && !h_shares))
+        return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_match: bad argument");
+    std::vector<int> counts((size_t)mc->world);
+    for (int c = 0; c < mc->world; ++c) counts[(size_t)c] = mc->h_counts[c];
+    const int grain = clc_k2nn_queries_per_block(mc->ctx);
+    std::vector<clc_mc_share> shares((size_t)mc->world * (size_t)mc->world + 2);
+    int n = 0;
+    int rc = clc_mc_plan(counts.data(), mc->world, mc->world, mc->rank, grain, shares.data(), (int)shares.size(), &n);
+    if (rc != CLC_OK) return mc_fail(mc, rc, "mc_match: planning failed");
+    if (n > share_capacity) return mc_fail(mc, CLC_ERR_CAPACITY, "mc_match: share array too small");
+    std::vector<clc_match_job> jobs((size_t)n);
+    uint64_t rows = 0;
+    for (int k = 0; k < n; ++k) {
+        const clc_mc_share& s = shares[(size_t)k];
+        jobs[(size_t)k].q_offset = (uint32_t)s.first * (uint32_t)mc->cap + s.q_begin;
+        jobs[(size_t)k].nq = s.nq;
+        jobs[(size_t)k].t_offset = (uint32_t)s.second * (uint32_t)mc->cap;
+        jobs[(size_t)k].nt = (uint32_t)counts[(size_t)s.second];
+        jobs[(size_t)k].out_offset = s.out_offset;
+        jobs[(size_t)k].threshold = (uint32_t)threshold;
+        rows += s.nq;
+        if (h_shares) h_shares[k] = s;
+    }
+    if (rows > (uint64_t)match_capacity) return mc_fail(mc, CLC_ERR_CAPACITY, "mc_match: result buffer too small");
+    *n_shares = n;
+    if (n == 0) return CLC_OK;
+    rc = clc_match_jobs_dev(mc->ctx, mc->d_arena, jobs.data(), n, d_match, stream);
+    if (rc != CLC_OK) return mc_fail(mc, rc, clc_last_error_string(mc->ctx));
+    return CLC_OK;
+}
+
+} // extern "C"

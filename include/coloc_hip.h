@@ -108,6 +108,8 @@ const char* clc_last_error_string(const clc_ctx* ctx);
 int clc_sync(clc_ctx* ctx);
 /* The context's hipStream_t (as void*), for callers that enqueue their own work in order. */
 void* clc_stream(clc_ctx* ctx);
+/* The device the context lives on. */
+int clc_ctx_device(const clc_ctx* ctx);
 
 /* ---- kernel timing (replaces the std::chrono prints around CUDAK2NN, GPUMatcher.hpp:204-206) ---
  * When enabled, every kernel launch made through this context is bracketed by a pair of HIP
@@ -299,6 +301,48 @@ int clc_pnp_localize(clc_ctx* ctx, const double* h_X, const double* h_x, int N, 
 /* The hypotheses of the minimal solver alone: h_Rt_out receives 4 S x 12 doubles (NaN = no solution). */
 int clc_pnp_p3p(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K,
                 const int32_t* h_samples, int S, double* h_Rt_out);
+
+/* ---- several cameras on several GPUs (no counterpart in the reference) ------------------------------------------------
+ * The reference matches its cameras in a serial all-pairs loop inside one process (GPUMatcher::computeMatches,
+ * GPUMatcher.hpp:143-155 over Utils::handlePairs, colocUtils.hpp:58-61).  Here: one process (and context) per GPU, rank r
+ * owns camera r; clc_mc_gather_dev exchanges the descriptor blocks over xGMI, clc_mc_match_dev sweeps this rank's
+ * contiguous share of the flattened (pair, query block) sequence; the union over the ranks is exactly the serial loop's
+ * per-pair result (Q = descriptors of `first`, T = of `second`).  RCCL is loaded at run time (dlopen), only when
+ * world > 1.  Exchange forms: CLC_MC_RCCL = ncclAllGather of the fixed-capacity blocks; CLC_MC_PEER_COPY = every rank
+ * copies its block into each peer's arena through IPC-mapped pointers (one xGMI hop each) and a 4-byte all-gather of
+ * the counts acts as the fence. */
+#define CLC_MC_ID_BYTES 128
+enum { CLC_MC_RCCL = 0, CLC_MC_PEER_COPY = 1 };
+typedef struct clc_mc clc_mc;
+/* one contiguous run of query rows of pair (first, second) assigned to a rank */
+typedef struct clc_mc_share {
+    int32_t  first, second;  /* camera ids, first < second                                  */
+    uint32_t q_begin, nq;    /* query rows [q_begin, q_begin + nq) of camera `first`         */
+    uint32_t out_offset;     /* first int32 of this run inside the rank-local result buffer */
+} clc_mc_share;
+/* Pure host arithmetic (no GPU, no context): the shares of `rank` when `world` ranks split the all-pairs work of
+ * cameras with counts[c] descriptors, cut on `grain` queries (clc_k2nn_queries_per_block).  The C twin of
+ * coloc_amd/multicam.py shard_pairs. */
+int clc_mc_plan(const int* counts, int ncams, int world, int rank, int grain, clc_mc_share* out, int capacity, int* n_out);
+/* Rank 0 creates the rendezvous id; the HOST application hands it to the other ranks (MPI, a socket, a file ...). */
+int clc_mc_unique_id(uint8_t id[CLC_MC_ID_BYTES]);
+/* Joins the `world`-rank group on ctx's device; maxkp = capacity of a camera's descriptor block (the same on all
+ * ranks).  world == 1 needs no id and no RCCL.  world > 1 with id == NULL creates a REHEARSAL handle without a
+ * communicator: the calling process plays the other ranks with clc_mc_virtual_put (how the one-GPU tests drive every
+ * rank's share through this entry); clc_mc_gather_dev then only files the rank's own block. */
+int clc_mc_create(clc_ctx* ctx, const uint8_t id[CLC_MC_ID_BYTES], int world, int rank, int maxkp, clc_mc** out);
+int clc_mc_virtual_put(clc_mc* mc, int other_rank, const void* d_desc, int count, void* stream);
+int clc_mc_destroy(clc_mc* mc);
+const char* clc_mc_last_error_string(const clc_mc* mc);
+/* The gathered arena [world][maxkp][64 B] (valid for the handle's lifetime). */
+int clc_mc_arena(const clc_mc* mc, void** d_arena, int* world, int* maxkp);
+/* Exchange: this rank's descriptors (d_my_desc: a device buffer of maxkp rows, my_count of them valid) go to every
+ * rank's arena, the counts come back to the host (h_counts_out: world ints, nullable).  Synchronises the stream. */
+int clc_mc_gather_dev(clc_mc* mc, const void* d_my_desc, int my_count, int mode, int* h_counts_out, void* stream);
+/* Sweep this rank's shares of the gathered arena (enqueue only): d_match receives the runs back to back
+ * (share.out_offset), h_shares the shares themselves. */
+int clc_mc_match_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares,
+                     int share_capacity, int* n_shares, void* stream);
 
 /* ---- a-contrario model selection: what the reference actually runs ------------------------------------------------------
  * Localizer::localizeImage calls SfM_Localizer::Localize(P3P_KE_CVPR17, ..., {error_max = +inf, max_iteration = 256})

@@ -51,3 +51,45 @@ def test_every_ranks_jobs_reassemble_to_the_all_pairs_loop(oracle, world, counts
         assert np.array_equal(got[p], want) and np.array_equal(m, want)
         assert (want >= 0).sum() > 50
     ctx.close()
+
+
+@pytest.mark.parametrize("world,counts", [(2, [3000, 2500]), (4, [2000, 1500, 2500, 1800]), (8, [1200] * 8), (3, [700, 0, 1300])])
+def test_c_entry_points_every_rank_of_a_virtual_world(oracle, world, counts):
+    """The same reassembly through the C multi-camera entry (clc_mc_create / gather / match, coloc_amd/csrc/multicam.hip):
+    one rehearsal handle per rank on the one GPU, the other ranks' blocks filed with clc_mc_virtual_put in place of the
+    RCCL all-gather / peer copies (which need one GPU per rank and run on the driver's multi-GPU node)."""
+    import torch
+    from coloc_amd import Context, MultiCam
+    cap = max(counts)
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    descs = [synth.random_descriptors(n, seed=3100 + c) for c, n in enumerate(counts)]
+    for c in range(1, world):
+        k = min(len(descs[0]), len(descs[c])) // 2
+        descs[c][:k] = descs[0][:k]
+        descs[c][:k, c] ^= 0x5A
+    dev = [torch.from_numpy(np.ascontiguousarray(np.concatenate([d, np.zeros((cap - len(d), 64), np.uint8)]))).cuda() for d in descs]
+    results, shares_all = [], []
+    for r in range(world):
+        mc = MultiCam(ctx, world=world, rank=r, maxkp=cap)            # no id: rehearsal handle
+        for o in range(world):
+            if o != r:
+                mc.virtual_put(o, dev[o].data_ptr(), counts[o])
+        got_counts = mc.gather_dev(dev[r].data_ptr(), counts[r], mode=r % 2)
+        assert got_counts == counts
+        out = torch.full((max(1, cap * world),), -9, dtype=torch.int32, device="cuda")
+        shares = mc.match_dev(40, out.data_ptr(), cap * world)
+        ctx.sync()
+        assert shares == [(j.pair[0], j.pair[1], j.q_begin, j.nq, j.out_offset)
+                          for j in multicam.shard_pairs(counts, world, r, grain=ctx.k2nn_queries_per_block)]
+        results.append(out.cpu().numpy()); shares_all.append(shares)
+        mc.close()
+    for (i, j) in multicam.exhaustive_pairs(world):
+        if not counts[i] or not counts[j]:
+            continue
+        got = np.full(counts[i], -7, np.int32)
+        for r in range(world):
+            for (a, b, q0, nq, off) in shares_all[r]:
+                if (a, b) == (i, j):
+                    got[q0:q0 + nq] = results[r][off:off + nq]
+        assert np.array_equal(got, oracle.k2nn(descs[i], descs[j], 40))
+    ctx.close()

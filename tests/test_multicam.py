@@ -106,3 +106,19 @@ def test_world2_gloo_matches_single_process_loop(tmp_path, oracle, counts):
         im = multicam.ind_matches(got[(i, j)])
         assert im == [(int(q), int(t)) for q, t in enumerate(want) if t != -1]
         assert len(im) > 100
+
+
+def test_c_planner_equals_python_planner():
+    """clc_mc_plan (the planner a C++ host uses, coloc_amd/csrc/multicam.hip) deals out exactly the shares of
+    multicam.shard_pairs -- pure host arithmetic, callable without a GPU."""
+    from coloc_amd import mc_plan
+    rng = np.random.default_rng(3)
+    cases = [([10000] * 8, 8), ([10000, 10000], 2), ([5, 0, 700, 1300], 3), ([0, 0], 2), ([1], 1), ([257, 256, 255, 1, 4000], 4)]
+    for _ in range(40):
+        n = int(rng.integers(1, 9))
+        cases.append(([int(c) for c in rng.integers(0, 12000, n) * (rng.random(n) > 0.15)], int(rng.integers(1, 9))))
+    for counts, world in cases:
+        for grain in (128, 256):
+            for rank in range(world):
+                want = [(j.pair[0], j.pair[1], j.q_begin, j.nq, j.out_offset) for j in multicam.shard_pairs(counts, world, rank, grain=grain)]
+                assert mc_plan(counts, world, rank, grain) == want, (counts, world, rank, grain)
