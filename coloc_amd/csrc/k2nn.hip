@@ -316,12 +316,15 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     constexpr int QT = kMxQT;
     constexpr int kStride = 65;      // uint4 per k-step of a train tile in LDS: 64 lanes + 1 pad, so that the 8 k-steps
                                      // one row is expanded into land in different banks (ds_write_b128, 8 lanes per pass)
-    __shared__ u32x4 s_a[2][8 * kStride];
+    constexpr int kQRow = 17;        // dwords per staged query row: 16 + 1 pad -> the 32 rows a half-wave reads hit 32 banks
+    constexpr int kStageDw = kMxWaves * QT * 32 * kQRow;
+    constexpr int kTileDw = 2 * 8 * kStride * 4;
+    // one buffer, two lives: the prologue stages the raw query rows in it (per wave), the loop keeps the expanded train tiles
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[kStageDw > kTileDw ? kStageDw : kTileDw];
+    u32x4 (*s_a)[8 * kStride] = reinterpret_cast<u32x4 (*)[8 * kStride]>(s_mem);
     __shared__ uint32_t s_best[kMxQPerBlock], s_second[kMxQPerBlock];
     __shared__ uint32_t s_arrival;
     const K2nnJobDev& job = jobs.j[blockIdx.y];
-    // consecutive workgroups walk the splits of one query block and the planner makes `splits` a multiple of 8:
-    // with round-robin placement XCD x only sees train splits = x (mod 8) (see the popcount kernel)
     const uint32_t nblk = job.qblocks * job.splits;
     if (blockIdx.x >= nblk) return;
     const uint32_t qblock = blockIdx.x / job.splits;
@@ -329,19 +332,38 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // B operands: lane (row = l & 31, half h = l >> 5) holds the 32 k-values of words 2 j + h of its query row
+    // B operands: lane (row = l & 31, half h = l >> 5) holds the 32 k-values of words 2 j + h of its query row.
+    // The wave's 64 rows are fetched with COALESCED 16-byte loads (4 KB = four wave instructions) and handed round
+    // through the wave's own LDS staging area; every lane then picks its 8 words per tile.  (Each lane loading its own
+    // words straight from memory -- 16 strided dword loads touching 32 cache lines per instruction -- took 11 k cycles
+    // per wave, a quarter of the kernel, measured with in-kernel stamps: tools/k2nn_mfma.hip.)
     mx_v4i b[QT][8];
+    {
+        uint32_t* stage = s_mem + wave * (QT * 32 * kQRow);
+        const global_cu4_ptr qbase = (global_cu4_ptr)(uintptr_t)job.q;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        uint32_t row = qblock * kMxQPerBlock + (wave * QT + qt) * 32u + (lane & 31u);
-        if (row >= job.nq) row = job.nq - 1u;                       // clamp: duplicate work, never stored
-        const global_cu32_ptr qp = (global_cu32_ptr)(uintptr_t)job.q + (size_t)row * 16u + (lane >> 5);
+        for (int i = 0; i < 2 * QT; ++i) {
+            const uint32_t idx = (uint32_t)i * 64u + lane;               // 16-byte chunk of the wave's QT x 32 rows
+            const uint32_t r_local = idx >> 2, chunk = idx & 3u;
+            uint32_t row = qblock * kMxQPerBlock + wave * (QT * 32u) + r_local;
+            if (row >= job.nq) row = job.nq - 1u;                        // clamp: duplicate work, never stored
+            const u32x4 v = qbase[(size_t)row * 4u + chunk];
+            uint32_t* d = stage + r_local * kQRow + chunk * 4u;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const u32x4 v = mx_expand(qp[2 * j]);
-            b[qt][j] = mx_v4i{ (int)v.x, (int)v.y, (int)v.z, (int)v.w };
+        for (int qt = 0; qt < QT; ++qt) {
+            const uint32_t* src = stage + ((uint32_t)qt * 32u + (lane & 31u)) * kQRow + (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const u32x4 v = mx_expand(src[2 * j]);
+                b[qt][j] = mx_v4i{ (int)v.x, (int)v.y, (int)v.z, (int)v.w };
+            }
         }
     }
+    __syncthreads();                 // the staging area becomes the train-tile buffer
     // C of the first MFMA of a tile: 2^23 + 2^21 + index (inside the split) of the lane's 16 train rows
     // (C/D layout of the 32x32 forms: column = lane & 31, row = 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3))
     float cinit[16];
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     for (int qt = 0; qt < QT; ++qt) { best[qt] = __uint_as_float(kMxInf); second[qt] = __uint_as_float(kMxInf); }
 
     // this workgroup's train rows [s0, s1): t_per_split is a multiple of 32, so only the train set's last tile can be partial
-    const uint32_t s0 = min(split * job.t_per_split, job.nt);       // (the planner may pad with empty trailing splits)
+    const uint32_t s0 = min(split * job.t_per_split, job.nt);
     const uint32_t s1 = min(s0 + job.t_per_split, job.nt);
     const uint32_t ntiles = (s1 - s0 + 31u) >> 5;
     const int scale_a = 0x8B8B8B8B, scale_b = 0x7F7F7F7F;            // E8M0 block scales: 2^12 (trains), 1 (queries)
@@ -560,7 +582,10 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         total_qblocks += jobs[j].qblocks;
     }
     if (total_qblocks == 0) total_qblocks = 1;
-    uint32_t want = ((uint32_t)target_blocks + total_qblocks - 1) / total_qblocks;
+    // popcount: about target_blocks workgroups, several rounds of them; matrix: at most target_blocks (= the resident
+    // slots, 3 workgroups per CU), so that the whole grid runs as ONE round -- a partial second round costs a full
+    // round's time at a fraction of the machine
+    uint32_t want = mx ? (uint32_t)target_blocks / total_qblocks : ((uint32_t)target_blocks + total_qblocks - 1) / total_qblocks;
     if (want < 1) want = 1;
     size_t off = 0;
     for (int j = 0; j < njobs; ++j) {
@@ -570,8 +595,9 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         const uint32_t min_per = mx ? 64u : 16u * kWaves;
         const uint32_t max_splits = jb.nt / min_per > 0 ? jb.nt / min_per : 1u;
         if (splits > max_splits) splits = max_splits;
-        // a multiple of 8 splits pins train split s to XCD s & 7 (see the sweep kernels)
-        if (xcd_map && splits >= 8u) splits = (splits + 4u) / 8u * 8u > max_splits ? splits / 8u * 8u : (splits + 4u) / 8u * 8u;
+        // popcount: a multiple of 8 splits pins train split s to XCD s & 7 (see that kernel).  The matrix kernel reads the
+        // 64-byte rows themselves (a 10k-row set is 640 KB: every XCD's L2 holds all of it), so it keeps the exact count.
+        if (!mx && xcd_map && splits >= 8u) splits = (splits + 4u) / 8u * 8u > max_splits ? splits / 8u * 8u : (splits + 4u) / 8u * 8u;
         uint32_t per = jb.nt ? (jb.nt + splits - 1) / splits : 1u;
         if (mx) {
             per = (per + 31u) & ~31u;                                     // whole tiles of 32 train rows
@@ -579,9 +605,6 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         }
         if (per > kIdxMask + 1u) per = kIdxMask + 1u;                     // index field is 22 bits
         splits = jb.nt ? (jb.nt + per - 1) / per : 1u;
-        // rounding `per` up to whole tiles can leave a split count that is not a multiple of 8: pad it with empty
-        // trailing splits (their workgroups only take part in the arrival count) to keep the XCD pinning
-        if (mx && xcd_map && splits >= 8u) splits = (splits + 7u) & ~7u;
         jb.splits = splits;
         jb.t_per_split = per;
         jb.nq_pad = (jb.nq + 63u) & ~63u;

@@ -176,13 +176,15 @@ __device__ __forceinline__ u32x4 expand32(uint32_t x)
     return y;
 }
 
-template <int QT, int XCD>
+template <int QT, int XCD, int ABL = 0>
 __global__ __launch_bounds__(256) void fused_kernel(const uint32_t* __restrict__ Q, const uint32_t* __restrict__ T, uint32_t nq,
                                                     uint32_t nt, uint32_t qblocks, uint32_t splits, uint32_t tiles_per_split,
                                                     uint2* __restrict__ partial, uint32_t nq_pad)
 {
     constexpr int kStride = 65;                              // uint4 per k-step in LDS (64 + 1 pad)
     __shared__ u32x4 s_a[2][8 * kStride];
+    const uint64_t tk_entry = ABL == 9 ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t rt_entry = ABL == 9 ? __builtin_amdgcn_s_memrealtime() : 0;
     uint32_t bid = blockIdx.x;
     if (XCD) {                                               // consecutive ids round-robin over 8 XCDs: give XCD x the splits = x mod 8
         const uint32_t per = gridDim.x >> 3;                 // host makes gridDim.x a multiple of 8 and splits a multiple of 8
@@ -224,13 +226,22 @@ __global__ __launch_bounds__(256) void fused_kernel(const uint32_t* __restrict__
         return *reinterpret_cast<const uint2*>(T + (size_t)row * 16u + 2u * my_j);
     };
     uint2 r0 = load_bits(tb), r1 = load_bits(min(tb + 1u, te - 1u));
+    uint64_t ph[5] = { 0, 0, 0, 0, 0 }, tk0 = 0, tk_start = 0;
+    if (ABL == 9) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tk_start = __builtin_amdgcn_s_memtime(); }
+#define STAMP(i) if (ABL == 9) { const uint64_t now = __builtin_amdgcn_s_memtime(); ph[i] += now - tk0; tk0 = now; }
     for (uint32_t t = tb; t < te; ++t) {
+        if (ABL == 9) tk0 = __builtin_amdgcn_s_memtime();
         const uint32_t buf = (t - tb) & 1u;
-        s_a[buf][dst] = expand32(~r0.x);
-        s_a[buf][dst + 32] = expand32(~r0.y);
+        if (ABL != 3) {
+            s_a[buf][dst] = expand32(~r0.x);
+            s_a[buf][dst + 32] = expand32(~r0.y);
+        }
         r0 = r1;
-        __syncthreads();
-        if (t + 2u < te) r1 = load_bits(t + 2u);
+        if (ABL == 9) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+        STAMP(0)
+        if (ABL != 3 && ABL != 5) __syncthreads();
+        STAMP(1)
+        if (ABL != 4 && t + 2u < te) r1 = load_bits(t + 2u);
         if (t + 1u == t_tiles && (nt & 31u)) {
             const uint32_t valid = nt & 31u;
 #pragma unroll
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256) void fused_kernel(const uint32_t* __restrict__
         v16f acc[QT];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const u32x4 av = s_a[buf][j * kStride + lane];
+            const u32x4 av = ABL == 3 ? u32x4{ r0.x + j, r0.y, r1.x, r1.y } : s_a[buf][j * kStride + lane];
             const v8i a8 = { (int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0 };
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -250,7 +261,8 @@ __global__ __launch_bounds__(256) void fused_kernel(const uint32_t* __restrict__
 #pragma unroll
                     for (int i = 0; i < 16; ++i) c[i] = cinit[i];
                 } else c = acc[qt];
-                acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, scale_a, 0, scale_b);
+                if (ABL == 2) { acc[qt] = c; acc[qt][j] += __int_as_float(a8[0] ^ b8[1]); }
+                else acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4, 4, 0, scale_a, 0, scale_b);
             }
         }
 #pragma unroll
@@ -263,6 +275,158 @@ __global__ __launch_bounds__(256) void fused_kernel(const uint32_t* __restrict__
         }
 #pragma unroll
         for (int i = 0; i < 16; ++i) cinit[i] += 32.0f;
+        if (ABL == 9) { asm volatile("" : "+v"(best[0]), "+v"(second[0]), "+v"(best[QT - 1]), "+v"(second[QT - 1])); }
+        STAMP(3)
+    }
+    const uint64_t tk_loop_end = ABL == 9 ? __builtin_amdgcn_s_memtime() : 0;
+
+    const uint32_t t0 = tb * 32u;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const uint32_t mb = __float_as_uint(best[qt]), ms = __float_as_uint(second[qt]);
+        const uint32_t ob = __shfl_xor(mb, 32), os = __shfl_xor(ms, 32);
+        const uint32_t s = min(min(ms, os), max(mb, ob));
+        const uint32_t bb = min(mb, ob);
+        const uint32_t q = ((qblock * 4u + wave) * QT + qt) * 32u + (lane & 31u);
+        if (lane < 32u && q < nq) {
+            auto decode = [&](uint32_t key) -> uint32_t {
+                const uint32_t rel = key - kMagic;
+                const uint32_t d = rel >> kIdxBits;
+                if (key == kInfBits || d > 512u) return kEmptyKey;
+                return (d << 22) | (t0 + (rel & ((1u << kIdxBits) - 1u)));
+            };
+            partial[(size_t)split * nq_pad + q] = make_uint2(decode(bb), decode(s));
+        }
+    }
+    if (ABL == 9) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            uint64_t* o = reinterpret_cast<uint64_t*>(partial) + (size_t)nq_pad * splits + ((size_t)blockIdx.x * 4 + wave) * 8;
+            o[0] = ph[0]; o[1] = ph[1]; o[2] = tk_start - tk_entry; o[3] = ph[3]; o[4] = tk_loop_end - tk_start; o[5] = te - tb;
+            o[6] = __builtin_amdgcn_s_memtime() - tk_loop_end; o[7] = rt_entry;
+        }
+    }
+}
+
+// ---- pipelined fused sweep: the top-2 of tile t runs in the shadow of tile t + 1's MFMAs ---------------------------
+// Two accumulator sets per query tile; the loop body is unrolled by two so that the sets alternate without copies.
+// An MFMA blocks the SIMD's vector issue for 8 of its 32 cycles: 4 v_med3 + ~2 other VALU fit in the rest, so ONE wave
+// per SIMD can in principle keep the matrix pipe busy.  sched_group_barrier spells the interleave out for the scheduler.
+template <int QT>
+__global__ __launch_bounds__(256) void pipe_kernel(const uint32_t* __restrict__ Q, const uint32_t* __restrict__ T, uint32_t nq,
+                                                   uint32_t nt, uint32_t qblocks, uint32_t splits, uint32_t tiles_per_split,
+                                                   uint2* __restrict__ partial, uint32_t nq_pad)
+{
+    constexpr int kStride = 65;
+    __shared__ u32x4 s_a[2][8 * kStride];
+    const uint32_t bid = blockIdx.x;
+    const uint32_t qblock = bid / splits, split = bid - qblock * splits;
+    if (qblock >= qblocks) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t t_tiles = (nt + 31u) >> 5;
+    const uint32_t tb = split * tiles_per_split, te = min(tb + tiles_per_split, t_tiles);
+    if (tb >= te) return;
+    const uint32_t ntiles = te - tb;
+
+    v4i b[QT][8];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        uint32_t row = ((qblock * 4u + wave) * QT + qt) * 32u + (lane & 31u);
+        if (row >= nq) row = nq - 1u;
+        const uint32_t* qp = Q + (size_t)row * 16u + (lane >> 5);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32x4 v = expand32(qp[2 * j]);
+            b[qt][j] = v4i{ (int)v.x, (int)v.y, (int)v.z, (int)v.w };
+        }
+    }
+    v16f cinit;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) cinit[i] = 8388608.0f + 2097152.0f + (float)(8 * (i >> 2) + 4 * (int)(lane >> 5) + (i & 3));
+    float best[QT], second[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { best[qt] = __uint_as_float(kInfBits); second[qt] = __uint_as_float(kInfBits); }
+    const int scale_a = 0x8B8B8B8B, scale_b = 0x7F7F7F7F;
+    const uint32_t my_row = tid >> 3, my_j = tid & 7u;
+    const uint32_t dst = my_j * kStride + my_row;
+    auto load_bits = [&](uint32_t t) -> uint2 {
+        uint32_t row = (tb + t) * 32u + my_row;
+        if (row >= nt) row = nt - 1u;
+        return *reinterpret_cast<const uint2*>(T + (size_t)row * 16u + 2u * my_j);
+    };
+    uint2 r0 = load_bits(0u), r1 = load_bits(min(1u, ntiles - 1u));
+    auto stage = [&](uint32_t t) {                      // expand tile t (bits in r0) into LDS, queue the bits of t + 2
+        const uint32_t buf = t & 1u;
+        s_a[buf][dst] = expand32(~r0.x);
+        s_a[buf][dst + 32] = expand32(~r0.y);
+        r0 = r1;
+        __syncthreads();
+        if (t + 2u < ntiles) r1 = load_bits(t + 2u);
+        if (tb + t + 1u == t_tiles && (nt & 31u)) {
+            const uint32_t valid = nt & 31u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if ((uint32_t)(8 * (i >> 2) + 4 * (int)(lane >> 5) + (i & 3)) >= valid) cinit[i] += 4194304.0f + 8192.0f;
+        }
+    };
+    // MFMAs of tile t into `cur`, top-2 of the previous tile's `old` interleaved (have_old = false: prologue)
+    auto compute = [&](uint32_t t, v16f (&cur)[QT], v16f (&old)[QT], const bool have_old) {
+        const uint32_t buf = t & 1u;
+        v4i a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32x4 av = s_a[buf][j * kStride + lane];
+            a[j] = v4i{ (int)av.x, (int)av.y, (int)av.z, (int)av.w };
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const v8i a8 = { a[j].x, a[j].y, a[j].z, a[j].w, 0, 0, 0, 0 };
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const v8i b8 = { b[qt][j].x, b[qt][j].y, b[qt][j].z, b[qt][j].w, 0, 0, 0, 0 };
+                cur[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, j == 0 ? cinit : cur[qt], 4, 4, 0, scale_a, 0, scale_b);
+            }
+        }
+        if (have_old) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    second[qt] = fmed3(best[qt], second[qt], old[qt][i]);
+                    best[qt] = fmed3(best[qt], old[qt][i], 0.0f);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cinit[i] += 32.0f;
+        // the interleave: per MFMA four top-2 instructions of the previous tile (+ the odd cinit add)
+        if (have_old) {
+#pragma unroll
+            for (int k = 0; k < 8 * QT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (32 * QT + 16) / (8 * QT), 0);
+            }
+        }
+    };
+    v16f accA[QT], accB[QT];
+    stage(0u);
+    compute(0u, accA, accB, false);
+    uint32_t t = 1;
+    for (; t + 1u < ntiles; t += 2) {
+        stage(t);
+        compute(t, accB, accA, true);
+        stage(t + 1u);
+        compute(t + 1u, accA, accB, true);
+    }
+    v16f (*last)[QT] = &accA;
+    if (t < ntiles) { stage(t); compute(t, accB, accA, true); last = &accB; }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            second[qt] = fmed3(best[qt], second[qt], (*last)[qt][i]);
+            best[qt] = fmed3(best[qt], (*last)[qt][i], 0.0f);
+        }
     }
 
     const uint32_t t0 = tb * 32u;
@@ -335,7 +499,8 @@ static int run_case(int nq, int nt, int target_blocks, int reps, bool verify)
     uint32_t *dQ, *dT; u32x4 *dQx, *dTx; uint2* dP;
     CHECK(hipMalloc(&dQ, Q.size() * 4)); CHECK(hipMalloc(&dT, T.size() * 4));
     CHECK(hipMalloc(&dQx, (size_t)q_tiles * 8192)); CHECK(hipMalloc(&dTx, (size_t)t_tiles * 8192));
-    CHECK(hipMalloc(&dP, (size_t)splits * nq_pad * 8));
+    const size_t stamp_words = (size_t)qblocks * splits * 4 * 8;
+    CHECK(hipMalloc(&dP, (size_t)splits * nq_pad * 8 + stamp_words * 8));
     CHECK(hipMemcpy(dQ, Q.data(), Q.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(dT, T.data(), T.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemset(dP, 0xFF, (size_t)splits * nq_pad * 8));
@@ -353,6 +518,12 @@ static int run_case(int nq, int nt, int target_blocks, int reps, bool verify)
         if (MODE == 0)
             hipLaunchKernelGGL(sweep_kernel<QT>, dim3(qblocks * splits), dim3(256), 0, 0, dQx, dTx, (uint32_t)nq, (uint32_t)nt, q_tiles,
                                splits, tps, dP, nq_pad);
+        else if (MODE == 3)
+            hipLaunchKernelGGL((pipe_kernel<QT>), dim3(qblocks * splits), dim3(256), 0, 0, dQ, dT, (uint32_t)nq, (uint32_t)nt,
+                               qblocks, splits, tps, dP, nq_pad);
+        else if (MODE >= 10)
+            hipLaunchKernelGGL((fused_kernel<QT, 0, MODE - 10>), dim3(qblocks * splits), dim3(256), 0, 0, dQ, dT, (uint32_t)nq, (uint32_t)nt,
+                               qblocks, splits, tps, dP, nq_pad);
         else
             hipLaunchKernelGGL((fused_kernel<QT, MODE == 2>), dim3(qblocks * splits), dim3(256), 0, 0, dQ, dT, (uint32_t)nq, (uint32_t)nt,
                                qblocks, splits, tps, dP, nq_pad);
@@ -367,6 +538,24 @@ static int run_case(int nq, int nt, int target_blocks, int reps, bool verify)
     printf("mode=%d QT=%d nq=%d nt=%d qblocks=%u splits=%u tiles/split=%u : expand %.2f us, sweep %.2f us, %.1f Gcmp/s\n", MODE, QT, nq, nt, qblocks,
            splits, tps, ms_expand * 1e3, ms_sweep * 1e3, (double)nq * nt / (ms_sweep * 1e-3) * 1e-9);
 
+    if (MODE == 19) {
+        std::vector<uint64_t> st(stamp_words);
+        CHECK(hipMemcpy(st.data(), (char*)dP + (size_t)splits * nq_pad * 8, stamp_words * 8, hipMemcpyDeviceToHost));
+        double sum[8] = {};
+        size_t nw = 0;
+        uint64_t rt_min = ~0ull, rt_max = 0;
+        for (size_t w = 0; w < (size_t)qblocks * splits * 4; ++w) {
+            if (st[w * 8 + 5] == 0) continue;
+            const double nt_ = (double)st[w * 8 + 5];
+            sum[0] += st[w * 8 + 0] / nt_; sum[1] += st[w * 8 + 1] / nt_; sum[3] += st[w * 8 + 3] / nt_;
+            sum[2] += (double)st[w * 8 + 2]; sum[4] += (double)st[w * 8 + 4]; sum[6] += (double)st[w * 8 + 6];
+            sum[5] += nt_;
+            rt_min = std::min(rt_min, st[w * 8 + 7]); rt_max = std::max(rt_max, st[w * 8 + 7]);
+            ++nw;
+        }
+        printf("  stamps, mean over %zu waves: per tile: expand+ds_write %.0f | barrier %.0f | rest (loads issue, ds_read, MFMA, top-2) %.0f cycles ; per wave: prologue %.0f, loop %.0f (%.1f tiles), epilogue %.0f cycles ; wave start spread %.2f us\n",
+               nw, sum[0] / nw, sum[1] / nw, sum[3] / nw, sum[2] / nw, sum[4] / nw, sum[5] / nw, sum[6] / nw, (double)(rt_max - rt_min) / 100.0);
+    }
     int bad = 0;
     if (verify) {
         std::vector<uint2> P((size_t)splits * nq_pad);
@@ -398,25 +587,13 @@ int main(int argc, char** argv)
 {
     const int target = argc > 1 ? atoi(argv[1]) : 768;
     int bad = 0;
-    bad += run_case<2, 1>(1000, 777, target, 3, true);
-    bad += run_case<2, 1>(33, 1, target, 3, true);
-    bad += run_case<2, 1>(257, 31, target, 3, true);
-    bad += run_case<2, 1>(2500, 9000, target, 3, true);
-    bad += run_case<2, 0>(10000, 10000, target, 20, true);
     bad += run_case<2, 1>(10000, 10000, target, 20, true);
-    bad += run_case<2, 2>(10000, 10000, target, 20, true);
-    bad += run_case<1, 1>(10000, 10000, target, 20, true);
-    bad += run_case<3, 1>(10000, 10000, target, 20, true);
-    for (int tb : { 512, 640, 768, 1024, 1536 }) {
-        run_case<2, 0>(10000, 10000, tb, 20, false);
-        run_case<2, 1>(10000, 10000, tb, 20, false);
-        run_case<2, 2>(10000, 10000, tb, 20, false);
-        run_case<3, 1>(10000, 10000, tb, 20, false);
+    for (int rep = 0; rep < 2; ++rep) {
+        run_case<2, 1>(10000, 10000, target, 20, false);
+        run_case<2, 19>(10000, 10000, target, 20, false);
+        run_case<1, 19>(10000, 10000, target, 20, false);
+        run_case<2, 19>(10000, 10000, 256, 20, false);
     }
-    run_case<2, 0>(20000, 20000, 2048, 10, false);
-    run_case<2, 1>(20000, 20000, 2048, 10, false);
-    run_case<2, 2>(20000, 20000, 2048, 10, false);
-    run_case<3, 2>(20000, 20000, 2048, 10, false);
     printf(bad ? "FAILED: %d mismatches\n" : "ALL OK\n", bad);
     return bad ? 1 : 0;
 }
