@@ -1,14 +1,14 @@
 #!/bin/bash
 # rocprofv3 PMC passes over the default bench run (separate passes, --pmc only; run via gpurun).
 # Usage: tools/prof_pmc.sh <tag>
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; }
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-seconds 0 > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; }
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" "$name" <<'PY'
 import csv, sys, collections
