@@ -11,6 +11,7 @@
 #include "clc_acr.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1230,24 +1231,26 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     if (h_mask && N > 0) memset(h_mask, 0, (size_t)N);
     if (N <= m || max_iteration == 0) return CLC_OK;                       // ACRANSAC: nData <= sizeSample -> (0, 0), no model
     if (N > kAcrMaxN) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 8192 correspondences per solve");
-    if (max_iteration > 65536) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 65536 iterations");
+    if (max_iteration > 500000) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 500000 iterations");
     if (kind == 1 && (img_w <= 0 || img_h <= 0)) return fail(ctx, CLC_ERR_BAD_ARG, "acransac: image size needed for the point-to-line model");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     const bool refine = kind == 0 && refine_huber > 0.0;
-    // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k ] uploaded in one copy, then scratch
-    const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1));
+    // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k | initial state | first batch's samples ] uploaded
+    // in one copy, then scratch
     const size_t samples_d = dbl(sizeof(int32_t) * kAcrMaxBatch * 5);
+    const size_t state_d = dbl(sizeof(AcrState));
+    const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d + samples_d;
     const size_t models_d = (size_t)kAcrMaxBatch * M * md;
     const size_t hyp_d = dbl(acr_hyp_bytes() * kAcrMaxBatch * M);
     const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)kAcrMaxBatch * M * N);
     const size_t idx_d = dbl(sizeof(uint32_t) * (size_t)N);
-    const size_t state_d = dbl(sizeof(AcrState)), res_d = dbl(sizeof(AcrResult)), mask_d = dbl((size_t)N);
+    const size_t res_d = dbl(sizeof(AcrResult)), mask_d = dbl((size_t)N);
     const size_t ref_d = refine ? dbl(pnp_refine_out_bytes()) : 0;
-    int rc = ensure_pnp(ctx, in_d + samples_d + models_d + hyp_d + sorted_d + 2 * idx_d + state_d + res_d + mask_d + ref_d + 16);
+    int rc = ensure_pnp(ctx, in_d + models_d + hyp_d + sorted_d + 2 * idx_d + res_d + mask_d + ref_d + 16);
     if (rc != CLC_OK) return rc;
-    // pinned: [ inputs | state mirror | result | mask | inlier list | refine record ]
+    // pinned: [ inputs | state mirror | sequence word | result | mask | inlier list | refine record ]
     const size_t inl_d = dbl(sizeof(int32_t) * (size_t)N);
-    rc = ensure_pinned(ctx, (in_d + state_d + res_d + mask_d + inl_d + ref_d) * sizeof(double) + 64);
+    rc = ensure_pinned(ctx, (in_d + state_d + 1 + res_d + mask_d + inl_d + ref_d) * sizeof(double) + 64);   // (+1: the polled word)
     if (rc != CLC_OK) return rc;
     double* d = ctx->d_pnp;
     double* d_a = d;                       d += (size_t)ad * N;
@@ -1256,13 +1259,13 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     double* d_K2 = d;                      d += 16;
     float* d_cn = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
     float* d_ck = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
+    AcrState* d_state = (AcrState*)d;      d += state_d;
     int32_t* d_samples = (int32_t*)d;      d += samples_d;
     double* d_models = d;                  d += models_d;
     AcrHyp* d_hyp = (AcrHyp*)d;            d += hyp_d;
     uint32_t* d_sorted = (uint32_t*)d;     d += sorted_d;
     uint32_t* d_best = (uint32_t*)d;       d += idx_d;
     uint32_t* d_index = (uint32_t*)d;      d += idx_d;
-    AcrState* d_state = (AcrState*)d;      d += state_d;
     AcrResult* d_res = (AcrResult*)d;      d += res_d;
     uint8_t* d_mask = (uint8_t*)d;         d += mask_d;
     double* d_ref = d;
@@ -1276,11 +1279,32 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     float* h_cn = (float*)(hK + 32);
     float* h_ck = (float*)(hK + 32 + dbl(sizeof(float) * ((size_t)N + 1)));
     acr_tables(N, m, h_cn, h_ck);
-    AcrState* h_state = (AcrState*)(hp + in_d);
-    AcrResult* h_res = (AcrResult*)(hp + in_d + state_d);
-    uint8_t* p_mask = (uint8_t*)(hp + in_d + state_d + res_d);
-    int32_t* p_inl = (int32_t*)(hp + in_d + state_d + res_d + mask_d);
-    double* p_ref = hp + in_d + state_d + res_d + mask_d + inl_d;
+    // the state ACRANSAC starts from and the first batch's samples (drawn from all data) are part of the upload
+    AcrState* h_init = (AcrState*)(hK + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)));
+    int32_t* h_samples = (int32_t*)((double*)h_init + state_d);
+    memset(h_init, 0, sizeof(AcrState));
+    h_init->min_nfa = INFINITY; h_init->error_max = INFINITY;
+    h_init->best_iter = -1;
+    h_init->reserve = max_iteration / 10;
+    h_init->n_iter = max_iteration - h_init->reserve;
+    h_init->n_index = N; h_init->index_all = 1;
+    h_init->ac_mode = std::isinf(precision) ? 1 : 0;
+    h_init->grow = 32;
+    h_init->cur_batch = h_init->n_iter < 32 ? h_init->n_iter : 32;
+    {
+        const int nb = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
+        for (int it = 0; it < nb; ++it) {
+            uint32_t pos[8];
+            clc_acr_sample(seed, (uint32_t)it, (uint32_t)N, m, pos);
+            for (int j = 0; j < m; ++j) h_samples[it * m + j] = (int32_t)pos[j];
+        }
+    }
+    unsigned long long* h_word = (unsigned long long*)(hp + in_d + state_d);
+    AcrResult* h_res = (AcrResult*)(hp + in_d + state_d + 1);
+    uint8_t* p_mask = (uint8_t*)(hp + in_d + state_d + 1 + res_d);
+    int32_t* p_inl = (int32_t*)(hp + in_d + state_d + 1 + res_d + mask_d);
+    double* p_ref = hp + in_d + state_d + 1 + res_d + mask_d + inl_d;
+    __atomic_store_n(h_word, 0ull, __ATOMIC_RELAXED);
 
     AcrProblem pb{};
     pb.kind = kind; pb.n = N; pb.m = m; pb.max_models = M; pb.model_doubles = md;
@@ -1304,22 +1328,40 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     hipStream_t st = ctx->stream;
     CLC_HIP(ctx, hipMemcpyAsync(ctx->d_pnp, hp, in_d * sizeof(double), hipMemcpyHostToDevice, st));
     prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
-    CLC_HIP(ctx, launch_acr_init(pb, max_iteration, d_state, d_samples, nullptr, st));
-    int iter = 0, n_iter = max_iteration - max_iteration / 10;
-    int batch = 32;
-    while (iter < n_iter) {
-        int B = n_iter - iter;
-        if (B > batch) B = batch;
-        if (B > kAcrMaxBatch) B = kAcrMaxBatch;
-        if (kind == 0) CLC_HIP(ctx, launch_p3p(d_a, d_b, N, d_K1, d_samples, B, d_models, st));
-        else CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, B, d_models, st));
-        CLC_HIP(ctx, launch_acr_round(pb, B, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_state, st));
-        CLC_HIP(ctx, hipStreamSynchronize(st));
-        const bool event = h_state->last_batch < B || h_state->index_all == 0;
-        iter = h_state->iter;
-        n_iter = h_state->n_iter;
-        // no meaningful model yet: look further ahead per round; afterwards the whole reserve goes in one batch
-        batch = event ? kAcrMaxBatch : (batch * 2 > kAcrMaxBatch ? kAcrMaxBatch : batch * 2);
+    // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
+    // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
+    // select straight into the next round's solve while the host is still polling (a 10 us bubble per round otherwise).
+    auto enqueue_round = [&]() -> int {
+        const int32_t* d_cnt = &d_state->cur_batch;
+        if (kind == 0) CLC_HIP(ctx, launch_p3p(d_a, d_b, N, d_K1, d_samples, kAcrMaxBatch, d_models, st, d_cnt));
+        else CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, kAcrMaxBatch, d_models, st, d_cnt));
+        CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st));
+        return CLC_OK;
+    };
+    rc = enqueue_round();
+    if (rc != CLC_OK) return rc;
+    uint32_t round = 0;
+    for (;;) {
+        rc = enqueue_round();                                          // speculative: round + 2
+        if (rc != CLC_OK) return rc;
+        // the select kernel publishes one packed word (round number, iterations consumed, iter, n_iter) in pinned memory:
+        // poll it (a stream synchronisation costs ~10 us per round); after 2 ms without progress fall back to the
+        // synchronisation, which also surfaces errors
+        ++round;
+        unsigned long long w = 0;
+        {
+            const auto t_start = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (((w = __atomic_load_n(h_word, __ATOMIC_ACQUIRE)) >> 49) < (round & 0x7FFFu)) {
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(2)) {
+                    CLC_HIP(ctx, hipStreamSynchronize(st));
+                    w = __atomic_load_n(h_word, __ATOMIC_ACQUIRE);
+                    if ((w >> 49) < (round & 0x7FFFu)) return fail(ctx, CLC_ERR_HIP, "acransac: round did not complete");
+                }
+            }
+        }
+        if ((int)(w & 0xFFFFFu) >= (int)((w >> 20) & 0xFFFFFu)) break;   // iter >= n_iter: the round enqueued ahead is empty
+        if (round > 0x7000u) return fail(ctx, CLC_ERR_STATE, "acransac: too many rounds");
     }
     CLC_HIP(ctx, launch_acr_finish(pb, d_state, d_best, d_mask, d_res, p_mask, p_inl, h_res, st));
     prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);

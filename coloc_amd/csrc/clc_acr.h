@@ -102,8 +102,9 @@ CLC_ACR_HD double clc_acr_log10(double x)
 // OpenMVG draws the minimal sample of iteration `iter` with UniformSample over the current index set from a
 // std::mt19937 stream -- a sequential stream whose bits are not pinned by anything the reference holds.  Here the
 // sample is a pure function of (seed, iteration, size of the index set): a counter-based splitmix64 stream per
-// iteration, positions drawn with rejection of repeats.  That makes the result independent of how many iterations
-// are evaluated speculatively in one batch on the GPU, and lets the sequential oracle reproduce it.
+// iteration, positions = high half of (32 random bits x n_index) (no 64-bit division on the GPU), drawn with rejection
+// of repeats.  That makes the result independent of how many iterations are evaluated speculatively in one batch on
+// the GPU, and lets the sequential oracle reproduce it.
 CLC_ACR_HD uint64_t clc_acr_mix(uint64_t z)
 {
     z += 0x9E3779B97F4A7C15ull;
@@ -120,7 +121,7 @@ CLC_ACR_HD void clc_acr_sample(uint64_t seed, uint32_t iter, uint32_t n_index, i
         bool again;
         do {
             s = clc_acr_mix(s);
-            p = (uint32_t)(s % (uint64_t)n_index);
+            p = (uint32_t)(((s >> 32) * (uint64_t)n_index) >> 32);
             again = false;
             for (int q = 0; q < j; ++q) again = again || pos[q] == p;
         } while (again);

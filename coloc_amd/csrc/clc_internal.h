@@ -141,10 +141,11 @@ size_t pnp_result_valid_offset();   // byte offset of the int32 "winning hypothe
 size_t pnp_refine_out_bytes();
 
 // the minimal solvers alone (pnp.hip), for the a-contrario rounds: S samples -> 4 S pose slots / 10 S {F, E} slots
+// d_count (nullable): the number of samples actually solved is min(S, *d_count), read on the device
 hipError_t launch_p3p(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples, int S, double* d_Rt,
-                      hipStream_t stream);
+                      hipStream_t stream, const int32_t* d_count = nullptr);
 hipError_t launch_fivept(const double* d_x1, const double* d_x2, int N, const double* d_K1, const double* d_K2, const int32_t* d_samples,
-                         int S, double* d_FE, hipStream_t stream);
+                         int S, double* d_FE, hipStream_t stream, const int32_t* d_count = nullptr);
 
 // ---- a-contrario RANSAC (acransac.hip) -----------------------------------------------------------------------
 static constexpr int kAcrMaxBatch = 128;           // iterations evaluated per round
@@ -163,13 +164,15 @@ struct AcrProblem {        // passed by value to every kernel of a solve
     double norm;           // resection: 1 / focal (residuals are scaled to the normalised camera plane); essential: 1
     uint64_t seed;
 };
-struct AcrState {          // device resident; mirrored into pinned host memory after every round
+struct AcrState {          // device resident; the host sees one packed 8-byte word of it after every round
     double min_nfa, error_max;
     double model[18];
     int32_t n_inliers, best_iter;
     int32_t iter, n_iter, reserve;
     int32_t n_index, index_all, ac_mode;
     int32_t rounds, last_batch;
+    int32_t cur_batch;     // iterations the NEXT round evaluates (the solve / nfa kernels read it from here: rounds are enqueued
+    int32_t grow;          // one ahead of the host's knowledge); grow = batch size while no event has happened (32, 64, 128)
 };
 struct AcrResult {
     double model[18];
@@ -181,10 +184,10 @@ struct AcrResult {
 };
 struct AcrHyp;
 size_t acr_hyp_bytes();
-hipError_t launch_acr_init(const AcrProblem& pb, int max_iteration, AcrState* d_state, int32_t* d_samples, AcrState* h_state, hipStream_t stream);
-// nfa + select of one batch of B iterations whose models are in d_models (B x max_models slots)
-hipError_t launch_acr_round(const AcrProblem& pb, int B, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
-                            uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, AcrState* h_state, hipStream_t stream);
+// nfa + select of one batch (state->cur_batch iterations) whose models are in d_models (max_models slots each)
+hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
+                            uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, unsigned long long* h_word,
+                            hipStream_t stream);
 hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
                              uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream);
 

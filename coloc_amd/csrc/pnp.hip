@@ -89,7 +89,8 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
                                                  const double* __restrict__ K, const int32_t* __restrict__ samples,
                                                  const int S, const int N, double* __restrict__ Rt,
                                                  const int solve_blocks, const double* __restrict__ stage_src,
-                                                 double* __restrict__ stage_dst, const int stage_n)
+                                                 double* __restrict__ stage_dst, const int stage_n,
+                                                 const int32_t* __restrict__ n_dev = nullptr)
 {
     if ((int)blockIdx.x >= solve_blocks) {
         // staging duty (clc_pnp_ransac / clc_pnp_localize): X, x, K and samples above are the caller's PINNED HOST
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
     }
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int sidx = gid >> 2, root = gid & 3;
-    if (sidx >= S) return;
+    if (sidx >= S || (n_dev && sidx >= *n_dev)) return;
     double Xs[3][3], f[3][3];
     bool ok = true;
     const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
@@ -542,10 +543,10 @@ hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const 
         const double* hK = hx + (size_t)2 * N;
         const int32_t* hSamples = (const int32_t*)(hK + 16);
         hipLaunchKernelGGL(p3p_kernel, dim3(solve_blocks + stage_blocks), dim3(64), 0, stream, hX, hx, hK, hSamples, S, N, d_Rt,
-                           solve_blocks, hs->src, const_cast<double*>(d_X), hs->n_doubles);
+                           solve_blocks, hs->src, const_cast<double*>(d_X), hs->n_doubles, (const int32_t*)nullptr);
     } else {
         hipLaunchKernelGGL(p3p_kernel, dim3(solve_blocks), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt, solve_blocks,
-                           (const double*)nullptr, (double*)nullptr, 0);
+                           (const double*)nullptr, (double*)nullptr, 0, (const int32_t*)nullptr);
     }
     hipLaunchKernelGGL(pnp_score_kernel, dim3(4 * S), dim3(256), 0, stream, (const double*)d_Rt, d_X, d_x, N, d_K, thr2, d_count, d_cost);
     hipLaunchKernelGGL(pnp_select_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_Rt,
@@ -628,13 +629,13 @@ __device__ __forceinline__ void normalise_px(const double* __restrict__ K, doubl
 __global__ __launch_bounds__(64) void fivept_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                     const double* __restrict__ K1, const double* __restrict__ K2,
                                                     const int32_t* __restrict__ samples, const int S, const int N,
-                                                    double* __restrict__ FE /* S x 10 x 18 */)
+                                                    double* __restrict__ FE /* S x 10 x 18 */, const int32_t* __restrict__ n_dev = nullptr)
 {
     // ONE sample per wave, every lane running the same problem: the solver is full of data-dependent loops (pivoting,
     // QR sweeps until deflation, inverse iteration), and 64 different problems in one wave serialise every divergent
     // branch -- measured 4.8 ms for 256 samples with a problem per lane; lane 0 writes the result
     const int sidx = blockIdx.x;
-    if (sidx >= S) return;
+    if (sidx >= S || (n_dev && sidx >= *n_dev)) return;
     double q1[5][2], q2[5][2];
     bool ok = true;
     for (int p = 0; p < 5; ++p) {
@@ -736,7 +737,7 @@ hipError_t launch_essential_ransac(const double* d_x1, const double* d_x2, int N
 {
     if (S <= 0 || N <= 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_PNP_SCORE, true, stream);
-    hipLaunchKernelGGL(fivept_kernel, dim3(S), dim3(64), 0, stream, d_x1, d_x2, d_K1, d_K2, d_samples, S, N, d_FE);
+    hipLaunchKernelGGL(fivept_kernel, dim3(S), dim3(64), 0, stream, d_x1, d_x2, d_K1, d_K2, d_samples, S, N, d_FE, (const int32_t*)nullptr);
     hipLaunchKernelGGL(epipolar_score_strided_kernel, dim3(10 * S), dim3(256), 0, stream, (const double*)d_FE, d_x1, d_x2, N, thr2,
                        d_count, d_cost);
     hipLaunchKernelGGL(epipolar_select_mask_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, (const double*)d_FE,
@@ -779,20 +780,20 @@ hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const 
 }
 
 hipError_t launch_p3p(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples, int S, double* d_Rt,
-                      hipStream_t stream)
+                      hipStream_t stream, const int32_t* d_count)
 {
     if (S <= 0 || N <= 0) return hipSuccess;
     const int solve_blocks = (4 * S + 63) / 64;
     hipLaunchKernelGGL(p3p_kernel, dim3(solve_blocks), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt, solve_blocks,
-                       (const double*)nullptr, (double*)nullptr, 0);
+                       (const double*)nullptr, (double*)nullptr, 0, d_count);
     return hipGetLastError();
 }
 
 hipError_t launch_fivept(const double* d_x1, const double* d_x2, int N, const double* d_K1, const double* d_K2, const int32_t* d_samples,
-                         int S, double* d_FE, hipStream_t stream)
+                         int S, double* d_FE, hipStream_t stream, const int32_t* d_count)
 {
     if (S <= 0 || N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fivept_kernel, dim3(S), dim3(64), 0, stream, d_x1, d_x2, d_K1, d_K2, d_samples, S, N, d_FE);
+    hipLaunchKernelGGL(fivept_kernel, dim3(S), dim3(64), 0, stream, d_x1, d_x2, d_K1, d_K2, d_samples, S, N, d_FE, d_count);
     return hipGetLastError();
 }
 
