@@ -18,6 +18,8 @@ PY
 }
 run a SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
 run b SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_RD SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS
-# (a TA_*_sum / TCP_*_sum pass hung rocprofv3 on this pool for 7 minutes: do not add those counters back)
+# (a pass with eight TA_*_sum / TCP_*_sum counters hung rocprofv3 on this pool for 7 minutes in round 1: they are derived sums
+#  over every TA / TCP instance, each instance using one of the block's few hardware counters -- see profiles/README.md;
+#  request at most two of them per pass, in a pass of their own)
 run e SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS SQ_IFETCH SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU
 run f GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_WAVES
