@@ -268,6 +268,62 @@ int orc_k2nn_omp_ex(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule
     return nthreads;
 }
 
+/* include/coloc/CPUMatcher.hpp:67-76 (computeMatchesPair), :56-65 (matchMapFeatures), :85-89 (matchSceneWithMap):
+ * matching::DistanceRatioMatch(ratio, BRUTE_FORCE_HAMMING, regions_I, regions_J, out).  OpenMVG is an empty, unpinned
+ * submodule, so this follows SURVEY.md 8(a) row a-9's statement of it (parity unpinned):
+ *   regions_I is the DATABASE, regions_J the QUERIES; per query the two smallest Hamming distances over all database
+ *   rows; keep iff (float)d1 < ratio*ratio * (float)d2 (ties at the best distance therefore never pass, so the kept
+ *   index is unambiguous); emit IndMatch(i_ = database index, j_ = query index); drop exact duplicate pairs; drop
+ *   matches whose (x_I, y_I, x_J, y_J) coordinates repeat an earlier one.
+ * Fewer than two database rows or no query gives no match.  Output: pairs[2k] = i_, pairs[2k+1] = j_, ordered by
+ * (x_I, y_I, x_J, y_J, i_, j_); the order OpenMVG's set-based pass leaves is not restated, so compare as a SET.
+ * Returns the match count; *threads_out (optional) = OpenMP threads of the distance sweep. */
+typedef struct { float x1, y1, x2, y2; int32_t i, j; } cpm_row;
+
+static int cpm_cmp(const void* a, const void* b)
+{
+    const cpm_row* p = (const cpm_row*)a; const cpm_row* q = (const cpm_row*)b;
+    if (p->x1 != q->x1) return p->x1 < q->x1 ? -1 : 1;
+    if (p->y1 != q->y1) return p->y1 < q->y1 ? -1 : 1;
+    if (p->x2 != q->x2) return p->x2 < q->x2 ? -1 : 1;
+    if (p->y2 != q->y2) return p->y2 < q->y2 ? -1 : 1;
+    if (p->i != q->i) return p->i < q->i ? -1 : 1;
+    if (p->j != q->j) return p->j < q->j ? -1 : 1;
+    return 0;
+}
+
+int orc_cpumatcher_pair(const uint8_t* desc_i, const float* xy_i, int n_i, const uint8_t* desc_j, const float* xy_j, int n_j,
+                        float ratio, int kernel, int32_t* pairs, int* threads_out)
+{
+    if (threads_out) *threads_out = 1;
+    if (n_i < 2 || n_j <= 0) return 0;
+    int32_t* m = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_j);
+    cpm_row* rows = (cpm_row*)malloc(sizeof(cpm_row) * (size_t)n_j);
+    if (!m || !rows) { free(m); free(rows); return -1; }
+    const int nthr = orc_k2nn_omp_ex(desc_j, n_j, desc_i, n_i, 1, 0, ratio, kernel, m);
+    if (threads_out) *threads_out = nthr;
+    int n = 0;
+    for (int j = 0; j < n_j; ++j) {
+        if (m[j] < 0) continue;
+        const int i = m[j];
+        cpm_row r = { xy_i[2 * i], xy_i[2 * i + 1], xy_j[2 * j], xy_j[2 * j + 1], i, j };
+        rows[n++] = r;
+    }
+    qsort(rows, (size_t)n, sizeof(cpm_row), cpm_cmp);
+    int k = 0;
+    for (int a = 0; a < n; ++a) {
+        if (k > 0) {
+            const cpm_row* p = &rows[k - 1];
+            if (p->i == rows[a].i && p->j == rows[a].j) continue;                                 /* IndMatch::getDeduplicated */
+            if (p->x1 == rows[a].x1 && p->y1 == rows[a].y1 && p->x2 == rows[a].x2 && p->y2 == rows[a].y2) continue;   /* IndMatchDecorator */
+        }
+        rows[k++] = rows[a];
+    }
+    for (int a = 0; a < k; ++a) { pairs[2 * a] = rows[a].i; pairs[2 * a + 1] = rows[a].j; }
+    free(m); free(rows);
+    return k;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* pyramid                                                                                     */
 /* ------------------------------------------------------------------------------------------ */

@@ -73,6 +73,13 @@ int orc_k2nn_omp_ex(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule
                     float ratio, int kernel, int32_t* match_out);
 int orc_k2nn_avx512_available(void);
 
+/* The whole CPU comparator of include/coloc/CPUMatcher.hpp:56-98: DistanceRatioMatch(ratio, BRUTE_FORCE_HAMMING,
+ * regions_I = database, regions_J = queries) = top-2 sweep + ratio test + IndMatch(i_ = database, j_ = query) + the two
+ * de-duplication passes (identical pairs; identical (x,y,x,y)).  xy_* are n x 2 float positions.  pairs holds 2*n_j
+ * int32; returns the match count (compare as a set -- see the definition). */
+int orc_cpumatcher_pair(const uint8_t* desc_i, const float* xy_i, int n_i, const uint8_t* desc_j, const float* xy_j, int n_j,
+                        float ratio, int kernel, int32_t* pairs, int* threads_out);
+
 /* ---- pyramid (include/coloc/GPUDetector.hpp:109-114,249-254; src/CUDALERP.cu:157-178) --- */
 
 /* Level dims: f_0 = 1, f_i = f_{i-1} * scale_factor (fp32); w_i = (uint32)((float)W / f_i + 0.5f). */

@@ -69,6 +69,22 @@ class Oracle:
                                         C.c_int(int(threshold)), C.c_float(ratio), C.c_int(kernel), _ptr(m))
         return m, nthr
 
+    def cpumatcher_pair(self, desc_i, xy_i, desc_j, xy_j, ratio=0.8, kernel=-1):
+        """CPUMatcher::computeMatchesPair (CPUMatcher.hpp:67-76): regions_I = database, regions_J = queries.
+        Returns (pairs[k,2] of (i_, j_), threads)."""
+        di = np.ascontiguousarray(desc_i, dtype=np.uint8).reshape(-1, 64)
+        dj = np.ascontiguousarray(desc_j, dtype=np.uint8).reshape(-1, 64)
+        pi = np.ascontiguousarray(xy_i, dtype=np.float32).reshape(-1, 2)
+        pj = np.ascontiguousarray(xy_j, dtype=np.float32).reshape(-1, 2)
+        assert pi.shape[0] == di.shape[0] and pj.shape[0] == dj.shape[0]
+        pairs = np.empty((max(dj.shape[0], 1), 2), dtype=np.int32)
+        thr = C.c_int(0)
+        self.lib.orc_cpumatcher_pair.restype = C.c_int
+        k = self.lib.orc_cpumatcher_pair(_ptr(di), _ptr(pi), C.c_int(di.shape[0]), _ptr(dj), _ptr(pj), C.c_int(dj.shape[0]),
+                                         C.c_float(ratio), C.c_int(kernel), _ptr(pairs), C.byref(thr))
+        assert k >= 0
+        return pairs[:k].copy(), thr.value
+
     def avx512_available(self):
         return bool(self.lib.orc_k2nn_avx512_available())
 

@@ -113,3 +113,52 @@ def test_omp_baseline_matches_k2nn_rule(oracle):
     assert nthr >= 1 and np.array_equal(m, oracle.k2nn(Q, T, 40))
     m2, _ = oracle.k2nn_omp(Q, T, rule=1, ratio=0.8)
     assert ((m2 >= 0) | (m2 == -1)).all()
+
+
+def _numpy_cpumatcher(di, pi, dj, pj, ratio=0.8):
+    """Definition-level DistanceRatioMatch(ratio, BRUTE_FORCE_HAMMING, I = database, J = queries) + both dedupe passes."""
+    bi = np.unpackbits(di, axis=1).astype(np.int32)
+    bj = np.unpackbits(dj, axis=1).astype(np.int32)
+    D = bj @ (1 - bi).T + (1 - bj) @ bi.T                    # [query j, database i]
+    r2 = np.float32(ratio) * np.float32(ratio)
+    seen_xy, out = set(), set()
+    rows = []
+    for j in range(D.shape[0]):
+        o = np.argsort(D[j], kind="stable")
+        d1, d2 = D[j, o[0]], D[j, o[1]]
+        if np.float32(d1) < r2 * np.float32(d2):
+            rows.append((float(pi[o[0], 0]), float(pi[o[0], 1]), float(pj[j, 0]), float(pj[j, 1]), int(o[0]), j))
+    for r in sorted(rows):
+        if r[:4] in seen_xy:
+            continue
+        seen_xy.add(r[:4])
+        out.add((r[4], r[5]))
+    return out
+
+
+def test_cpumatcher_pair_semantics(oracle):
+    """CPUMatcher::computeMatchesPair (CPUMatcher.hpp:67-76) restated: database = first region set, queries = second,
+    IndMatch(i_ = database, j_ = query), ratio 0.8^2 on integer distances, and the coordinate de-duplication."""
+    rng = np.random.default_rng(9)
+    Q, T = synth.planted_descriptors(300, 420, seed=77)       # Q rows are noisy copies of T rows
+    di, dj = T, Q
+    pi = rng.integers(0, 640, (di.shape[0], 2)).astype(np.float32)
+    pj = rng.integers(0, 480, (dj.shape[0], 2)).astype(np.float32)
+    # two queries at the same position matched to database rows at the same position -> one of them is dropped
+    dj[1] = dj[0]; pj[1] = pj[0]
+    pairs, nthr = oracle.cpumatcher_pair(di, pi, dj, pj)
+    want = _numpy_cpumatcher(di, pi, dj, pj)
+    assert nthr >= 1 and len(want) > 50
+    assert set(map(tuple, pairs.tolist())) == want
+    assert (pairs[:, 0] < di.shape[0]).all() and (pairs[:, 1] < dj.shape[0]).all()
+    assert not {(int(a), 1) for a, b in pairs if b == 1} or not {(int(a), 0) for a, b in pairs if b == 0}
+    # the direction matters: swapping the arguments searches the other way and swaps the roles of i_ and j_
+    swapped, _ = oracle.cpumatcher_pair(dj, pj, di, pi)
+    assert set(map(tuple, swapped.tolist())) == _numpy_cpumatcher(dj, pj, di, pi)
+    # degenerate region sets give no match
+    assert oracle.cpumatcher_pair(di[:1], pi[:1], dj, pj)[0].shape[0] == 0
+    assert oracle.cpumatcher_pair(di, pi, dj[:0], pj[:0])[0].shape[0] == 0
+    # both inner loops agree
+    for kernel in (0, 1):
+        p2, _ = oracle.cpumatcher_pair(di, pi, dj, pj, kernel=kernel)
+        assert np.array_equal(p2, pairs)
