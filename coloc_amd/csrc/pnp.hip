@@ -16,7 +16,7 @@
 // relative tolerance on `cost` in the tests.
 #include "clc_internal.h"
 #include "p3p.h"
-#include "fivept.h"
+#include "fivept_wave.h"
 
 namespace clc {
 
@@ -631,9 +631,9 @@ __global__ __launch_bounds__(64) void fivept_kernel(const double* __restrict__ x
                                                     const int32_t* __restrict__ samples, const int S, const int N,
                                                     double* __restrict__ FE /* S x 10 x 18 */, const int32_t* __restrict__ n_dev = nullptr)
 {
-    // ONE sample per wave, every lane running the same problem: the solver is full of data-dependent loops (pivoting,
-    // QR sweeps until deflation, inverse iteration), and 64 different problems in one wave serialise every divergent
-    // branch -- measured 4.8 ms for 256 samples with a problem per lane; lane 0 writes the result
+    // ONE sample per wave: the solver is full of data-dependent steps (pivoting, iterations that stop on convergence), and 64
+    // different problems in one wave serialise every divergent branch -- measured 4.8 ms for 256 samples with a problem per
+    // lane.  The wave's lanes share the work of their problem instead (csrc/fivept_wave.h); lane 0 writes the result
     const int sidx = blockIdx.x;
     if (sidx >= S || (n_dev && sidx >= *n_dev)) return;
     double q1[5][2], q2[5][2];
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64) void fivept_kernel(const double* __restrict__ x
     }
     __shared__ FptWorkspace ws;      // one problem per wave: every lane reads and writes the same values
     __shared__ double E[90];
-    const int n = ok ? fivept_solve(q1, q2, E, ws) : 0;
+    const int n = ok ? fpw::solve(q1, q2, E, ws) : 0;
     // F = K2^-T E K1^-1 for upper-triangular K = [fx s cx; 0 fy cy; 0 0 1]: K^-1 = [1/fx, -s/(fx fy), (s cy - cx fy)/(fx fy); 0, 1/fy, -cy/fy; 0 0 1]
     double A1[9], A2[9];
     {

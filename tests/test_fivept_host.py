@@ -1,0 +1,50 @@
+"""The sequential statement of the five-point solver (coloc_amd/csrc/fivept.h: null space -> ten cubic constraints ->
+Gauss-Jordan -> action matrix -> Hessenberg + balancing -> Ehrlich-Aberth eigenvalues -> (y, z) -> polish), run on the
+host.  It is the role of OpenMVG's essential::kernel::FivePointSolver inside RobustMatcher::filterEssential
+(RobustMatcher.hpp:153-186); OpenMVG is absent, so the checks are the defining properties of the solutions."""
+import numpy as np
+
+import fivept_host
+
+
+def _check(E, q1, q2):
+    h1 = np.c_[q1, np.ones(5)]
+    h2 = np.c_[q2, np.ones(5)]
+    epi = np.abs(np.einsum("ij,jk,ik->i", h2, E, h1)).max() / np.linalg.norm(E)
+    sv = np.linalg.svd(E, compute_uv=False)
+    return epi, abs(sv[0] - sv[1]) / sv[0], sv[2] / sv[0]
+
+
+def test_solutions_are_essential_matrices_through_the_points_and_contain_the_truth():
+    rng = np.random.default_rng(2024)
+    S, hits, nsol = 1500, 0, 0
+    for _ in range(S):
+        q1, q2, Et = fivept_host.random_two_view(rng)
+        Et = Et / np.linalg.norm(Et)
+        best = 1.0
+        sols = fivept_host.solve(q1, q2)
+        assert len(sols) <= 10
+        for E in sols:
+            nsol += 1
+            epi, ds, s3 = _check(E, q1, q2)
+            assert epi < 1e-9 and ds < 1e-4 and s3 < 1e-4
+            En = E / np.linalg.norm(E)
+            best = min(best, np.abs(En - Et).max(), np.abs(En + Et).max())
+        hits += best < 1e-6
+    assert hits >= 0.985 * S, hits / S                     # measured 0.9948 on 5000 scenes (tools/fivept_host.cpp)
+    assert 2.0 < nsol / S <= 10.0
+
+
+def test_no_duplicate_solutions_and_degenerate_input():
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        q1, q2, _ = fivept_host.random_two_view(rng)
+        sols = [E / np.linalg.norm(E) for E in fivept_host.solve(q1, q2)]
+        for i in range(len(sols)):
+            for j in range(i):
+                assert min(np.abs(sols[i] - sols[j]).max(), np.abs(sols[i] + sols[j]).max()) > 1e-9
+    # five copies of one correspondence: rank-deficient constraint matrix -> no solution, no crash
+    q = np.tile(np.array([[0.1, -0.2]]), (5, 1))
+    assert fivept_host.solve(q, q + 0.05) == []
+    # all-zero input
+    assert fivept_host.solve(np.zeros((5, 2)), np.zeros((5, 2))) == []
