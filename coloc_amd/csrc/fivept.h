@@ -106,8 +106,11 @@ __device__ __forceinline__ double fpt_rcp(const double x)
     r = fma(fma(-x, r, 1.0), r, r);
     return r;
 }
+// ~2^-24 relative: enough where the value only steers an iteration and does not move its fixed point
+__device__ __forceinline__ double fpt_rcp_rough(const double x) { return __builtin_amdgcn_rcp(x); }
 #else
-static inline double fpt_rcp(const double x) { return 1.0 / x; }
+FPT_HD double fpt_rcp(const double x) { return 1.0 / x; }
+FPT_HD double fpt_rcp_rough(const double x) { return 1.0 / x; }
 #endif
 // phase time stamps for tools/fivept_bench.hip (no-op in the library)
 #ifndef FPT_STAMP
@@ -204,15 +207,15 @@ FPT_HD void fpt_balance10(FptWorkspace& w)
 // spend ~10 ln(ratio) sweeps creeping inwards (53 sweeps on average, measured on 5000 synthetic scenes), a geometric ladder
 // of radii around |det|^(1/10) 14, the diagonal 10.4 -- and, what matters for a kernel that waits for its slowest wave, the
 // tail goes: 99 % of the problems are done after 19 sweeps instead of 32.  A root stops when its step is below 1e-12 of its
-// size, or small and no longer shrinking (evaluation noise of an ill-conditioned eigenvalue); everything stops after 18
-// sweeps (hit rate 0.9948, the double-shift QR iteration used until round 2 had 0.9942).  Roots are polished on the
+// size, or small and no longer shrinking (evaluation noise of an ill-conditioned eigenvalue); everything stops after 16
+// sweeps (hit rate 0.994; 18 sweeps give 0.9948, 14 give 0.990; the double-shift QR iteration used until round 2 had 0.9942).  Roots are polished on the
 // constraints afterwards.  (The sequential QR took 46 % of the solver's time on the GPU: ~150 dependent Householder steps
 // of divisions and square roots, each with LDS round trips.)
 #ifndef FPT_CPLX_STAG
 #define FPT_CPLX_STAG 1e-4
 #endif
 #ifndef FPT_SWEEPS
-#define FPT_SWEEPS 18
+#define FPT_SWEEPS 16
 #endif
 constexpr int kFptAberthSweeps = FPT_SWEEPS;
 // Only the REAL eigenvalues are used.  A root that is plainly complex and already creeping (step below FPT_CPLX_SETTLE of its
@@ -280,7 +283,7 @@ FPT_HD void fpt_aberth10(FptWorkspace& w, double* wr, double* wi, const double a
                 for (int j = 0; j < 10; ++j) {
                     const double dr = zr - or_[j], di = zi - oi_[j];
                     const double d2 = dr * dr + di * di;
-                    const double q = (j != k && d2 > 0.0) ? fpt_rcp(d2 > 0.0 ? d2 : 1.0) : 0.0;
+                    const double q = (j != k && d2 > 0.0) ? fpt_rcp_rough(d2 > 0.0 ? d2 : 1.0) : 0.0;
                     sr += dr * q; si -= di * q;
                 }
                 const double er = 1.0 - (nr * sr - ni * si), ei = -(nr * si + ni * sr);
@@ -316,7 +319,7 @@ FPT_UNROLL
                 for (int j = 0; j < 10; ++j) {                   // branch-free: the nine reciprocals overlap
                     const double dr = zr - wr[j], di = zi - wi[j];
                     const double d2 = dr * dr + di * di;
-                    const double q = (j != k && d2 > 0.0) ? fpt_rcp(d2 > 0.0 ? d2 : 1.0) : 0.0;
+                    const double q = (j != k && d2 > 0.0) ? fpt_rcp_rough(d2 > 0.0 ? d2 : 1.0) : 0.0;
                     sr += dr * q; si -= di * q;
                 }
                 // delta = N / (1 - N S)
@@ -499,9 +502,10 @@ FPT_HD int fpt_polish_update(const double (&s)[9], double* x, double* y, double*
     const double a00 = s[0], a01 = s[1], a02 = s[2], a11 = s[3], a12 = s[4], a22 = s[5], b0 = s[6], b1 = s[7], b2 = s[8];
     const double det = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
     if (!(fabs(det) > 1e-300)) return -1;
-    const double dx = (b0 * (a11 * a22 - a12 * a12) - a01 * (b1 * a22 - a12 * b2) + a02 * (b1 * a12 - a11 * b2)) / det;
-    const double dy = (a00 * (b1 * a22 - a12 * b2) - b0 * (a01 * a22 - a12 * a02) + a02 * (a01 * b2 - b1 * a02)) / det;
-    const double dz = (a00 * (a11 * b2 - b1 * a12) - a01 * (a01 * b2 - b1 * a02) + b0 * (a01 * a12 - a11 * a02)) / det;
+    const double idet = fpt_rcp(det);
+    const double dx = (b0 * (a11 * a22 - a12 * a12) - a01 * (b1 * a22 - a12 * b2) + a02 * (b1 * a12 - a11 * b2)) * idet;
+    const double dy = (a00 * (b1 * a22 - a12 * b2) - b0 * (a01 * a22 - a12 * a02) + a02 * (a01 * b2 - b1 * a02)) * idet;
+    const double dz = (a00 * (a11 * b2 - b1 * a12) - a01 * (a01 * b2 - b1 * a02) + b0 * (a01 * a12 - a11 * a02)) * idet;
     if (!(dx == dx) || !(dy == dy) || !(dz == dz)) return -1;
     *x -= dx; *y -= dy; *z -= dz;
     return fabs(dx) + fabs(dy) + fabs(dz) < 1e-15 * (1.0 + fabs(*x) + fabs(*y) + fabs(*z)) ? 1 : 0;

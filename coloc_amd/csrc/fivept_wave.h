@@ -17,8 +17,9 @@
 //   6. roots -> (y, z) -> polish on the constraints    six lanes per root: each takes (at most) two of the ten constraint rows
 //                                                      of a Gauss-Newton step, partial sums meet in LDS
 // Why: one problem per wave is latency-bound -- a solve is a chain of ~10^4 dependent steps and every LDS round trip or
-// barrier in it costs 100+ cycles.  Phase times for one problem before / after (cycles, MI355X): null space 17.6k, polynomials
-// 13.2k, Gauss-Jordan 27.6k, Hessenberg 26.5k -> see profiles/r02_fivept_phases.txt.
+// barrier in it costs 100+ cycles.  Phase times for one problem before -> after (cycles, MI355X): null space 17.5k -> 4.5k,
+// polynomials 13.3k -> 5.4k, Gauss-Jordan 27.5k -> 7.4k, Hessenberg 26.3k -> 8.9k, roots 175k -> 16.6k
+// (profiles/r02_fivept_phases.txt); 256 samples: 257.7 us -> 44.5 us.
 #ifndef CLC_FIVEPT_WAVE_H
 #define CLC_FIVEPT_WAVE_H
 
@@ -60,7 +61,7 @@ __device__ __forceinline__ bool null_space(const double q1[5][2], const double q
         }
 #pragma unroll
         for (int i = r + 1; i < 5; ++i) if (p == i) { const double t = a[r]; a[r] = a[i]; a[i] = t; }
-        const double inv = 1.0 / readlane(a[r], col);
+        const double inv = fpt_rcp(readlane(a[r], col));
         a[r] *= inv;
 #pragma unroll
         for (int i = 0; i < 5; ++i) if (i != r) { const double f = readlane(a[i], col); a[i] -= f * a[r]; }
@@ -98,7 +99,7 @@ __device__ __forceinline__ bool gauss_jordan(double (&m)[10])
 #pragma unroll
         for (int i = c + 1; i < 10; ++i)
             if (p == i) { double t = m[c]; m[c] = m[i]; m[i] = t; t = v[c]; v[c] = v[i]; v[i] = t; }
-        const double inv = 1.0 / v[c];
+        const double inv = fpt_rcp(v[c]);
         m[c] *= inv;
 #pragma unroll
         for (int i = 0; i < 10; ++i) if (i != c) m[i] -= v[i] * m[c];
@@ -190,6 +191,48 @@ __device__ __forceinline__ void root_candidates(FptWorkspace& w)
     __syncthreads();
     if (grouped && part == 0 && fpt_root_is_real(w, k)) fpt_root_finish(w, k, x, yv, z);
     __syncthreads();
+}
+
+// ---- 7. compaction with the sequential rule of fpt_compact (a root is dropped if it repeats an ACCEPTED earlier one), the 45
+// pairwise comparisons done by 45 lanes at once and the accept/reject chain on the resulting bit masks
+__device__ __forceinline__ int compact(FptWorkspace& w, double* E_out)
+{
+    const int lane = (int)threadIdx.x;
+    // pair index -> (k, s2), s2 < k: lane = k (k - 1) / 2 + s2
+    int k = 1, s2 = 0;
+    {
+        int l = lane < 45 ? lane : 44;
+        k = 1;
+        while (l >= k) { l -= k; ++k; }
+        s2 = l;
+    }
+    bool close = false;
+    if (lane < 45 && w.root[k].valid && w.root[s2].valid) {
+        const double* a = w.root[k].cand;
+        const double* b = w.root[s2].cand;
+        double scale = 0.0, d = 0.0;
+#pragma unroll
+        for (int c = 0; c < 9; ++c) { scale = fmax(scale, fabs(a[c])); d = fmax(d, fabs(a[c] - b[c])); }
+        close = d < 1e-9 * (1.0 + scale);
+    }
+    const unsigned long long close_mask = __ballot(close);
+    unsigned valid_mask = 0;
+    for (int r = 0; r < 10; ++r) valid_mask |= w.root[r].valid ? (1u << r) : 0u;
+    unsigned accepted = 0;
+    for (int r = 0; r < 10; ++r) {
+        if (!((valid_mask >> r) & 1u)) continue;
+        const unsigned row_bits = (unsigned)((close_mask >> (r * (r - 1) / 2)) & ((1ull << r) - 1ull));     // bit s2: close to root s2
+        if (row_bits & accepted) continue;
+        accepted |= 1u << r;
+    }
+    __syncthreads();
+    if (lane < 10 && ((accepted >> lane) & 1u)) {
+        const int slot = __popc(accepted & ((1u << lane) - 1u));
+#pragma unroll
+        for (int c = 0; c < 9; ++c) E_out[9 * slot + c] = w.root[lane].cand[c];
+    }
+    __syncthreads();
+    return __popc(accepted);
 }
 
 // q1, q2: 5 x 2 normalised coordinates (every lane holds the same values).  E_out (LDS): up to 10 x 9.
@@ -302,7 +345,7 @@ __device__ __forceinline__ int solve(const double q1[5][2], const double q2[5][2
     // ---- 6
     root_candidates(w);
     FPT_STAMP(6);
-    return fpt_compact(w, E_out);
+    return compact(w, E_out);
 }
 
 } // namespace fpw
