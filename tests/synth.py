@@ -119,3 +119,57 @@ def random_poses(n, seed=4100, base_R=None, base_t=None, jitter=0.2):
         t = (base_t if base_t is not None else np.zeros(3)) + rng.normal(0, jitter, 3)
         out[i] = np.concatenate([R, t[:, None]], 1).reshape(-1)
     return out
+
+
+# ---- a textured plane seen by pinhole cameras: geometrically consistent frames for end-to-end runs --------------------
+def plane_texture(size=1400, seed=77, n_rect=900):
+    """High-contrast random rectangles (corners for FAST) with mild noise, uint8 size x size."""
+    rng = np.random.default_rng(seed)
+    tex = np.full((size, size), 110.0)
+    for _ in range(n_rect):
+        w, h = rng.integers(12, 90, 2)
+        x, y = rng.integers(0, size - w), rng.integers(0, size - h)
+        tex[y:y + h, x:x + w] = rng.integers(20, 236)
+    tex += rng.normal(0.0, 1.5, tex.shape)
+    return np.clip(tex, 0, 255)
+
+
+def look_at_plane_pose(center_xy, height, yaw=0.0, tilt=(0.0, 0.0)):
+    """World -> camera [R|t] of a camera at (cx, cy, -height) looking along +z at the plane z = 0, rotated by yaw about
+    its optical axis and tilted by (rx, ry) radians."""
+    cz, sz = math.cos(yaw), math.sin(yaw)
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1.0]])
+    cx_, sx_ = math.cos(tilt[0]), math.sin(tilt[0])
+    Rx = np.array([[1.0, 0, 0], [0, cx_, -sx_], [0, sx_, cx_]])
+    cy_, sy_ = math.cos(tilt[1]), math.sin(tilt[1])
+    Ry = np.array([[cy_, 0, sy_], [0, 1.0, 0], [-sy_, 0, cy_]])
+    R = Rz @ Rx @ Ry
+    C = np.array([center_xy[0], center_xy[1], -float(height)])
+    return R, -R @ C
+
+
+def render_plane(tex, tex_px_per_unit, K, R, t, W=640, H=480):
+    """Image of the plane z = 0 (texture pixel (u, v) <-> world (u, v) / tex_px_per_unit) from camera [R|t], bilinear."""
+    v, u = np.mgrid[0:H, 0:W]
+    d = np.linalg.inv(K) @ np.stack([u.ravel() + 0.0, v.ravel() + 0.0, np.ones(W * H)])
+    o = -R.T @ t
+    dw = R.T @ d
+    lam = -o[2] / dw[2]
+    Xw = o[:, None] + lam * dw
+    tu, tv = Xw[0] * tex_px_per_unit, Xw[1] * tex_px_per_unit
+    x0 = np.clip(np.floor(tu).astype(np.int64), 0, tex.shape[1] - 2)
+    y0 = np.clip(np.floor(tv).astype(np.int64), 0, tex.shape[0] - 2)
+    fx, fy = np.clip(tu - x0, 0, 1), np.clip(tv - y0, 0, 1)
+    img = (tex[y0, x0] * (1 - fx) * (1 - fy) + tex[y0, x0 + 1] * fx * (1 - fy) + tex[y0 + 1, x0] * (1 - fx) * fy + tex[y0 + 1, x0 + 1] * fx * fy)
+    inside = (tu >= 0) & (tu < tex.shape[1] - 1) & (tv >= 0) & (tv < tex.shape[0] - 1) & (lam > 0)
+    img = np.where(inside, img, 0.0)
+    return np.clip(img + 0.5, 0, 255).astype(np.uint8).reshape(H, W)
+
+
+def backproject_to_plane(px, K, R, t):
+    """World points (n x 3, z = 0) seen at pixels px (n x 2) by camera [R|t]."""
+    d = np.linalg.inv(K) @ np.c_[px, np.ones(len(px))].T
+    o = -R.T @ t
+    dw = R.T @ d
+    lam = -o[2] / dw[2]
+    return (o[:, None] + lam * dw).T
