@@ -81,6 +81,9 @@ def cpu_baseline(desc_q, desc_t, xy_q, xy_t):
 
 
 def main():
+    if os.environ.get("BENCH_FAULT_AFTER"):          # debugging aid: dump every thread's stack and exit if the run takes this long
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_FAULT_AFTER"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -226,7 +229,13 @@ def main():
     sustained = None
     clock = None
     if args.sustain_seconds > 0:
-        n_sus = max(args.steps, int(args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)
+        # back-to-back steps run ~20 % faster than the event-bracketed burst the estimate comes from (no launch gaps): 1.3x margin
+        n_sus = max(args.steps, int(1.3 * args.sustain_seconds / max(dt / args.steps, 1e-6)) + 1)
+        if world > 1:
+            # every rank must run the SAME number of steps (each step holds a collective): take rank 0's count
+            t_n = torch.tensor([n_sus], dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+            dist.broadcast(t_n, src=0)
+            n_sus = int(t_n.item())
         fence()
         ts = time.perf_counter()
         for _ in range(n_sus):

@@ -46,11 +46,11 @@ def test_default_line_has_contract_fields():
 
 
 def test_two_rank_rehearsal_runs():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FAULT_AFTER="200")   # a hung rank dumps its stacks and exits
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
            "--backend", "gloo"]
-    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["pairs"] == 1 and d["value"] > 0 and "REHEARSAL" in d["collective"]
