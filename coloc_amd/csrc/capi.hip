@@ -643,17 +643,20 @@ int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t,
     }
     const size_t nwg = (size_t)jobs[0].qblocks * jobs[0].splits;
     uint64_t* d_stamps = nullptr;
-    CLC_HIP(ctx, hipMalloc((void**)&d_stamps, nwg * 4 * sizeof(uint64_t)));
-    std::vector<uint64_t> h(nwg * 4);
-    hipError_t e = hipMemsetAsync(d_stamps, 0, nwg * 4 * sizeof(uint64_t), st);
+    CLC_HIP(ctx, hipMalloc((void**)&d_stamps, nwg * 8 * sizeof(uint64_t)));
+    std::vector<uint64_t> h(nwg * 8);
+    hipError_t e = hipMemsetAsync(d_stamps, 0, nwg * 8 * sizeof(uint64_t), st);
     if (e == hipSuccess) e = launch_k2nn(jobs.data(), 1, ctx->d_partial, st, nullptr, ctx->formulation, d_stamps);
-    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_stamps, nwg * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_stamps, nwg * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_stamps);
     if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "k2nn_clock_check", e);
+    if (const char* dump = getenv("CLC_K2NN_STAMP_DUMP")) {            // diagnostic: raw per-workgroup stamps for tools/k2nn_timeline.py
+        if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), sizeof(uint64_t), h.size(), f); fclose(f); }
+    }
     std::vector<double> ghz;
     for (size_t w = 0; w < nwg; ++w) {
-        const uint64_t dc = h[4 * w + 2] - h[4 * w], dr = h[4 * w + 3] - h[4 * w + 1];
+        const uint64_t dc = h[8 * w + 2] - h[8 * w], dr = h[8 * w + 3] - h[8 * w + 1];
         if (dr > 20) ghz.push_back((double)dc / (double)dr * 0.1);       // s_memrealtime ticks at 100 MHz
     }
     if (ghz.empty()) return fail(ctx, CLC_ERR_STATE, "k2nn_clock_check: sweep too short to stamp");

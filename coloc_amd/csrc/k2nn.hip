@@ -307,8 +307,8 @@ __device__ __forceinline__ uint32_t mx_decode(const uint32_t bits, const uint32_
 }
 
 // STAMP: diagnostic build for the clock check (MI355X guide, DVFS item 6): lane 0 of every workgroup brackets its tile loop
-// with s_memtime (shader clock) / s_memrealtime (constant 100 MHz) and stores the four values in a buffer nothing else
-// reads.  The product kernel (STAMP = false) contains no stamp.
+// with s_memtime (shader clock) / s_memrealtime (constant 100 MHz) and stores them, with its entry / folded-in times and its
+// XCC id (tools/k2nn_timeline.py), in a buffer nothing else reads.  The product kernel (STAMP = false) contains no stamp.
 template <bool STAMP>
 __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial,
                                                                       uint64_t* __restrict__ stamps)
@@ -325,6 +325,8 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     __shared__ uint32_t s_best[kMxQPerBlock], s_second[kMxQPerBlock];
     __shared__ uint32_t s_arrival;
     const K2nnJobDev& job = jobs.j[blockIdx.y];
+    uint64_t st_entry = 0;
+    if (STAMP) st_entry = __builtin_amdgcn_s_memrealtime();
     // XCD-aware order (speed only): workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD has its own
     // L2.  Workgroup L works on query block (L & 7) + 8 ((L >> 3) / splits): every split of a query block lands on ONE
     // XCD, so an XCD's L2 pulls an eighth of the queries plus the train set instead of all of both (PMC, 10k x 10k:
@@ -440,8 +442,8 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     if (STAMP) {
         const uint64_t en_clk = __builtin_amdgcn_s_memtime(), en_real = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            uint64_t* o = stamps + 4u * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
-            o[0] = st_clk; o[1] = st_real; o[2] = en_clk; o[3] = en_real;
+            uint64_t* o = stamps + 8u * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = st_clk; o[1] = st_real; o[2] = en_clk; o[3] = en_real; o[4] = st_entry;
         }
     }
     // lanes l and l ^ 32 hold the same query column (different train rows): fold them, decode to canonical keys with the
@@ -482,6 +484,12 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     unsigned int* cnt = reinterpret_cast<unsigned int*>(partial) + job.cnt_off + qblock;
     if (tid == 0) s_arrival = atomicAdd(cnt, 1u) + 1u;
     __syncthreads();
+    if (STAMP && tid == 0) {          // folded in: everything but the finalize of the last arrival
+        uint64_t* o = stamps + 8u * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        o[5] = __builtin_amdgcn_s_memrealtime();
+        o[6] = ((uint64_t)qblock << 32) | split;
+        o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));      // XCC_ID[3:0]
+    }
     if (s_arrival != job.splits - 1u) return;
     if (tid == 0) atomicExch(cnt, kEmpty);
     if (qi < job.nq) {

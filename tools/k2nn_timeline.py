@@ -1,0 +1,40 @@
+"""Per-workgroup timeline of one 10k x 10k matrix-formulation sweep (stamped diagnostic build, CLC_K2NN_STAMP_DUMP):
+when each workgroup enters, starts / ends its tile loop and has folded its results in, on the constant 100 MHz clock.
+usage: k2nn_timeline.py   (run ON the GPU box)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch, synth
+from coloc_amd import Context
+ctx = Context(device=0, width=640, height=480, maxkp=10000, detector=False)
+Q, T = synth.planted_descriptors(10000, 10000, seed=3000)
+dq, dt = torch.from_numpy(Q).cuda(), torch.from_numpy(T).cuda()
+dm = torch.empty(10000, dtype=torch.int32, device="cuda")
+for _ in range(200):
+    ctx.match_2nn_dev(dq.data_ptr(), 10000, dt.data_ptr(), 10000, 40, dm.data_ptr())
+path = "/tmp/k2nn_stamps.bin"
+os.environ["CLC_K2NN_STAMP_DUMP"] = path
+clk = ctx.k2nn_clock_check(dq.data_ptr(), 10000, dt.data_ptr(), 10000, dm.data_ptr())
+h = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
+h = h[h[:, 4] > 0]
+t0 = h[:, 4].min()
+ent, ls, le, ex = [(h[:, i].astype(np.int64) - int(t0)) * 0.01 for i in (4, 1, 3, 5)]       # microseconds
+xcc = h[:, 7] & 0xF
+cyc = (h[:, 2] - h[:, 0]).astype(np.float64)
+print("clock", clk)
+print("workgroups %d" % len(h))
+q = lambda v: "min %.2f p10 %.2f p50 %.2f p90 %.2f max %.2f" % tuple(np.percentile(v, [0, 10, 50, 90, 100]))
+print("entry            us:", q(ent))
+print("loop start       us:", q(ls))
+print("loop end         us:", q(le))
+print("folded in        us:", q(ex))
+print("prologue (entry -> loop start) us:", q(ls - ent))
+print("loop length      us:", q(le - ls), " cycles:", q(cyc))
+print("epilogue + fold  us:", q(ex - le))
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print("  XCC %d: %3d workgroups, entry p50 %.2f, loop end p50 %.2f max %.2f, folded max %.2f" % (x, m.sum(), np.median(ent[m]), np.median(le[m]), le[m].max(), ex[m].max()))
+# how many workgroups are inside their loop at each instant
+for tt in np.arange(0, ex.max() + 1, 2.0):
+    print("  t=%5.1f us: %3d entered, %3d in loop, %3d done" % (tt, (ent <= tt).sum(), ((ls <= tt) & (le > tt)).sum(), (ex <= tt).sum()))
