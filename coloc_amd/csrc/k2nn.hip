@@ -291,6 +291,18 @@ __device__ __forceinline__ u32x4 mx_expand(const uint32_t x)
     y.w = (x & 0x88888888u) | 0x22222222u;
     return y;
 }
+// the same for the COMPLEMENT of x, written so that each output is one shift + one three-input bit op (v_bitop3_b32):
+// complementing first and shifting the complement costs a v_not and separate and / or per output (22 instead of 14
+// instructions for the 8 train bytes a thread expands per tile)
+__device__ __forceinline__ u32x4 mx_expand_not(const uint32_t x)
+{
+    u32x4 y;
+    y.x = (~(x << 3) & 0x88888888u) | 0x22222222u;
+    y.y = (~(x << 2) & 0x88888888u) | 0x22222222u;
+    y.z = (~(x << 1) & 0x88888888u) | 0x22222222u;
+    y.w = (~x & 0x88888888u) | 0x22222222u;
+    return y;
+}
 // Keys are positive finite floats, "none" is +inf: float order == unsigned order of the bits.  v_med3_f32 through the
 // builtin, NOT inline asm: the compiler pads the MFMA-result -> VALU-read hazard only for instructions it can see
 // (an asm v_med3_u32 placed straight after the last MFMA of a tile read the PREVIOUS tile's accumulator register).
@@ -389,9 +401,10 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     const uint32_t my_row = tid >> 3, my_j = tid & 7u;
     const uint32_t dst = my_j * kStride + my_row;
     const global_cu2_ptr tbase = (global_cu2_ptr)(uintptr_t)job.t + (size_t)my_j;
+    const uint32_t last_row = job.nt - 1u;                           // in a register: read through `job` it is a scalar load
+                                                                     // (+ wait) from the kernel arguments in every tile
     auto load_bits = [&](const uint32_t tile) -> u32x2 {
-        uint32_t row = s0 + tile * 32u + my_row;
-        if (row >= job.nt) row = job.nt - 1u;                       // stays in bounds; such rows are penalised through C
+        const uint32_t row = min(s0 + tile * 32u + my_row, last_row);   // stays in bounds; such rows are penalised through C
         return tbase[(size_t)row * 8u];
     };
     u32x2 r0 = load_bits(0u), r1 = load_bits(min(1u, ntiles - 1u));
@@ -399,8 +412,8 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     if (STAMP) { st_clk = __builtin_amdgcn_s_memtime(); st_real = __builtin_amdgcn_s_memrealtime(); }
     for (uint32_t t = 0; t < ntiles; ++t) {
         const uint32_t buf = t & 1u;
-        s_a[buf][dst] = mx_expand(~r0.x);
-        s_a[buf][dst + 32] = mx_expand(~r0.y);
+        s_a[buf][dst] = mx_expand_not(r0.x);
+        s_a[buf][dst + 32] = mx_expand_not(r0.y);
         r0 = r1;
         __syncthreads();          // one barrier per tile: buffer `buf` was last read two iterations ago, before the previous barrier
         if (t + 2u < ntiles) r1 = load_bits(t + 2u);                // bits of the tile after next: in flight for a whole tile
