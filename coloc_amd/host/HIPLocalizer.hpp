@@ -16,6 +16,10 @@
 //        leaves in rmse after cv::projectPoints with zero distortion and fy = fx, :141-170)
 // Functions return EXIT_SUCCESS / EXIT_FAILURE through bool, i.e. FALSE MEANS SUCCESS (coloc.hpp:241,338), except
 // refine(), which like the reference returns the refiner's own status (true = refined).
+// Second call site of the same solve: Reconstructor::resectionCamera (Reconstructor.hpp:282-307) calls
+//   sfm::SfM_Localizer::Localize(resection::SolverType::P3P_KE_CVPR17, {w, h}, intrinsics, resectionData, pose)
+// directly; HIP_SfM_Localizer::Localize below has that signature (P3P only: without intrinsics OpenMVG falls back to the
+// uncalibrated 6-point DLT kernel, which is not on this path -> returns false).
 // What differs underneath: the random samples (OpenMVG's std::mt19937 stream is unpinned -- `seed` below selects
 // the documented counter-based sampler of clc_acr.h), the P3P root order and Ceres' iterates (absent submodules).
 #pragma once
@@ -92,6 +96,13 @@ public:
     bool localize(const openMVG::cameras::Pinhole_Intrinsic_Radial_K3& cam, openMVG::sfm::Image_Localizer_Match_Data& matching_data,
                   openMVG::geometry::Pose3& pose)
     {
+        return localize_with(ctx_, seed++, cam, matching_data, pose);
+    }
+
+    // the solve itself, on any context (shared with HIP_SfM_Localizer::Localize)
+    static bool localize_with(clc_ctx* ctx_, const uint64_t seed_value, const openMVG::cameras::Pinhole_Intrinsic_Radial_K3& cam,
+                              openMVG::sfm::Image_Localizer_Match_Data& matching_data, openMVG::geometry::Pose3& pose)
+    {
         const int n = static_cast<int>(matching_data.pt3D.cols());
         matching_data.vec_inliers.clear();
         if (!ctx_ || n == 0) return false;
@@ -107,7 +118,7 @@ public:
         double Rt[12], emax = 0.0, nfa = 0.0;
         std::vector<int32_t> inl(static_cast<size_t>(n));
         int n_inl = 0, its = 0;
-        const int rc = clc_pnp_acransac(ctx_, X.data(), x.data(), n, Kd, static_cast<int>(matching_data.max_iteration), seed++, precision, Rt,
+        const int rc = clc_pnp_acransac(ctx_, X.data(), x.data(), n, Kd, static_cast<int>(matching_data.max_iteration), seed_value, precision, Rt,
                                         nullptr, inl.data(), &n_inl, &emax, &nfa, &its);
         if (rc != CLC_OK) {
             std::cerr << "HIPLocalizer: clc_pnp_acransac: " << clc_last_error_string(ctx_) << std::endl;
@@ -184,6 +195,25 @@ private:
     std::vector<openMVG::Mat3>* K;
     std::vector<openMVG::Vec3>* dist;
     std::string* rootFolder;
+};
+
+// sfm::SfM_Localizer::Localize as Reconstructor::resectionCamera calls it (Reconstructor.hpp:304-306) and Localizer::localizeImage
+// through its member (Localizer.hpp:93): true = resection succeeded (more than 2.5 x 3 inliers), resection_data.vec_inliers /
+// error_max updated, pose set.  One context per process, created on first use.
+namespace resection { enum class SolverType { DLT_6POINTS = 0, P3P_KE_CVPR17 = 1, P3P_KNEIP_CVPR11 = 2, P3P_NORDBERG_ECCV18 = 3, UP2P_KUKELOVA_ACCV10 = 4 }; }
+struct HIP_SfM_Localizer {
+    static bool Localize(const resection::SolverType& solver_type, const std::pair<size_t, size_t>& image_size,
+                         const openMVG::cameras::Pinhole_Intrinsic_Radial_K3* optional_intrinsics,
+                         openMVG::sfm::Image_Localizer_Match_Data& resection_data, openMVG::geometry::Pose3& pose, uint64_t seed = 1)
+    {
+        (void)image_size;                                   // only feeds the uncalibrated kernel's normalisation in OpenMVG
+        if (!optional_intrinsics || solver_type == resection::SolverType::DLT_6POINTS) {
+            std::cerr << "HIP_SfM_Localizer::Localize: only the calibrated P3P path is provided" << std::endl;
+            return false;
+        }
+        static clc_ctx* shared = []() { clc_ctx* c = nullptr; return clc_ctx_create(0, nullptr, nullptr, &c) == CLC_OK ? c : nullptr; }();
+        return HIPLocalizer::localize_with(shared, seed, *optional_intrinsics, resection_data, pose);
+    }
 };
 
 } // namespace coloc

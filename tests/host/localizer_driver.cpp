@@ -65,6 +65,22 @@ int main(int argc, char** argv)
         out.push_back(rmse);
         out.push_back((double)inliers.size());
         for (uint32_t v : inliers) out.push_back(v);
+        // the second call site of the same solve (Reconstructor::resectionCamera): SfM_Localizer::Localize called directly on
+        // prepared Image_Localizer_Match_Data; same sampler seed as the member call above -> the same inlier set
+        {
+            cameras::Pinhole_Intrinsic_Radial_K3 cam((int)w, (int)h, K(0, 0), K(0, 2), K(1, 2), dist[0], dist[1], dist[2]);
+            sfm::Image_Localizer_Match_Data rd;
+            rd.error_max = std::numeric_limits<double>::infinity();
+            rd.max_iteration = 256;
+            localizer.setupTracks(&cam, data, *data.regions.at(0), tracked, &rd);
+            geometry::Pose3 pose2;
+            const bool ok = coloc::HIP_SfM_Localizer::Localize(coloc::resection::SolverType::P3P_KE_CVPR17, { (size_t)w, (size_t)h }, &cam, rd, pose2, 1);
+            out.push_back(ok ? 1.0 : 0.0);
+            out.push_back((double)rd.vec_inliers.size());
+            for (int i = 0; i < 3; ++i) out.push_back(pose2.center()[i]);
+            const bool none = coloc::HIP_SfM_Localizer::Localize(coloc::resection::SolverType::P3P_KE_CVPR17, { (size_t)w, (size_t)h }, nullptr, rd, pose2, 1);
+            out.push_back(none ? 1.0 : 0.0);
+        }
         dump(dir + "/loc_out.bin", out);
     }
     // ---- twoview.bin: [w, h, f, ppx, ppy, n, x1 (2 n), x2 (2 n)]  (undistorted pixels)

@@ -64,6 +64,10 @@ def test_localizer_and_two_view_drivers(tmp_path, gpu_ctx):
     inside = (sc["x"][:, 0] > 0) & (sc["x"][:, 0] < 1280) & (sc["x"][:, 1] > 0) & (sc["x"][:, 1] < 720)
     assert np.abs(xu - sc["x"])[inside].max() < 1e-3              # the bisection inverts the distortion (float32 storage limits it)
     assert np.array_equal(np.sort(ref["inliers"]), np.sort(inl))
+    # second call site (Reconstructor::resectionCamera -> SfM_Localizer::Localize directly): same solve, same seed, no refinement
+    tail = o[51 + n_inl:]
+    assert tail[0] == 1.0 and int(tail[1]) == n_inl and np.linalg.norm(tail[2:5] - Ctrue) < 0.05
+    assert tail[5] == 0.0                                          # without intrinsics: the uncalibrated kernel is not provided
 
     t = np.fromfile(tmp_path / "twoview_out.bin", dtype=np.float64)
     assert t[0] == 0.0
