@@ -6,6 +6,9 @@
 //        initial_residual_tolerance = +inf)  ->  clc_essential_acransac (a-contrario five-point RANSAC on the GPU);
 //        failure iff inliers < 2.5 x 5; with findPose: RelativePoseFromEssential(bearings1, bearings2, E, inliers, &pose)
 //   bool RelativePoseFromEssential(...)                                                                :176-183
+//   bool computeRelativePose(relativePose, pair, regions, putativeMatches)                            :372-424
+//   bool filterMatchesPair(pair, regions, putativeMatches, geometricMatches, relativePoses)           :426-453  (coloc.hpp:296)
+//   void filterMatches(regions, putativeMatches, geometricMatches, relativePoses)                     :455-483  (coloc.hpp:167, 412)
 //        host arithmetic, restated from OpenMVG's published multiview code (motion_from_essential.hpp): the four
 //        (R, t) candidates of E = U diag(1,1,0) V^T (R = U W V^T or U W^T V^T, t = +-u3), every inlier triangulated
 //        (DLT on the bearing vectors) under each candidate, the candidate with most points in front of both cameras
@@ -19,6 +22,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <map>
 #include <vector>
 
 #include "coloc_hip.h"
@@ -184,6 +188,8 @@ inline bool RelativePoseFromEssential(const openMVG::Mat3X& x1, const openMVG::M
 
 } // namespace hipgeom
 
+typedef std::map<openMVG::Pair, openMVG::sfm::RelativePose_Info> InterPoseMap;     // colocData.hpp:25
+
 class HIPRobustMatcher {
 public:
     int iterationCount = 256;                              // RobustMatcher.hpp:34
@@ -240,6 +246,61 @@ public:
             relativePose_info.relativePose = relative_pose;
         }
         return EXIT_SUCCESS;
+    }
+
+    // RobustMatcher::computeRelativePose (:372-424): positions of the pair's putative matches, undistorted through each camera's
+    // radial-K3 model, into the filter selected by params->model.  Only the essential-matrix model ('E', the one the reference's
+    // own launch files use) is on this path; 'H' / 'F' report failure.
+    bool computeRelativePose(openMVG::sfm::RelativePose_Info& relativePose, openMVG::Pair current_pair, FeatureMap& regions,
+                             openMVG::matching::PairWiseMatches& putativeMatches)
+    {
+        const uint32_t I = std::min(current_pair.first, current_pair.second);
+        const uint32_t J = std::max(current_pair.first, current_pair.second);
+        const std::vector<openMVG::matching::IndMatch> pairMatches = putativeMatches[current_pair];
+        openMVG::Mat xL(2, pairMatches.size()), xR(2, pairMatches.size());
+        const auto& Ka = params->K[current_pair.first];
+        const auto& Kb = params->K[current_pair.second];
+        const auto& da = params->dist[current_pair.first];
+        const auto& db = params->dist[current_pair.second];
+        const openMVG::cameras::Pinhole_Intrinsic_Radial_K3 camL(params->imageSize.first, params->imageSize.second, Ka(0, 0), Ka(0, 2), Ka(1, 2), da[0],
+                                                                 da[1], da[2]),
+            camR(params->imageSize.first, params->imageSize.second, Kb(0, 0), Kb(0, 2), Kb(1, 2), db[0], db[1], db[2]);
+        for (size_t k = 0; k < pairMatches.size(); ++k) {
+            const auto pi = regions.at(I)->GetRegionPosition(pairMatches[k].i_);
+            const auto pj = regions.at(J)->GetRegionPosition(pairMatches[k].j_);
+            const openMVG::Vec2 ui = camL.get_ud_pixel(openMVG::Vec2(pi[0], pi[1])), uj = camR.get_ud_pixel(openMVG::Vec2(pj[0], pj[1]));
+            xL(0, k) = ui[0]; xL(1, k) = ui[1];
+            xR(0, k) = uj[0]; xR(1, k) = uj[1];
+        }
+        bool status = EXIT_FAILURE;
+        if (params->model == 'E') status = filterEssential(&camL, &camR, xL, xR, relativePose, *params, true);
+        else std::cout << "HIPRobustMatcher: filtering model '" << params->model << "' is not provided (essential matrix only)." << std::endl;
+        if (status == EXIT_FAILURE) std::cerr << "Unable to estimate relative pose." << std::endl;
+        return status;
+    }
+
+    // RobustMatcher::filterMatchesPair (:426-453): geometricMatches[pair] = the putative matches the model keeps (none -> entry left
+    // alone), relativePoses[pair] = the model -- also when the estimate failed, like the reference
+    bool filterMatchesPair(openMVG::Pair currentPair, FeatureMap& regions, openMVG::matching::PairWiseMatches& putativeMatches,
+                           openMVG::matching::PairWiseMatches& geometricMatches, InterPoseMap& relativePoses)
+    {
+        const std::vector<openMVG::matching::IndMatch> pairMatches = putativeMatches[currentPair];
+        openMVG::sfm::RelativePose_Info relativePose;
+        const bool status = computeRelativePose(relativePose, currentPair, regions, putativeMatches);
+        std::vector<openMVG::matching::IndMatch> kept;
+        for (size_t ic = 0; ic < relativePose.vec_inliers.size(); ++ic) kept.push_back(pairMatches[relativePose.vec_inliers[ic]]);
+        if (!kept.empty()) geometricMatches[currentPair] = kept;
+        relativePoses[currentPair] = relativePose;
+        return status;
+    }
+
+    // RobustMatcher::filterMatches (:455-483): every pair that has putative matches
+    void filterMatches(FeatureMap& regions, openMVG::matching::PairWiseMatches& putativeMatches, openMVG::matching::PairWiseMatches& geometricMatches,
+                       InterPoseMap& relativePoses)
+    {
+        std::vector<openMVG::Pair> pairs;
+        for (const auto& kv : putativeMatches) pairs.push_back(kv.first);
+        for (const openMVG::Pair& pr : pairs) (void)filterMatchesPair(pr, regions, putativeMatches, geometricMatches, relativePoses);
     }
 
 private:

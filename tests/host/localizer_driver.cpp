@@ -108,6 +108,27 @@ int main(int argc, char** argv)
         out.push_back(info.found_residual_precision);
         out.push_back((double)info.vec_inliers.size());
         for (uint32_t v : info.vec_inliers) out.push_back(v);
+        // the members ColoC actually calls (coloc.hpp:167, 296): filterMatches over regions + putative matches.  Pair (0, 1):
+        // feature k of view 0 <-> feature n-1-k of view 1, so the match indices are not the identity
+        {
+            coloc::FeatureMap regions;
+            regions[0].reset(new features::AKAZE_Binary_Regions);
+            regions[1].reset(new features::AKAZE_Binary_Regions);
+            for (size_t i = 0; i < n; ++i) regions[0]->Features().emplace_back((float)xL(0, i), (float)xL(1, i), 7.0f, 0.0f);
+            for (size_t i = 0; i < n; ++i) regions[1]->Features().emplace_back((float)xR(0, n - 1 - i), (float)xR(1, n - 1 - i), 7.0f, 0.0f);
+            matching::PairWiseMatches putative, geometric;
+            for (size_t i = 0; i < n; ++i) putative[{ 0, 1 }].emplace_back((IndexT)i, (IndexT)(n - 1 - i));
+            coloc::InterPoseMap poses;
+            coloc::HIPRobustMatcher robust2(params);              // fresh object: same sampler seed as `robust` had
+            robust2.filterMatches(regions, putative, geometric, poses);
+            const auto& g = geometric[{ 0, 1 }];
+            out.push_back((double)g.size());
+            out.push_back((double)poses.count({ 0, 1 }));
+            size_t consistent = 0;
+            for (const auto& m : g) consistent += (m.i_ + m.j_ == n - 1) ? 1 : 0;
+            out.push_back((double)consistent);
+            for (int i = 0; i < 3; ++i) out.push_back(poses[{ 0, 1 }].relativePose.center()[i]);
+        }
         dump(dir + "/twoview_out.bin", out);
     }
     return 0;

@@ -81,3 +81,10 @@ def test_localizer_and_two_view_drivers(tmp_path, gpu_ctx):
     cosb = (C2 @ Crel) / (np.linalg.norm(C2) * np.linalg.norm(Crel))
     assert ang < 0.5 and cosb > 0.995 and abs(np.linalg.norm(C2) - 1) < 1e-9     # rotation, baseline DIRECTION (scale is free), unit t
     assert abs(np.linalg.det(R2) - 1) < 1e-9
+    # filterMatches (what ColoC calls): same inlier count through regions + putative matches (float32 feature storage moves a few
+    # borderline points), every kept match is one of the putative ones, the pose map is filled with the same baseline direction
+    tail = t[24 + n2:]
+    n_geo, n_pose, n_cons = int(tail[0]), int(tail[1]), int(tail[2])
+    assert abs(n_geo - n2) <= 0.02 * n2 and n_pose == 1 and n_cons == n_geo
+    C3 = tail[3:6]
+    assert (C3 @ Crel) / (np.linalg.norm(C3) * np.linalg.norm(Crel)) > 0.995
