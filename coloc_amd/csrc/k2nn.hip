@@ -318,6 +318,17 @@ __device__ __forceinline__ uint32_t mx_decode(const uint32_t bits, const uint32_
     return (d << kKeyShift) | (t0 + (rel & (kMxMaxSplit - 1u)));
 }
 
+// the same for a key whose index field is relative to `end` (the row behind the split): value = 2^23 + (distance << 13) + rel,
+// rel in [-8192, -1].  Through the float VALUE, not its bits: with distance 0 the value lies below 2^23, where floats step by 0.5.
+__device__ __forceinline__ uint32_t mx_decode_rel(const uint32_t bits, const uint32_t end)
+{
+    if (bits == kMxInf) return kEmpty;
+    const int v = (int)__uint_as_float(bits) - 8388608 + (int)kMxMaxSplit;          // (distance << 13) + rel + 8192, >= 0
+    const uint32_t d = (uint32_t)v >> kMxIdxBits;
+    if (d > 512u) return kEmpty;
+    return (d << kKeyShift) | (end - kMxMaxSplit + ((uint32_t)v & (kMxMaxSplit - 1u)));
+}
+
 // STAMP: diagnostic build for the clock check (MI355X guide, DVFS item 6): lane 0 of every workgroup brackets its tile loop
 // with s_memtime (shader clock) / s_memrealtime (constant 100 MHz) and stores them, with its entry / folded-in times and its
 // XCC id (tools/k2nn_timeline.py), in a buffer nothing else reads.  The product kernel (STAMP = false) contains no stamp.
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
         }
     }
     __syncthreads();                 // the staging area becomes the train-tile buffer
-    // C of the first MFMA of a tile: 2^23 + 2^21 + index (inside the split) of the lane's 16 train rows
+    // C of the first MFMA of a tile: 2^23 + 2^21 + index (inside the TILE) of the lane's 16 train rows; the same for every tile
     // (C/D layout of the 32x32 forms: column = lane & 31, row = 8 (reg >> 2) + 4 (lane >> 5) + (reg & 3))
     float cinit[16];
 #pragma unroll
@@ -448,8 +459,11 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
                 best[qt] = mx_med3(best[qt], acc[qt][i], 0.0f);       // = min: every key is > 0
             }
         }
+        // next tile: instead of advancing the index part of the sixteen C registers, the running pair steps BACK by one tile --
+        // its index field is then relative to the tile about to be processed (negative for the tiles behind; the integer stays
+        // exact in fp32, order and tie rule unchanged: a lower global index is a lower value).  4 VALU instead of 16 per tile.
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cinit[i] += 32.0f;
+        for (int qt = 0; qt < QT; ++qt) { best[qt] -= 32.0f; second[qt] -= 32.0f; }
     }
 
     if (STAMP) {
@@ -468,9 +482,10 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
         const uint32_t ob = __shfl_xor(mb, 32), os = __shfl_xor(ms, 32);
         if (lane < 32u) {
             const uint32_t slot = (wave * QT + qt) * 32u + lane;
-            const uint32_t base = job.atomic_merge ? s0 : 0u;
-            s_best[slot] = mx_decode(min(mb, ob), base);
-            s_second[slot] = mx_decode(min(min(ms, os), max(mb, ob)), base);
+            // after the last tile's step back every index is relative to the row BEHIND the split: -(rows of the split) .. -1
+            const uint32_t end = (job.atomic_merge ? s0 : 0u) + 32u * ntiles;
+            s_best[slot] = mx_decode_rel(min(mb, ob), end);
+            s_second[slot] = mx_decode_rel(min(min(ms, os), max(mb, ob)), end);
         }
     }
     __syncthreads();
