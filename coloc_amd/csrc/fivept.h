@@ -198,6 +198,50 @@ FPT_HD void fpt_balance10(FptWorkspace& w)
         FPT_SYNC();
     }
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// the partner lane's value inside an (even, odd) lane pair: DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ double fpt_pair_swap(const double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+// fpt_hyman_newton on TWO lanes per root: the even lane carries the real parts of x, x' and of the forty running sums, the odd
+// lane the imaginary parts.  Above the diagonal the coefficients are real, so each lane updates its own half with the same
+// instructions (2 FMAs per entry instead of 4); only the diagonal term (h_jj - z) x_j mixes the halves -- one DPP swap of x and
+// x' per column.  Same operations on the same operands as the one-lane form, both lanes end with the full N.
+// (210 instead of 356 fp64 instructions per evaluation: the iteration is issue-bound, one wave per SIMD.)
+__device__ __forceinline__ void fpt_hyman_newton_pair(const double (&h)[10][10], const double (&isub)[10], const double zr, const double zi,
+                                                      const int comp, double* nr, double* ni)
+{
+    double s[10], t[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) { s[i] = 0.0; t[i] = 0.0; }
+    const double szi = comp ? -zi : zi;
+    double x = comp ? 0.0 : 1.0, d = 0.0, alpha = 0.0, dalpha = 0.0;
+#pragma unroll
+    for (int j = 9; j >= 0; --j) {
+#pragma unroll
+        for (int i = 0; i < j; ++i) { const double hij = h[i][j]; s[i] += hij * x; t[i] += hij * d; }
+        const double px = fpt_pair_swap(x), pd = fpt_pair_swap(d);
+        const double hr_ = h[j][j] - zr;
+        const double a = s[j] + (hr_ * x + szi * px);
+        const double b = t[j] + (hr_ * d + szi * pd) - x;
+        if (j > 0) { const double m = -isub[j]; x = a * m; d = b * m; }
+        else { alpha = a; dalpha = b; }
+    }
+    const double palpha = fpt_pair_swap(alpha), pdalpha = fpt_pair_swap(dalpha);
+    double ar = comp ? palpha : alpha, ai = comp ? alpha : palpha, br = comp ? pdalpha : dalpha, bi = comp ? dalpha : pdalpha;
+    const double sc = fmax(fabs(br), fabs(bi));
+    if (!(sc > 0.0) || !(sc < 1e300)) { *nr = 0.0; *ni = 0.0; return; }
+    const double inv = fpt_rcp(sc);
+    br *= inv; bi *= inv; ar *= inv; ai *= inv;
+    const double dd = fpt_rcp(br * br + bi * bi);
+    *nr = (ar * br + ai * bi) * dd;
+    *ni = (ai * br - ar * bi) * dd;
+}
+#endif
+
 // All ten eigenvalues of the Hessenberg matrix in w.hr at once: Ehrlich-Aberth iteration
 //     z_k <- z_k - N_k / (1 - N_k sum_{j != k} 1 / (z_k - z_j)),   N_k = p(z_k) / p'(z_k)  (fpt_hyman_newton),
 // every root updated from the previous sweep's values (on the device: one root per lane, ten lanes, state in registers, the
@@ -254,6 +298,14 @@ FPT_HD void fpt_aberth10(FptWorkspace& w, double* wr, double* wi, const double a
 #pragma unroll
         for (int j = 0; j < 10; ++j) hreg[i][j] = j >= i ? h[i][j] : 0.0;
     }
+    // made opaque AFTER all the loads are issued: otherwise the compiler re-reads LDS inside the iteration instead of keeping
+    // the 64 values in registers
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        asm volatile("" : "+v"(isubreg[i]));
+#pragma unroll
+        for (int j = i; j < 10; ++j) asm volatile("" : "+v"(hreg[i][j]));
+    }
 #define FPT_H hreg
 #define FPT_ISUB isubreg
 #else
@@ -262,22 +314,24 @@ FPT_HD void fpt_aberth10(FptWorkspace& w, double* wr, double* wi, const double a
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
     {
-        // one root per lane, state in registers; the other roots' positions come over v_readlane (lane index static) and the
-        // stop test is a ballot: no LDS traffic and no barrier inside the iteration
-        const int k = (int)threadIdx.x < 10 ? (int)threadIdx.x : 9;
-        const bool mine = (int)threadIdx.x < 10;
+        // one root per lane PAIR (real / imaginary halves of the Hyman evaluation, everything else computed identically by both),
+        // state in registers; the other roots' positions come over v_readlane (lane index static) and the stop test is a ballot:
+        // no LDS traffic and no barrier inside the iteration
+        const int k = (int)threadIdx.x < 20 ? (int)threadIdx.x >> 1 : 9;
+        const int comp = (int)threadIdx.x & 1;
+        const bool mine = (int)threadIdx.x < 20;
         double zr = wr[k], zi = wi[k], step = 1e300;
         bool done = !mine;
         for (int it = 0; it < kFptAberthSweeps; ++it) {
             double or_[10], oi_[10];
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
-                or_[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zr), j), __builtin_amdgcn_readlane(__double2loint(zr), j));
-                oi_[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zi), j), __builtin_amdgcn_readlane(__double2loint(zi), j));
+                or_[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zr), 2 * j), __builtin_amdgcn_readlane(__double2loint(zr), 2 * j));
+                oi_[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(zi), 2 * j), __builtin_amdgcn_readlane(__double2loint(zi), 2 * j));
             }
             if (!done) {
                 double nr, ni;
-                fpt_hyman_newton(FPT_H, FPT_ISUB, zr, zi, &nr, &ni);
+                fpt_hyman_newton_pair(FPT_H, FPT_ISUB, zr, zi, comp, &nr, &ni);
                 double sr = 0.0, si = 0.0;
 #pragma unroll
                 for (int j = 0; j < 10; ++j) {
@@ -300,7 +354,7 @@ FPT_HD void fpt_aberth10(FptWorkspace& w, double* wr, double* wi, const double a
             if (__ballot(!done && !fpt_aberth_settled_complex(zr, zi, step)) == 0ull) break;
             FPT_STAMP(10 + (it >= 5 ? 5 : it));
         }
-        if (mine) { wr[k] = zr; wi[k] = zi; }
+        if (mine && comp == 0) { wr[k] = zr; wi[k] = zi; }
     }
 #else
     for (int it = 0; it < kFptAberthSweeps; ++it) {
