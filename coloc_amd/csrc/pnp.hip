@@ -285,8 +285,12 @@ __device__ __forceinline__ double d_rodrigues_entry(const double* w, const doubl
     return (A[3 * i] * R[j] + A[3 * i + 1] * R[3 + j] + A[3 * i + 2] * R[6 + j]) / th2;
 }
 
-// Cholesky solve of the damped 6x6 system (A + lambda diag(A)) d = g; returns false if not SPD
-__device__ __forceinline__ bool solve6(const double* A, const double* g, double lambda, double* d)
+// index of entry (i, j), j >= i, in the packed upper triangle the normal-equation sums are kept in (row-major: 00 01 .. 05 11 ..)
+__device__ __forceinline__ constexpr int packed6(const int i, const int j) { return i <= j ? i * 6 - i * (i - 1) / 2 + (j - i) : j * 6 - j * (j - 1) / 2 + (i - j); }
+
+// Cholesky solve of the damped 6x6 system (A + lambda diag(A)) d = g, A given as its PACKED upper triangle (21 values, read
+// where they lie -- LDS: a 6 x 6 register copy costs 72 VGPRs in the one lane that runs this); returns false if not SPD
+__device__ __forceinline__ bool solve6(const double* Ap, const double* g, double lambda, double* d)
 {
     // fully unrolled (compile-time indices) so that L, y stay in registers instead of scratch
     double L[36], Linv[6];    // Linv[i] = 1 / L[i][i]: six divisions instead of twenty-seven
@@ -295,7 +299,8 @@ __device__ __forceinline__ bool solve6(const double* A, const double* g, double 
     for (int i = 0; i < 6; ++i) {
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-            double sum = A[6 * i + j] + (i == j ? lambda * (A[6 * i + i] > 1e-12 ? A[6 * i + i] : 1e-12) : 0.0);
+            const double aij = Ap[packed6(i, j)];
+            double sum = aij + (i == j ? lambda * (aij > 1e-12 ? aij : 1e-12) : 0.0);
 #pragma unroll
             for (int k = 0; k < j; ++k) sum -= L[6 * i + k] * L[6 * j + k];
             if (i == j) { spd = spd && (sum > 0.0); L[6 * i + i] = sqrt(sum > 0.0 ? sum : 1.0); Linv[i] = 1.0 / L[6 * i + i]; }
@@ -321,7 +326,7 @@ __device__ __forceinline__ bool solve6(const double* A, const double* g, double 
     return true;
 }
 
-// column c of A^-1 (A SPD): called by six lanes in parallel, one column each
+// column c of A^-1 (A SPD, packed upper triangle): called by six lanes in parallel, one column each
 __device__ __forceinline__ bool invert6_column(const double* A, int c, double* inv)
 {
     double e[6], col[6];
@@ -402,11 +407,16 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
             const double pu0 = fx * iz, pu1 = sk * iz, pu2 = -(fx * xn + sk * yn) * iz;
             const double pv1 = fy * iz, pv2 = -fy * yn * iz;
             double Ju[6], Jv[6];      // Jacobian of the PROJECTION (residual = obs - proj -> J_r = -J)
+            // the 27 derivative entries are read from LDS per point (uniform address: a broadcast read); hoisted out of the loop
+            // they take 54 VGPRs and push the kernel over its 256-register budget into scratch -- the opaque offset stops that
+            int dro = 0;
+            asm volatile("" : "+v"(dro));
+            const double (*dRp)[9] = reinterpret_cast<const double (*)[9]>(&s_dR[0][0] + dro);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double d0 = s_dR[k][0] * X0 + s_dR[k][1] * X1 + s_dR[k][2] * X2;
-                const double d1 = s_dR[k][3] * X0 + s_dR[k][4] * X1 + s_dR[k][5] * X2;
-                const double d2 = s_dR[k][6] * X0 + s_dR[k][7] * X1 + s_dR[k][8] * X2;
+                const double d0 = dRp[k][0] * X0 + dRp[k][1] * X1 + dRp[k][2] * X2;
+                const double d1 = dRp[k][3] * X0 + dRp[k][4] * X1 + dRp[k][5] * X2;
+                const double d2 = dRp[k][6] * X0 + dRp[k][7] * X1 + dRp[k][8] * X2;
                 Ju[k] = pu0 * d0 + pu1 * d1 + pu2 * d2;
                 Jv[k] = pv1 * d1 + pv2 * d2;
             }
@@ -446,51 +456,69 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
         __syncthreads();
     };
 
-    double lambda = 1e-4;
+    // ONE call site of pass() (it is inlined: two copies cost a dozen spilled VGPRs at the 256-register budget of a 512-thread
+    // workgroup): the first trip evaluates the start s_par, every later one the trial s_try; the Levenberg-Marquardt bookkeeping
+    // around it is the loop  "step -> [flag] -> evaluate -> accept / reject"  unrolled by half a turn.
+    double lambda = 1e-4, cost = 0.0;
     int it = 0;
-    pass(s_par);
-    if (tid < kRefineSums) s_A[tid] = s_tot[tid];
-    __syncthreads();
-    double cost = s_A[27];
-    for (; it < max_iter; ++it) {
-        if (tid == 0) {
-            double A[36], g[6], d[6];
-            int idx = 0;
-            for (int a_ = 0; a_ < 6; ++a_) for (int b_ = a_; b_ < 6; ++b_) { A[6 * a_ + b_] = s_A[idx]; A[6 * b_ + a_] = s_A[idx]; ++idx; }
-            for (int a_ = 0; a_ < 6; ++a_) g[a_] = s_A[21 + a_];
-            bool ok = solve6(A, g, lambda, d);
-            double gn = 0, dn = 0, pn = 0;
-            for (int a_ = 0; a_ < 6; ++a_) { gn = fmax(gn, fabs(g[a_])); dn += d[a_] * d[a_]; pn += s_par[a_] * s_par[a_]; }
-            // convergence like the reference's settings (gradient / parameter tolerance 1e-8, Refiner.hpp:169-171)
-            s_flag = !ok ? 2 : ((gn < 1e-8 * fmax(1.0, cost) || sqrt(dn) < 1e-8 * (sqrt(pn) + 1e-8)) ? 1 : 0);
-            for (int a_ = 0; a_ < 6; ++a_) s_try[a_] = s_par[a_] + (ok ? d[a_] : 0.0);
-        }
-        __syncthreads();
-        const int flag = s_flag;
-        if (flag == 1) break;
-        if (flag == 2) { lambda *= 10.0; if (lambda > 1e10) break; __syncthreads(); continue; }
-        pass(s_try);
-        const double new_cost = s_tot[27];
-        if (new_cost < cost) {
-            const double rel = (cost - new_cost) / fmax(cost, 1e-300);
-            if (tid < 6) s_par[tid] = s_try[tid];
+    bool initial = true;
+    for (;;) {
+        pass(initial ? s_par : s_try);
+        if (initial) {
             if (tid < kRefineSums) s_A[tid] = s_tot[tid];
-            cost = new_cost;
-            lambda = fmax(lambda * 0.1, 1e-12);
             __syncthreads();
-            if (rel < 1e-8) { ++it; break; }                  // function tolerance 1e-8 (Refiner.hpp:169)
+            cost = s_A[27];
+            initial = false;
         } else {
-            lambda *= 10.0;
-            __syncthreads();
-            if (lambda > 1e10) break;
+            const double new_cost = s_tot[27];
+            bool stop = false;
+            if (new_cost < cost) {
+                const double rel = (cost - new_cost) / fmax(cost, 1e-300);
+                if (tid < 6) s_par[tid] = s_try[tid];
+                if (tid < kRefineSums) s_A[tid] = s_tot[tid];
+                cost = new_cost;
+                lambda = fmax(lambda * 0.1, 1e-12);
+                __syncthreads();
+                if (rel < 1e-8) { ++it; stop = true; }                // function tolerance 1e-8 (Refiner.hpp:169)
+            } else {
+                lambda *= 10.0;
+                __syncthreads();
+                if (lambda > 1e10) stop = true;
+            }
+            if (stop) break;
+            ++it;
         }
+        // the next step (rejected factorizations only raise lambda and try again)
+        bool leave = false;
+        for (;;) {
+            if (!(it < max_iter)) { leave = true; break; }
+            if (tid == 0) {
+                double g[6], d[6];
+                for (int a_ = 0; a_ < 6; ++a_) g[a_] = s_A[21 + a_];
+                bool ok = solve6(s_A, g, lambda, d);
+                double gn = 0, dn = 0, pn = 0;
+                for (int a_ = 0; a_ < 6; ++a_) { gn = fmax(gn, fabs(g[a_])); dn += d[a_] * d[a_]; pn += s_par[a_] * s_par[a_]; }
+                // convergence like the reference's settings (gradient / parameter tolerance 1e-8, Refiner.hpp:169-171)
+                s_flag = !ok ? 2 : ((gn < 1e-8 * fmax(1.0, cost) || sqrt(dn) < 1e-8 * (sqrt(pn) + 1e-8)) ? 1 : 0);
+                for (int a_ = 0; a_ < 6; ++a_) s_try[a_] = s_par[a_] + (ok ? d[a_] : 0.0);
+            }
+            __syncthreads();
+            const int flag = s_flag;
+            if (flag == 1) { leave = true; break; }
+            if (flag == 2) {
+                lambda *= 10.0;
+                if (lambda > 1e10) { leave = true; break; }
+                __syncthreads();
+                ++it;
+                continue;
+            }
+            break;
+        }
+        if (leave) break;
     }
     // s_A holds the sums at s_par
     if (tid < 6) {
-        double A[36];
-        int idx = 0;
-        for (int a_ = 0; a_ < 6; ++a_) for (int b_ = a_; b_ < 6; ++b_) { A[6 * a_ + b_] = s_A[idx]; A[6 * b_ + a_] = s_A[idx]; ++idx; }
-        if (!invert6_column(A, tid, out->cov)) for (int r = 0; r < 6; ++r) out->cov[6 * r + tid] = 0.0;
+        if (!invert6_column(s_A, tid, out->cov)) for (int r = 0; r < 6; ++r) out->cov[6 * r + tid] = 0.0;
     }
     if (tid == 0) {
         double R[9];
