@@ -414,9 +414,17 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
         const int remaining = s.n_iter - s.iter;
         const int nb = remaining < kAcrMaxBatch ? remaining : kAcrMaxBatch;
         for (int it = tid; it < nb; it += T) {
-            uint32_t pos[8];
-            clc_acr_sample(pb.seed, (uint32_t)(s.iter + it), (uint32_t)s.n_index, pb.m, pos);
-            for (int j = 0; j < pb.m; ++j) samples[it * pb.m + j] = (int32_t)(src ? src[pos[j]] : pos[j]);
+            if (pb.m == 3) {                                       // P3P
+                uint32_t pos[3];
+                clc_acr_sample_t<3>(pb.seed, (uint32_t)(s.iter + it), (uint32_t)s.n_index, pos);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) samples[it * 3 + j] = (int32_t)(src ? src[pos[j]] : pos[j]);
+            } else {                                               // five-point
+                uint32_t pos[5];
+                clc_acr_sample_t<5>(pb.seed, (uint32_t)(s.iter + it), (uint32_t)s.n_index, pos);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) samples[it * 5 + j] = (int32_t)(src ? src[pos[j]] : pos[j]);
+            }
         }
     }
     if (tid == 0) {

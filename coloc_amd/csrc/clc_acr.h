@@ -129,6 +129,34 @@ CLC_ACR_HD void clc_acr_sample(uint64_t seed, uint32_t iter, uint32_t n_index, i
     }
 }
 
+// the same draw with the sample size as a template argument: every index is a compile-time constant, so on the GPU the positions
+// stay in registers (with a run-time m the array is dynamically indexed private memory: 48 B of scratch in the select kernel,
+// a memory round trip per access in a kernel that is nothing but a latency chain)
+#if defined(__cplusplus)
+template <int M>
+CLC_ACR_HD void clc_acr_sample_t(uint64_t seed, uint32_t iter, uint32_t n_index, uint32_t (&pos)[M])
+{
+    uint64_t s = clc_acr_mix(seed ^ clc_acr_mix((uint64_t)iter + 1u));
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int j = 0; j < M; ++j) {
+        uint32_t p;
+        bool again;
+        do {
+            s = clc_acr_mix(s);
+            p = (uint32_t)(((s >> 32) * (uint64_t)n_index) >> 32);
+            again = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+            for (int q = 0; q < M; ++q) again = again || (q < j && pos[q] == p);
+        } while (again);
+        pos[j] = p;
+    }
+}
+#endif
+
 // ---- NFA term -----------------------------------------------------------------------------------------------------
 // log10 NFA of taking the k smallest residuals as inliers (bestNFA in OpenMVG's robust_estimator_ACRansac.hpp):
 //   loge0 + (logalpha0 + mult * log10(e_k + FLT_EPSILON)) * (k - m) + logc_n[k] + logc_k[k],  evaluated left to right,
