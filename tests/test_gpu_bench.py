@@ -56,6 +56,19 @@ def test_two_rank_rehearsal_runs():
     assert d["n_gpus"] == 2 and d["config"]["pairs"] == 1 and d["value"] > 0 and "REHEARSAL" in d["collective"]
 
 
+def test_four_rank_rehearsal_runs():
+    """Four cameras on four ranks (sharing the one GPU, gloo staging): 6 pairs dealt over 4 ranks, every rank takes part in
+    the same number of collectives through warm-up, timed, sustained and breakdown legs."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FAULT_AFTER="200")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "1",
+           "--backend", "gloo", "--sustain-seconds", "0.2"]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    d = _last_json(out.stdout)
+    assert d["n_gpus"] == 4 and d["config"]["pairs"] == 6 and d["value"] > 0 and "REHEARSAL" in d["collective"]
+
+
 def test_streaming_scenario_runs_and_localizes():
     """BASELINE config[4] shape on one GPU, on RENDERED frames: the descriptors the front end computes are the ones matched
     against the map (CLATCH output of a reference view) and the a-contrario pose must land on the pose each frame was
