@@ -148,13 +148,36 @@ def look_at_plane_pose(center_xy, height, yaw=0.0, tilt=(0.0, 0.0)):
     return R, -R @ C
 
 
-def render_plane(tex, tex_px_per_unit, K, R, t, W=640, H=480):
-    """Image of the plane z = 0 (texture pixel (u, v) <-> world (u, v) / tex_px_per_unit) from camera [R|t], bilinear."""
+def smooth_relief(centres=((6.2, 6.4, 0.45, 0.9), (8.0, 7.6, 0.35, 0.7), (7.1, 8.3, 0.30, 0.6), (7.9, 6.0, 0.40, 0.8))):
+    """A gentle height field h(X, Y) >= 0 (Gaussian bumps: x, y, height, radius) that lifts the surface z = -h(X, Y) towards the
+    cameras: breaks the planar two-fold ambiguity of the essential matrix without creating occlusions."""
+    def h(X, Y):
+        out = np.zeros_like(X, dtype=np.float64)
+        for cx, cy, a, r in centres:
+            out = out + a * np.exp(-((X - cx) ** 2 + (Y - cy) ** 2) / (2 * r * r))
+        return out
+    return h
+
+
+def _surface_hit(o, dw, relief):
+    """Ray o + lam dw against the surface z = -relief(X, Y) (the plane z = 0 without relief): fixed-point iteration on lam,
+    a contraction for slopes well below the rays' inclination."""
+    lam = -o[2] / dw[2]
+    if relief is not None:
+        for _ in range(8):
+            Xw = o[:, None] + lam * dw
+            lam = (-relief(Xw[0], Xw[1]) - o[2]) / dw[2]
+    return lam
+
+
+def render_plane(tex, tex_px_per_unit, K, R, t, W=640, H=480, relief=None):
+    """Image of the surface z = -relief(X, Y) (the plane z = 0 by default; texture pixel (u, v) <-> world (X, Y) =
+    (u, v) / tex_px_per_unit) from camera [R|t], bilinear."""
     v, u = np.mgrid[0:H, 0:W]
     d = np.linalg.inv(K) @ np.stack([u.ravel() + 0.0, v.ravel() + 0.0, np.ones(W * H)])
     o = -R.T @ t
     dw = R.T @ d
-    lam = -o[2] / dw[2]
+    lam = _surface_hit(o, dw, relief)
     Xw = o[:, None] + lam * dw
     tu, tv = Xw[0] * tex_px_per_unit, Xw[1] * tex_px_per_unit
     x0 = np.clip(np.floor(tu).astype(np.int64), 0, tex.shape[1] - 2)
@@ -166,10 +189,10 @@ def render_plane(tex, tex_px_per_unit, K, R, t, W=640, H=480):
     return np.clip(img + 0.5, 0, 255).astype(np.uint8).reshape(H, W)
 
 
-def backproject_to_plane(px, K, R, t):
-    """World points (n x 3, z = 0) seen at pixels px (n x 2) by camera [R|t]."""
+def backproject_to_plane(px, K, R, t, relief=None):
+    """World points (n x 3, on z = -relief(X, Y), the plane z = 0 by default) seen at pixels px (n x 2) by camera [R|t]."""
     d = np.linalg.inv(K) @ np.c_[px, np.ones(len(px))].T
     o = -R.T @ t
     dw = R.T @ d
-    lam = -o[2] / dw[2]
+    lam = _surface_hit(o, dw, relief)
     return (o[:, None] + lam * dw).T
