@@ -26,27 +26,47 @@
 #define P3P_HD static inline
 #endif
 
+// The solver is one long dependent chain per lane (a P3P launch is 128 x 4 lanes: latency, not throughput), so it is written
+// for few instructions: fused multiply-adds (the library is otherwise built with -ffp-contract=off for the kernels whose
+// results are compared bit for bit with the oracle; nothing here is -- the poses are checked against an independent solver to a
+// tolerance, and the a-contrario oracle takes its minimal solutions from this very code), and reciprocals by v_rcp_f64 + two
+// Newton steps (1 ulp) instead of the IEEE division sequence (57 divisions per solve, ~10 instructions each).
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double p3p_rcp(const double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+#else
+P3P_HD double p3p_rcp(const double x) { return 1.0 / x; }
+#endif
+
 // real roots of x^3 + a x^2 + b x + c: returns count (1 or 3)
 P3P_HD int p3p_solve_cubic(double a, double b, double c, double* x)
 {
-    const double a3 = a / 3.0;
+    const double a3 = a * (1.0 / 3.0);
     const double p = b - a * a3;
     const double q = 2.0 * a3 * a3 * a3 - a3 * b + c;
-    const double disc = 0.25 * q * q + p * p * p / 27.0;
+    const double disc = 0.25 * q * q + p * p * p * (1.0 / 27.0);
     if (disc > 0.0) {
         const double s = sqrt(disc);
         const double u = cbrt(-0.5 * q + s), v = cbrt(-0.5 * q - s);
         x[0] = u + v - a3;
         return 1;
     }
-    const double r = sqrt(-p * p * p / 27.0);
-    double cosphi = r > 0.0 ? -0.5 * q / r : 0.0;
+    const double r = sqrt(-p * p * p * (1.0 / 27.0));
+    double cosphi = r > 0.0 ? -0.5 * q * p3p_rcp(r) : 0.0;
     cosphi = cosphi > 1.0 ? 1.0 : (cosphi < -1.0 ? -1.0 : cosphi);
     const double phi = acos(cosphi);
-    const double m = 2.0 * sqrt(-p / 3.0);
-    x[0] = m * cos(phi / 3.0) - a3;
-    x[1] = m * cos((phi + 2.0 * M_PI) / 3.0) - a3;
-    x[2] = m * cos((phi + 4.0 * M_PI) / 3.0) - a3;
+    const double m = 2.0 * sqrt(-p * (1.0 / 3.0));
+    x[0] = m * cos(phi * (1.0 / 3.0)) - a3;
+    x[1] = m * cos((phi + 2.0 * M_PI) * (1.0 / 3.0)) - a3;
+    x[2] = m * cos((phi + 4.0 * M_PI) * (1.0 / 3.0)) - a3;
     return 3;
 }
 
@@ -56,7 +76,8 @@ P3P_HD int p3p_solve_cubic(double a, double b, double c, double* x)
 // the slots that hold a real root.
 P3P_HD int p3p_solve_quartic(const double* co, double* roots)
 {
-    const double a = co[3] / co[4], b = co[2] / co[4], c = co[1] / co[4], d = co[0] / co[4];
+    const double i4 = p3p_rcp(co[4]);
+    const double a = co[3] * i4, b = co[2] * i4, c = co[1] * i4, d = co[0] * i4;
     // depressed quartic y^4 + p y^2 + q y + r, x = y - a/4
     const double a2 = a * a;
     const double p = b - 0.375 * a2;
@@ -82,7 +103,7 @@ P3P_HD int p3p_solve_quartic(const double* co, double* roots)
         if (m > 0.0) {
             const double s = sqrt(2.0 * m);
             const double t0 = 0.5 * p + m;
-            const double t1 = q / (2.0 * s);
+            const double t1 = q * p3p_rcp(2.0 * s);
             // y^2 + s y + (t0 - t1) = 0  and  y^2 - s y + (t0 + t1) = 0
             double disc = s * s - 4.0 * (t0 - t1);
             if (disc >= 0.0) { const double sq = sqrt(disc); y0 = 0.5 * (-s + sq); y1 = 0.5 * (-s - sq); mask |= 3; }
@@ -101,7 +122,7 @@ P3P_HD double p3p_polish_root(const double* co, double x)
         const double f = (((co[4] * x + co[3]) * x + co[2]) * x + co[1]) * x + co[0];
         const double df = ((4.0 * co[4] * x + 3.0 * co[3]) * x + 2.0 * co[2]) * x + co[1];
         if (df == 0.0) break;
-        x -= f / df;
+        x -= f * p3p_rcp(df);
     }
     return x;
 }
@@ -117,7 +138,8 @@ P3P_HD bool p3p_normalize(double* a)
 {
     const double n = sqrt(p3p_dot(a, a));
     if (!(n > 1e-300)) return false;
-    a[0] /= n; a[1] /= n; a[2] /= n;
+    const double in = p3p_rcp(n);
+    a[0] *= in; a[1] *= in; a[2] *= in;
     return true;
 }
 // orthonormal triad (columns e1,e2,e3) of three points
@@ -153,7 +175,7 @@ P3P_HD bool p3p_prepare(const double X[3][3], const double f[3][3], P3PProblem& 
     p.mask = 0;
     if (!(a2 > 0.0) || !(b2 > 0.0) || !(c2 > 0.0)) return false;
     const double ca = p3p_dot(f[1], f[2]), cb = p3p_dot(f[0], f[2]), cg = p3p_dot(f[0], f[1]);
-    const double q = (a2 - c2) / b2;
+    const double q = (a2 - c2) * p3p_rcp(b2);
     // polynomials in v, ascending coefficients
     p.N[0] = q + 1.0; p.N[1] = -2.0 * q * cb; p.N[2] = q - 1.0;
     p.D[0] = 2.0 * cg; p.D[1] = -2.0 * ca;
@@ -177,7 +199,8 @@ P3P_HD bool p3p_prepare(const double X[3][3], const double f[3][3], P3PProblem& 
         p.polish = true;
     } else if (fabs(co[3]) > 1e-12 * scale) {
         p.roots[3] = 0.0;
-        p.mask = (1 << p3p_solve_cubic(co[2] / co[3], co[1] / co[3], co[0] / co[3], p.roots)) - 1;
+        const double i3 = p3p_rcp(co[3]);
+        p.mask = (1 << p3p_solve_cubic(co[2] * i3, co[1] * i3, co[0] * i3, p.roots)) - 1;
         p.polish = false;
     } else {
         return false;
@@ -195,11 +218,11 @@ P3P_HD bool p3p_pose_from_root(const P3PProblem& p, const double X[3][3], const 
     if (!(v > 0.0)) return false;
     const double den = p.D[0] + p.D[1] * v;
     if (fabs(den) < 1e-12) return false;
-    const double u = (p.N[0] + (p.N[1] + p.N[2] * v) * v) / den;
+    const double u = (p.N[0] + (p.N[1] + p.N[2] * v) * v) * p3p_rcp(den);
     if (!(u > 0.0)) return false;
     const double w = p.W[0] + (p.W[1] + p.W[2] * v) * v;
     if (!(w > 0.0)) return false;
-    const double s1 = sqrt(p.b2 / w), s2 = u * s1, s3 = v * s1;
+    const double s1 = sqrt(p.b2 * p3p_rcp(w)), s2 = u * s1, s3 = v * s1;
     const double Q0[3] = { s1 * f[0][0], s1 * f[0][1], s1 * f[0][2] };
     const double Q1[3] = { s2 * f[1][0], s2 * f[1][1], s2 * f[1][2] };
     const double Q2[3] = { s3 * f[2][0], s3 * f[2][1], s3 * f[2][2] };
@@ -223,5 +246,9 @@ P3P_HD int p3p_solve(const double X[3][3], const double f[3][3], double* Rt_out)
         if (p3p_pose_from_root(p, X, f, k, Rt_out + 12 * ns)) ++ns;
     return ns;
 }
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
 
 #endif

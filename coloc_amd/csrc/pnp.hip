@@ -106,15 +106,16 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
     double Xs[3][3], f[3][3];
     bool ok = true;
     const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const double ifx = p3p_rcp(fx), ify = p3p_rcp(fy);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         int i = samples[3 * sidx + p];
         if (i < 0 || i >= N) { ok = false; i = 0; }
         Xs[p][0] = X[3 * i]; Xs[p][1] = X[3 * i + 1]; Xs[p][2] = X[3 * i + 2];
-        const double yn = (x[2 * i + 1] - cy) / fy;
-        const double xn = (x[2 * i] - cx - sk * yn) / fx;
-        const double nrm = sqrt(xn * xn + yn * yn + 1.0);
-        f[p][0] = xn / nrm; f[p][1] = yn / nrm; f[p][2] = 1.0 / nrm;
+        const double yn = (x[2 * i + 1] - cy) * ify;
+        const double xn = (x[2 * i] - cx - sk * yn) * ifx;
+        const double inrm = p3p_rcp(sqrt(xn * xn + yn * yn + 1.0));
+        f[p][0] = xn * inrm; f[p][1] = yn * inrm; f[p][2] = inrm;
     }
     P3PProblem prob;
     ok = ok && p3p_prepare(Xs, f, prob);
