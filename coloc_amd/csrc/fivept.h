@@ -27,6 +27,13 @@
 
 #include <math.h>
 
+// Fused multiply-adds throughout (the library's default is -ffp-contract=off, for the kernels whose results are compared bit for
+// bit with the oracle; nothing here is: the solutions are checked by their defining properties and against the host build of
+// this same file to 1e-7).  Restored at the end of csrc/fivept_wave.h / of this file.
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif
+
 #if defined(__HIPCC__) || defined(__HIP__)
 #define FPT_HD __host__ __device__ inline
 #else
@@ -727,6 +734,10 @@ static inline int fivept_solve(const double q1[5][2], const double q2[5][2], dou
     }
     return fpt_compact(w, E_out);
 }
+#endif
+
+#if defined(__clang__) && !defined(CLC_FIVEPT_WAVE_H)
+#pragma clang fp contract(off)
 #endif
 
 #endif

@@ -351,4 +351,8 @@ __device__ __forceinline__ int solve(const double q1[5][2], const double q2[5][2
 } // namespace fpw
 
 #endif // device
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 #endif

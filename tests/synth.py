@@ -148,7 +148,7 @@ def look_at_plane_pose(center_xy, height, yaw=0.0, tilt=(0.0, 0.0)):
     return R, -R @ C
 
 
-def smooth_relief(centres=((6.2, 6.4, 0.45, 0.9), (8.0, 7.6, 0.35, 0.7), (7.1, 8.3, 0.30, 0.6), (7.9, 6.0, 0.40, 0.8))):
+def smooth_relief(centres=((6.2, 6.4, 0.80, 0.9), (8.0, 7.6, 0.60, 0.7), (7.1, 8.3, 0.50, 0.6), (7.9, 6.0, 0.70, 0.8))):
     """A gentle height field h(X, Y) >= 0 (Gaussian bumps: x, y, height, radius) that lifts the surface z = -h(X, Y) towards the
     cameras: breaks the planar two-fold ambiguity of the essential matrix without creating occlusions."""
     def h(X, Y):
