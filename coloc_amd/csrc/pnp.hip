@@ -349,6 +349,9 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
                                                                     const int max_iter, const int32_t* __restrict__ valid,
                                                                     RefineOut* __restrict__ out_dev, RefineOut* __restrict__ out_host)
 {
+    // fused multiply-adds in this kernel (the file default is off for the residual kernels compared bit for bit with the oracle;
+    // the refinement is checked against scipy / numeric Jacobians to a tolerance)
+#pragma clang fp contract(fast)
     RefineOut* const out = out_host ? out_host : out_dev;      // pinned host record (no D2H copy command) or device record
     if (valid && *valid < 0) {          // chained after clc_pnp_ransac that found no pose: nothing to refine
         if (threadIdx.x < 12) out->Rt[threadIdx.x] = 0.0;
