@@ -87,6 +87,40 @@ __device__ __forceinline__ double acr_shfl_xor(const double v, const int mask)
     return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// lane ^ D exchange of one dword over DPP (vector-ALU moves, a few cycles) for the distances that have a DPP form; ds_bpermute
+// (an LDS-crossbar round trip, ~100 cycles) otherwise (v_permlane16/32_swap for 16 and 32 measured no better).  The sort is a chain of 55 dependent steps per wave and 34 of its 45
+// in-wave steps have distance 1, 2, 4 or 8 (ablation: the sort is 8 of the kernel's 14.8 us, and halving its vector instruction
+// count changed nothing -- it is latency per step).  D is a template argument: a run-time switch in every step cost more than
+// the DPP moves saved.
+template <int D>
+__device__ __forceinline__ uint32_t acr_lane_xor(const uint32_t v)
+{
+    if (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    if (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);       // quad_perm [2,3,0,1]
+    if (D == 4) {
+        int r = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);                      // row_shl:4 into lanes 0-3, 8-11 of a row
+        r = __builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xF, 0xA, false);                          // row_shr:4 into lanes 4-7, 12-15
+        return (uint32_t)r;
+    }
+    if (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);      // row_ror:8
+    return __shfl_xor(v, D);
+}
+// one in-wave compare-exchange step of the composite-key network: partner thread tid ^ DT (DT < 64), same slot
+template <int E, int DT>
+__device__ __forceinline__ void acr_step_wave(double (&c)[E], const int k, const int tid)
+{
+    const bool lower = (tid & DT) == 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint64_t u = (uint64_t)__double_as_longlong(c[e]);
+        const uint32_t lo32 = acr_lane_xor<DT>((uint32_t)u), hi32 = acr_lane_xor<DT>((uint32_t)(u >> 32));
+        const double o = __longlong_as_double((long long)(((uint64_t)hi32 << 32) | lo32));
+        const bool keep_min = lower == (((tid * E + e) & k) == 0);
+        const double lo = acr_fmin(c[e], o), hi = acr_fmax(c[e], o);
+        c[e] = keep_min ? lo : hi;
+    }
+}
+
 template <int E, bool EXACT>
 __device__ __forceinline__ void acr_bitonic(uint64_t (&key)[E], uint32_t (&idx)[E], double (&c)[E], const int P, const int tid, const int T,
                                             uint64_t* lkey, uint32_t* lidx)
@@ -115,6 +149,18 @@ __device__ __forceinline__ void acr_bitonic(uint64_t (&key)[E], uint32_t (&idx)[
                         }
                     }
                 }
+            } else if (!EXACT && j / E < 64) {
+                // the in-wave tail of a merge is always the same run of distances 32, 16, .. 1 from wherever it starts: straight-line
+                // code with compile-time distances, entered at the right place (a not-taken skip costs a cycle; a switch per step
+                // costs more than the DPP moves save)
+                const int d0 = j / E;
+                if (d0 >= 32) acr_step_wave<E, 32>(c, k, tid);
+                if (d0 >= 16) acr_step_wave<E, 16>(c, k, tid);
+                if (d0 >= 8) acr_step_wave<E, 8>(c, k, tid);
+                if (d0 >= 4) acr_step_wave<E, 4>(c, k, tid);
+                if (d0 >= 2) acr_step_wave<E, 2>(c, k, tid);
+                acr_step_wave<E, 1>(c, k, tid);
+                j = E;                                                   // the loop continues with the in-register steps (j < E), if any
             } else {
                 const int dt = j / E;                                    // partner thread = tid ^ dt, same e
                 const bool lower = (tid & dt) == 0;
