@@ -409,6 +409,44 @@ def main():
             if not same:
                 raise RuntimeError("the two K2NN formulations disagree")
 
+        def sec_two_streams():
+            # Throughput with consecutive steps OVERLAPPED (informational, not `value`): step i on stream / context / arena i & 1, so the
+            # K2NN sweep of one step (matrix pipe) runs beside the pyramid + CLATCH of the next (vector ALU + LDS).  Every step does all
+            # of its work and the results are checked against the sequential run; what changes is that the GPU is not drained between
+            # a step's sweep and the next step's describe -- how a streaming host would drive it.
+            if world != 1 or not abi_jobs:
+                return
+            ctx2 = Context(device=dev_index, width=W, height=H, maxkp=NKP)
+            try:
+                st2 = torch.cuda.Stream(device=dev)
+                arena2 = torch.zeros_like(arena)
+                match2 = torch.empty_like(d_match)
+                lanes = [(ctx, sptr, arena, d_match, [arena[c].data_ptr() for c in cams]),
+                         (ctx2, st2.cuda_stream, arena2, match2, [arena2[c].data_ptr() for c in cams])]
+                want = d_match[:n_out].clone()
+
+                def go(i):
+                    c_, s_, a_, m_, dp_ = lanes[i & 1]
+                    c_.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP] * len(cams), dp_, s_)
+                    c_.match_jobs_dev(a_.data_ptr(), abi_jobs, m_.data_ptr(), s_)
+                for i in range(20):
+                    go(i)
+                torch.cuda.synchronize()
+                n = max(200, int(0.5 / max(ms_per_step * 1e-3, 1e-6)))
+                t0 = time.perf_counter()
+                for i in range(n):
+                    go(i)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t0
+                same = bool(torch.equal(want, match2[:n_out])) and bool(torch.equal(want, d_match[:n_out]))
+                out["stages"]["two_streams_overlapped"] = {
+                    "what": "consecutive steps alternate between two streams / contexts / descriptor arenas; identical results per step",
+                    "steps": n, "ms_per_step": dt2 / n * 1e3, "Mmatches_per_s": total_cmp / (dt2 / n) / 1e6, "identical_results": same}
+                if not same:
+                    raise RuntimeError("overlapped steps produced different matches")
+            finally:
+                ctx2.close()
+
         def sec_front_end():
             # GPU-resident front end on a real frame (informational): pyramid -> FAST-9/NMS/orientation ->
             # CLATCH with the keypoint count kept in device memory (no host round trip)
@@ -520,6 +558,7 @@ def main():
         guarded("clatch_roofline", sec_clatch)
         guarded("host_path", sec_host_path)
         guarded("k2nn_ab", sec_k2nn_ab)
+        guarded("two_streams", sec_two_streams)
         guarded("front_end", sec_front_end)
         guarded("pose_solve", sec_pose)
         guarded("two_view", sec_two_view)

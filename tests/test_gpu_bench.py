@@ -37,6 +37,8 @@ def test_default_line_has_contract_fields():
     assert 1.0 < r["clock_ghz_in_kernel"]["median"] <= 2.5          # the chip's real in-kernel clock, not an assumed 2.4
     assert d["sustained"]["seconds"] >= 1.0 and d["sustained"]["steps"] >= 20 and d["sustained_value"] > 0
     assert d["stages"]["k2nn_other_formulation"]["identical_results"] is True
+    ts = d["stages"]["two_streams_overlapped"]                       # consecutive steps on alternating streams: same matches, not slower
+    assert ts["identical_results"] is True and ts["ms_per_step"] < 1.05 * d["sustained"]["ms_per_step"]
     assert d["accepted_matches_per_step"] > 5000                     # the two cameras see the same scene
     assert "acransac" in d["pose_solve"]["rule"].lower() or "a-contrario" in d["pose_solve"]["rule"]
     assert d["pose_solve_p50_ms"] > 0 and "section_errors" not in d
