@@ -414,8 +414,8 @@ def main():
             # K2NN sweep of one step (matrix pipe) runs beside the pyramid + CLATCH of the next (vector ALU + LDS).  Every step does all
             # of its work and the results are checked against the sequential run; what changes is that the GPU is not drained between
             # a step's sweep and the next step's describe -- how a streaming host would drive it.
-            if world != 1 or not abi_jobs:
-                return
+            if world != 1 or not abi_jobs or args.sustain_seconds <= 0:      # --sustain-seconds 0 (the rocprofv3 passes): one stream only,
+                return                                                          # so that per-kernel averages are of kernels that had the machine
             ctx2 = Context(device=dev_index, width=W, height=H, maxkp=NKP)
             try:
                 st2 = torch.cuda.Stream(device=dev)
