@@ -16,7 +16,9 @@ path = "/tmp/k2nn_stamps.bin"
 os.environ["CLC_K2NN_STAMP_DUMP"] = path
 clk = ctx.k2nn_clock_check(dq.data_ptr(), 10000, dt.data_ptr(), 10000, dm.data_ptr())
 h = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
-h = h[h[:, 4] > 0]
+keep = h[:, 4] > 0
+ids = np.nonzero(keep)[0]
+h = h[keep]
 t0 = h[:, 4].min()
 ent, ls, le, ex = [(h[:, i].astype(np.int64) - int(t0)) * 0.01 for i in (4, 1, 3, 5)]       # microseconds
 xcc = h[:, 7] & 0xF
@@ -38,3 +40,8 @@ for x in range(8):
 # how many workgroups are inside their loop at each instant
 for tt in np.arange(0, ex.max() + 1, 2.0):
     print("  t=%5.1f us: %3d entered, %3d in loop, %3d done" % (tt, (ent <= tt).sum(), ((ls <= tt) & (le > tt)).sum(), (ex <= tt).sum()))
+# loop length against the dispatch order (linear workgroup id = stamp slot): is "oldest on the CU runs fastest" visible?
+wg = ids                        # rows are in blockIdx.x order (one job)
+for lo in range(0, len(h), 128):
+    m = (wg >= lo) & (wg < lo + 128)
+    print("  workgroups %3d-%3d: loop length p50 %.2f us, loop end p50 %.2f us" % (lo, min(lo + 127, len(h) - 1), np.median((le - ls)[m]), np.median(le[m])))
