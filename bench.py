@@ -474,7 +474,7 @@ def main():
             for n_pts in (200, 1000, 5000):
                 sc = synth.pnp_scene(n_pts, seed=4000 + n_pts)
                 ta, tl, its = [], [], []
-                reps = 60 if n_pts != 1000 else 200
+                reps = 60 if n_pts != 1000 else 210          # >= 200 timed solves at the headline size after the 5 warm-up ones
                 for it in range(reps):
                     t1 = time.perf_counter()
                     r = ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], max_iteration=256, seed=it + 1)
