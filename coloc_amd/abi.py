@@ -52,6 +52,7 @@ EXPORTS = [
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put",
+    "clc_mc_gather_enqueue_dev", "clc_mc_match_enqueue_dev", "clc_mc_counts", "clc_match_jobs_counted_dev",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -154,6 +155,10 @@ def load_library():
     lib.clc_mc_gather_dev.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.clc_mc_virtual_put.argtypes = [vp, ci, vp, ci, vp]
     lib.clc_mc_match_dev.argtypes = [vp, ci, vp, ci, vp, ci, ip, vp]
+    lib.clc_mc_gather_enqueue_dev.argtypes = [vp, vp, ci, vp, ci, vp]
+    lib.clc_mc_match_enqueue_dev.argtypes = [vp, ci, vp, ci, vp, ci, ip, vp]
+    lib.clc_mc_counts.argtypes = [vp, vp, vp]
+    lib.clc_match_jobs_counted_dev.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.clc_k2nn_clock_check.argtypes = [vp, vp, ci, vp, ci, vp, vp, dp, dp, dp, ip]
     lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
     lib.clc_k2nn_queries_per_block.argtypes = [vp]
@@ -235,6 +240,23 @@ class MultiCam:
         n = C.c_int()
         self._chk(self.lib.clc_mc_match_dev(self.h, int(threshold), d_match, int(capacity), sh, cap, C.byref(n), stream))
         return [(s.first, s.second, s.q_begin, s.nq, s.out_offset) for s in sh[:n.value]]
+
+    def gather_enqueue_dev(self, d_my_desc, my_count, mode=0, stream=None, d_my_count=None):
+        """Enqueue-only exchange (no host synchronisation); my_count from the host, or d_my_count: device address of an int32."""
+        self._chk(self.lib.clc_mc_gather_enqueue_dev(self.h, d_my_desc, int(my_count), d_my_count, int(mode), stream))
+
+    def match_enqueue_dev(self, threshold, d_match, capacity, stream=None):
+        """Capacity-planned shares, counts read on the device: pairs with clc_mc_gather_enqueue_dev."""
+        cap = self.world * self.world + 2
+        sh = (McShare * cap)()
+        n = C.c_int()
+        self._chk(self.lib.clc_mc_match_enqueue_dev(self.h, int(threshold), d_match, int(capacity), sh, cap, C.byref(n), stream))
+        return [(s.first, s.second, s.q_begin, s.nq, s.out_offset) for s in sh[:n.value]]
+
+    def counts(self, stream=None):
+        cnt = (C.c_int * self.world)()
+        self._chk(self.lib.clc_mc_counts(self.h, cnt, stream))
+        return [int(c) for c in cnt]
 
     def close(self):
         if getattr(self, "h", None):

@@ -642,7 +642,10 @@ int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t,
         CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
         ctx->partial_dirty = false;
     }
-    const size_t nwg = (size_t)jobs[0].qblocks * jobs[0].splits;
+    // the launch grid pads the query blocks to a multiple of 8 (XCD-dealt order, k2nn.hip) and a stamped workgroup
+    // writes row blockIdx.y * gridDim.x + blockIdx.x: size the buffer for the PADDED grid (rows of padding workgroups
+    // stay zero and are skipped below)
+    const size_t nwg = (size_t)((jobs[0].qblocks + 7u) & ~7u) * jobs[0].splits;
     uint64_t* d_stamps = nullptr;
     CLC_HIP(ctx, hipMalloc((void**)&d_stamps, nwg * 8 * sizeof(uint64_t)));
     std::vector<uint64_t> h(nwg * 8);
@@ -709,6 +712,37 @@ int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_jo
         jb.nq = h_jobs[j].nq;
         jb.nt = h_jobs[j].nt;
         jb.thr = (uint32_t)(uint8_t)h_jobs[j].threshold;
+        jobs.push_back(jb);
+    }
+    if (jobs.empty()) return CLC_OK;
+    return run_jobs(ctx, jobs, pick(ctx, stream));
+}
+
+int clc_match_jobs_counted_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs, int njobs,
+                               const int32_t* const* d_cnt_q, const int32_t* const* d_cnt_t, const uint32_t* q_row0,
+                               int32_t* d_match, void* stream)
+{
+    if (!ctx || njobs < 0 || (njobs > 0 && (!d_desc_base || !h_jobs || !d_match || !d_cnt_q || !d_cnt_t || !q_row0)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs_counted: bad argument");
+    if (((uintptr_t)d_desc_base & 15u) || ((uintptr_t)d_match & 3u))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs_counted: device pointers must be 16-byte aligned");
+    if (njobs == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<K2nnJobDev> jobs;
+    jobs.reserve(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        if (h_jobs[j].nq == 0) continue;
+        // a planned train set of zero rows can hold nothing whatever the device count says; the sweep needs at least one split to
+        // answer the planned rows, so such a job is run with one (empty) planned row -- the count clamps it to zero again
+        if (!d_cnt_q[j] || !d_cnt_t[j]) return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs_counted: null count pointer");
+        K2nnJobDev jb{};
+        jb.q = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].q_offset * CLC_DESC_BYTES);
+        jb.t = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].t_offset * CLC_DESC_BYTES);
+        jb.out = d_match + h_jobs[j].out_offset;
+        jb.nq = h_jobs[j].nq;
+        jb.nt = h_jobs[j].nt ? h_jobs[j].nt : 1u;
+        jb.thr = (uint32_t)(uint8_t)h_jobs[j].threshold;
+        jb.cnt_q = d_cnt_q[j]; jb.cnt_t = d_cnt_t[j]; jb.q_row0 = q_row0[j];
         jobs.push_back(jb);
     }
     if (jobs.empty()) return CLC_OK;

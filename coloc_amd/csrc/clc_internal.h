@@ -76,7 +76,27 @@ struct K2nnJobDev {
     uint32_t     nq_pad;      // row length of the slab
     uint32_t     atomic_merge;// 1: splits are folded with two atomicMin per query into a top-2 row, no slab
     uint32_t     cnt_off;     // atomic mode: first arrival counter (one per query block) of this job, in uint32 units
+    // device-resident row counts (nullable; the multi-camera step plans its shares on the block CAPACITY and lets the sweep read the
+    // gathered counts itself, so that no host synchronisation sits between the exchange and the sweep): with cnt_q the job covers
+    // query rows [q_row0, q_row0 + nq) of a set of *cnt_q valid rows -- rows past the end are answered -1 --, with cnt_t the train
+    // set has min(nt, *cnt_t) rows.  nq / nt stay the planned sizes (grid, splits, result layout).
+    const int32_t* cnt_q;
+    const int32_t* cnt_t;
+    uint32_t     q_row0;
 };
+// the sizes a sweep workgroup works with (scalar loads when the counts live in device memory)
+__device__ __forceinline__ uint32_t k2nn_job_nq(const K2nnJobDev& job)
+{
+    if (!job.cnt_q) return job.nq;
+    const int left = *job.cnt_q - (int)job.q_row0;
+    return left <= 0 ? 0u : ((uint32_t)left < job.nq ? (uint32_t)left : job.nq);
+}
+__device__ __forceinline__ uint32_t k2nn_job_nt(const K2nnJobDev& job)
+{
+    if (!job.cnt_t) return job.nt;
+    const int c = *job.cnt_t;
+    return c <= 0 ? 0u : ((uint32_t)c < job.nt ? (uint32_t)c : job.nt);
+}
 static constexpr int kK2nnJobsPerLaunch = 16;
 // Passed BY VALUE as the kernel argument (1.2 KB of kernarg): no job upload, no staging hazard.
 struct K2nnJobList {

@@ -134,6 +134,7 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
 {
     __shared__ uint32_t s_best[kWaves - 1][R][64], s_second[kWaves - 1][R][64];
     const K2nnJobDev& job = jobs.j[blockIdx.y];
+    const uint32_t job_nq = k2nn_job_nq(job), job_nt = k2nn_job_nt(job);     // == job.nq / job.nt unless the counts live on the device
     // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id and every XCD has its own L2.
     // The planner makes `splits` a multiple of 8 (and with it gridDim.x), so XCD x only ever sees the train splits
     // with (split & 7) == x: each L2 holds an eighth of T plus the queries, the 8 L2s together pull 8 Q + T from HBM
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         uint32_t qi = qbase + 64u * r;
-        if (qi >= job.nq) qi = job.nq - 1u;   // clamp: duplicate work, never stored
+        if (qi >= job_nq) qi = job_nq ? job_nq - 1u : 0u;   // clamp: duplicate work, never stored (row 0 of the block always exists)
         const global_cu4_ptr qp = (global_cu4_ptr)(uintptr_t)job.q + (size_t)qi * 4u;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
     for (int r = 0; r < R; ++r) { best[r] = kEmpty; second[r] = kEmpty; }
 
     // this wave's quarter [t0, t1) of the workgroup's split [s0, s1)
-    const uint32_t s0 = split * job.t_per_split;
-    const uint32_t s1 = min(s0 + job.t_per_split, job.nt);
+    const uint32_t s0 = min(split * job.t_per_split, job_nt);
+    const uint32_t s1 = min(s0 + job.t_per_split, job_nt);
     const uint32_t per_wave = (s1 - s0 + kWaves - 1) / kWaves;
     const uint32_t t0 = min(s0 + wave * per_wave, s1);
     const uint32_t t1 = min(t0 + per_wave, s1);
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t qi = qbase + 64u * r;
-            if (qi < job.nq && best[r] != kEmpty) {
+            if (qi < job_nq && best[r] != kEmpty) {
                 const uint32_t bkey = best[r] + s0;
                 const uint32_t skey = second[r] == kEmpty ? kEmpty : second[r] + s0;
                 const uint32_t old = atomicMin(top + 2u * qi, bkey);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint32_t qi = qbase + 64u * r;
-            if (qi < job.nq) {
+            if (qi < job.nq) {          // every PLANNED row gets an answer; rows past a device-side count hold no key -> -1
                 const uint32_t bkey = atomicExch(top + 2u * qi, kEmpty);
                 const uint32_t skey = atomicExch(top + 2u * qi + 1u, kEmpty);
                 emit_result(job, qi, bkey, skey);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64 * kWaves) void k2nn_sweep_kernel(const K2nnJobLi
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const uint32_t qi = qbase + 64u * r;
-        if (qi < job.nq) prow[qi] = u32x2{ best[r], second[r] };
+        if (qi < job.nq) prow[qi] = qi < job_nq ? u32x2{ best[r], second[r] } : u32x2{ kEmpty, kEmpty };
     }
 }
 
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     __shared__ uint32_t s_best[kMxQPerBlock], s_second[kMxQPerBlock];
     __shared__ uint32_t s_arrival;
     const K2nnJobDev& job = jobs.j[blockIdx.y];
+    const uint32_t job_nq = k2nn_job_nq(job), job_nt = k2nn_job_nt(job);     // == job.nq / job.nt unless the counts live on the device
     uint64_t st_entry = 0;
     if (STAMP) st_entry = __builtin_amdgcn_s_memrealtime();
     // XCD-aware order (speed only): workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD has its own
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
             const uint32_t idx = (uint32_t)i * 64u + lane;               // 16-byte chunk of the wave's QT x 32 rows
             const uint32_t r_local = idx >> 2, chunk = idx & 3u;
             uint32_t row = qblock * kMxQPerBlock + wave * (QT * 32u) + r_local;
-            if (row >= job.nq) row = job.nq - 1u;                        // clamp: duplicate work, never stored
+            if (row >= job_nq) row = job_nq ? job_nq - 1u : 0u;          // clamp: duplicate work, never stored (row 0 of the block always exists)
             const u32x4 v = qbase[(size_t)row * 4u + chunk];
             uint32_t* d = stage + r_local * kQRow + chunk * 4u;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -403,8 +405,8 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     for (int qt = 0; qt < QT; ++qt) { best[qt] = __uint_as_float(kMxInf); second[qt] = __uint_as_float(kMxInf); }
 
     // this workgroup's train rows [s0, s1): t_per_split is a multiple of 32, so only the train set's last tile can be partial
-    const uint32_t s0 = min(split * job.t_per_split, job.nt);
-    const uint32_t s1 = min(s0 + job.t_per_split, job.nt);
+    const uint32_t s0 = min(split * job.t_per_split, job_nt);
+    const uint32_t s1 = min(s0 + job.t_per_split, job_nt);
     const uint32_t ntiles = (s1 - s0 + 31u) >> 5;
     const int scale_a = 0x8B8B8B8B, scale_b = 0x7F7F7F7F;            // E8M0 block scales: 2^12 (trains), 1 (queries)
     // train tile = 32 rows x 64 B = 2 KB contiguous: thread tid owns its 8 bytes number tid = row tid >> 3, words
@@ -412,13 +414,14 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     const uint32_t my_row = tid >> 3, my_j = tid & 7u;
     const uint32_t dst = my_j * kStride + my_row;
     const global_cu2_ptr tbase = (global_cu2_ptr)(uintptr_t)job.t + (size_t)my_j;
-    const uint32_t last_row = job.nt - 1u;                           // in a register: read through `job` it is a scalar load
+    const uint32_t last_row = job_nt ? job_nt - 1u : 0u;             // in a register: read through `job` it is a scalar load
                                                                      // (+ wait) from the kernel arguments in every tile
     auto load_bits = [&](const uint32_t tile) -> u32x2 {
         const uint32_t row = min(s0 + tile * 32u + my_row, last_row);   // stays in bounds; such rows are penalised through C
         return tbase[(size_t)row * 8u];
     };
-    u32x2 r0 = load_bits(0u), r1 = load_bits(min(1u, ntiles - 1u));
+    u32x2 r0 = u32x2{ 0u, 0u }, r1 = u32x2{ 0u, 0u };
+    if (ntiles) { r0 = load_bits(0u); r1 = load_bits(min(1u, ntiles - 1u)); }   // (an empty split -- device-side count -- reads nothing)
     uint64_t st_clk = 0, st_real = 0;
     if (STAMP) { st_clk = __builtin_amdgcn_s_memtime(); st_real = __builtin_amdgcn_s_memrealtime(); }
     for (uint32_t t = 0; t < ntiles; ++t) {
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     const uint32_t bkey_l = s_best[tid], skey_l = s_second[tid];
     if (!job.atomic_merge) {
         const global_u2_ptr prow = (global_u2_ptr)(uintptr_t)partial + job.partial_off + (size_t)split * job.nq_pad;
-        if (qi < job.nq) prow[qi] = u32x2{ bkey_l, skey_l };
+        if (qi < job.nq) prow[qi] = qi < job_nq ? u32x2{ bkey_l, skey_l } : u32x2{ kEmpty, kEmpty };
         return;
     }
     // same fold / arrival / finalize protocol as the popcount kernel (see there for why no fence is needed): every
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     // counts the workgroup in; the last arrival of a query block turns the rows into results and re-arms them.
     unsigned int* top = reinterpret_cast<unsigned int*>(partial + job.partial_off);
     uint32_t seen = 0;
-    if (qi < job.nq && bkey_l != kEmpty) {
+    if (qi < job_nq && bkey_l != kEmpty) {
         const uint32_t old = atomicMin(top + 2u * qi, bkey_l);
         const uint32_t cand = bkey_l < old ? min(old, skey_l) : bkey_l;
         seen |= old;

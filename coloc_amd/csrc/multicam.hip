@@ -13,15 +13,21 @@
 //   CLC_MC_PEER_COPY one-shot fan-out: every rank writes its block straight into each peer's arena through IPC-mapped
 //                    pointers (hipMemcpyAsync device-to-device, one xGMI hop each), and the counts' all-gather that
 //                    follows on the same stream is the fence -- a rank contributes only after its copies have drained.
+// Ordering contract of the peer copies (round 3): the arena is DOUBLE-BUFFERED by step parity.  Step k's blocks land in
+// buffer k & 1 while a peer may still be sweeping step k - 1 out of buffer (k - 1) & 1; buffer k & 1 is written again by
+// step k + 2, whose copies a rank enqueues behind its own part of step k + 1's count collective -- and that collective
+// completes only when EVERY rank has joined it, i.e. has its step-k sweep (enqueued earlier on the same stream) behind
+// it.  So the skew between ranks is bounded to one step and no copy ever lands in a buffer a sweep still reads.  Every
+// rank must call the gather the same number of times (the parity is a local call count).
 // RCCL is resolved at run time (dlopen "librccl.so.1": the copy the process already has, e.g. PyTorch's, or the
-// system one), so libcoloc_hip.so has no link-time dependency on it and single-GPU hosts never load it.
+// system one) and its handful of types is declared here, so libcoloc_hip.so needs neither the RCCL headers to build
+// nor the library to load, and single-GPU hosts never touch it.
 //
 // Written against the public C ABI + the HIP runtime only.  The planner (clc_mc_plan) is pure host arithmetic and is
 // the C twin of coloc_amd/multicam.py shard_pairs (tests/test_multicam.py checks them against each other).
 #include "clc_internal.h"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstring>
@@ -32,6 +38,15 @@
 extern "C" int clc_ctx_device(const clc_ctx* ctx);
 
 namespace {
+
+// the part of the (stable) NCCL / RCCL C API this file uses, declared locally: nccl.h's ncclUniqueId is 128 opaque bytes, a
+// communicator is an opaque pointer, results and data types are plain enums (ncclSuccess == 0, ncclUint8 == 1)
+struct ncclUniqueId { char internal[CLC_MC_ID_BYTES]; };
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint8 = 1;
 
 struct Rccl {
     void* lib = nullptr;
@@ -67,9 +82,12 @@ struct clc_mc {
     clc_ctx* ctx = nullptr;
     int world = 1, rank = 0, cap = 0, device = 0;
     ncclComm_t comm = nullptr;
-    uint8_t* d_arena = nullptr;            // [world][cap][64]
-    int32_t* d_counts = nullptr;           // [world] + my count at [world]
-    int32_t* h_counts = nullptr;           // pinned, [world] + staging slot
+    uint8_t* d_arena = nullptr;            // [2][world][cap][64]: buffer (step & 1) receives step's blocks
+    int32_t* d_counts = nullptr;           // [2][world + 1]: the gathered counts of a buffer, this rank's own count at [world]
+    int32_t* h_counts = nullptr;           // pinned, [2][world + 1]: host mirror (+ staging slot at [world])
+    int fill = 0;                          // buffer the NEXT gather (and clc_mc_virtual_put) writes
+    int cur = 0;                           // buffer of the last completed gather: what the match entries sweep
+    bool counts_on_host = false;           // the last gather synchronised and left the counts in h_counts[cur]
     std::vector<uint8_t*> peer_arena;      // IPC-mapped arenas of the peers (own pointer at [rank]); empty until first used
     bool peers_tried = false;
     bool is_virtual = false;
@@ -169,7 +187,6 @@ int clc_mc_plan(const int* counts, int ncams, int world, int rank, int grain, cl
 int clc_mc_unique_id(uint8_t id[CLC_MC_ID_BYTES])
 {
     if (!id) return CLC_ERR_BAD_ARG;
-    static_assert(CLC_MC_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
     if (!rccl().ok) return CLC_ERR_STATE;
     ncclUniqueId u;
     if (rccl().GetUniqueId(&u) != ncclSuccess) return CLC_ERR_HIP;
@@ -193,9 +210,11 @@ int clc_mc_create(clc_ctx* ctx, const uint8_t id[CLC_MC_ID_BYTES], int world, in
         memcpy(u.internal, id, CLC_MC_ID_BYTES);
         if (rccl().CommInitRank(&mc->comm, world, u, rank) != ncclSuccess) return bail(CLC_ERR_HIP);
     }
-    if (hipMalloc((void**)&mc->d_arena, (size_t)world * (size_t)maxkp * CLC_DESC_BYTES) != hipSuccess) return bail(CLC_ERR_HIP);
-    if (hipMalloc((void**)&mc->d_counts, sizeof(int32_t) * (size_t)(world + 1)) != hipSuccess) return bail(CLC_ERR_HIP);
-    if (hipHostMalloc((void**)&mc->h_counts, sizeof(int32_t) * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess) return bail(CLC_ERR_HIP);
+    if (hipMalloc((void**)&mc->d_arena, 2 * (size_t)world * (size_t)maxkp * CLC_DESC_BYTES) != hipSuccess) return bail(CLC_ERR_HIP);
+    if (hipMalloc((void**)&mc->d_counts, 2 * sizeof(int32_t) * (size_t)(world + 1)) != hipSuccess) return bail(CLC_ERR_HIP);
+    if (hipMemset(mc->d_counts, 0, 2 * sizeof(int32_t) * (size_t)(world + 1)) != hipSuccess) return bail(CLC_ERR_HIP);
+    if (hipHostMalloc((void**)&mc->h_counts, 2 * sizeof(int32_t) * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess) return bail(CLC_ERR_HIP);
+    memset(mc->h_counts, 0, 2 * sizeof(int32_t) * (size_t)(world + 1));
     *out = mc;
     return CLC_OK;
 }
@@ -219,9 +238,53 @@ const char* clc_mc_last_error_string(const clc_mc* mc) { return mc ? mc->err.c_s
 int clc_mc_arena(const clc_mc* mc, void** d_arena, int* world, int* maxkp)
 {
     if (!mc) return CLC_ERR_BAD_ARG;
-    if (d_arena) *d_arena = mc->d_arena;
+    if (d_arena) *d_arena = mc->d_arena + (size_t)mc->cur * (size_t)mc->world * (size_t)mc->cap * CLC_DESC_BYTES;
     if (world) *world = mc->world;
     if (maxkp) *maxkp = mc->cap;
+    return CLC_OK;
+}
+
+// the exchange itself, enqueue only: this rank's block and count into buffer `fill` of every rank
+static int mc_exchange(clc_mc* mc, const void* d_my_desc, int my_count, const int32_t* d_my_count, int mode, hipStream_t st)
+{
+    const size_t block = (size_t)mc->cap * CLC_DESC_BYTES, buf = (size_t)mc->world * block;
+    const int b = mc->fill;
+    uint8_t* arena = mc->d_arena + (size_t)b * buf;
+    int32_t* d_cnt = mc->d_counts + (size_t)b * (size_t)(mc->world + 1);
+    int32_t* h_cnt = mc->h_counts + (size_t)b * (size_t)(mc->world + 1);
+    // rows to move: the valid ones when the host knows the count, the whole fixed-capacity block when only the device does
+    const size_t rows = d_my_count ? (size_t)mc->cap : (size_t)my_count;
+    if (d_my_count) MC_HIP(mc, hipMemcpyAsync(d_cnt + mc->world, d_my_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    else {
+        h_cnt[mc->world] = my_count;
+        MC_HIP(mc, hipMemcpyAsync(d_cnt + mc->world, h_cnt + mc->world, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    if (mc->world == 1 || mc->is_virtual) {
+        uint8_t* slot = arena + (size_t)mc->rank * block;
+        if (rows > 0 && d_my_desc != slot)
+            MC_HIP(mc, hipMemcpyAsync(slot, d_my_desc, rows * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
+        MC_HIP(mc, hipMemcpyAsync(d_cnt + mc->rank, d_cnt + mc->world, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    } else if (mode == CLC_MC_RCCL) {
+        // the block is gathered at its fixed capacity (rows >= my_count are padding): d_my_desc must hold maxkp rows
+        MC_NCCL(mc, rccl().AllGather(d_my_desc, arena, block, ncclUint8, mc->comm, st));
+        MC_NCCL(mc, rccl().AllGather(d_cnt + mc->world, d_cnt, sizeof(int32_t), ncclUint8, mc->comm, st));
+    } else {
+        const int rc = open_peers(mc, st);
+        if (rc != CLC_OK) return rc;
+        for (int k = 0; k < mc->world; ++k) {                    // start with the right-hand neighbour: every link busy at once
+            const int p = (mc->rank + k) % mc->world;
+            if (rows > 0)
+                MC_HIP(mc, hipMemcpyAsync(mc->peer_arena[(size_t)p] + (size_t)b * buf + (size_t)mc->rank * block, d_my_desc,
+                                          rows * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
+        }
+        // fence: a rank's contribution to this collective is enqueued behind its copies on the same stream (and behind its
+        // sweep of the previous step: see the ordering contract at the top of this file)
+        MC_NCCL(mc, rccl().AllGather(d_cnt + mc->world, d_cnt, sizeof(int32_t), ncclUint8, mc->comm, st));
+    }
+    // the host mirror of the counts travels behind the exchange; whoever needs it synchronises the stream first
+    MC_HIP(mc, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * (size_t)mc->world, hipMemcpyDeviceToHost, st));
+    mc->cur = b;
+    mc->fill = b ^ 1;
     return CLC_OK;
 }
 
@@ -231,33 +294,33 @@ int clc_mc_gather_dev(clc_mc* mc, const void* d_my_desc, int my_count, int mode,
         return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_gather: bad argument");
     MC_HIP(mc, hipSetDevice(mc->device));
     hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
-    const size_t block = (size_t)mc->cap * CLC_DESC_BYTES;
-    mc->h_counts[mc->world] = my_count;
-    MC_HIP(mc, hipMemcpyAsync(mc->d_counts + mc->world, mc->h_counts + mc->world, sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (mc->world == 1 || mc->is_virtual) {
-        uint8_t* slot = mc->d_arena + (size_t)mc->rank * block;
-        if (my_count > 0 && d_my_desc != slot)
-            MC_HIP(mc, hipMemcpyAsync(slot, d_my_desc, (size_t)my_count * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
-        MC_HIP(mc, hipMemcpyAsync(mc->d_counts + mc->rank, mc->d_counts + mc->world, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    } else if (mode == CLC_MC_RCCL) {
-        // the block is gathered at its fixed capacity (rows >= my_count are padding): d_my_desc must hold maxkp rows
-        MC_NCCL(mc, rccl().AllGather(d_my_desc, mc->d_arena, block, ncclUint8, mc->comm, st));
-        MC_NCCL(mc, rccl().AllGather(mc->d_counts + mc->world, mc->d_counts, sizeof(int32_t), ncclUint8, mc->comm, st));
-    } else {
-        const int rc = open_peers(mc, st);
-        if (rc != CLC_OK) return rc;
-        for (int k = 0; k < mc->world; ++k) {                    // start with the right-hand neighbour: every link busy at once
-            const int p = (mc->rank + k) % mc->world;
-            if (my_count > 0)
-                MC_HIP(mc, hipMemcpyAsync(mc->peer_arena[(size_t)p] + (size_t)mc->rank * block, d_my_desc, (size_t)my_count * CLC_DESC_BYTES,
-                                          hipMemcpyDeviceToDevice, st));
-        }
-        // fence: a rank's contribution to this collective is enqueued behind its copies on the same stream
-        MC_NCCL(mc, rccl().AllGather(mc->d_counts + mc->world, mc->d_counts, sizeof(int32_t), ncclUint8, mc->comm, st));
-    }
-    MC_HIP(mc, hipMemcpyAsync(mc->h_counts, mc->d_counts, sizeof(int32_t) * (size_t)mc->world, hipMemcpyDeviceToHost, st));
-    MC_HIP(mc, hipStreamSynchronize(st));                          // the shares below are planned from the counts
-    if (h_counts_out) for (int c = 0; c < mc->world; ++c) h_counts_out[c] = mc->h_counts[c];
+    const int rc = mc_exchange(mc, d_my_desc, my_count, nullptr, mode, st);
+    if (rc != CLC_OK) return rc;
+    MC_HIP(mc, hipStreamSynchronize(st));                          // clc_mc_match_dev plans its shares from the counts
+    mc->counts_on_host = true;
+    const int32_t* h_cnt = mc->h_counts + (size_t)mc->cur * (size_t)(mc->world + 1);
+    if (h_counts_out) for (int c = 0; c < mc->world; ++c) h_counts_out[c] = h_cnt[c];
+    return CLC_OK;
+}
+
+int clc_mc_gather_enqueue_dev(clc_mc* mc, const void* d_my_desc, int my_count, const int32_t* d_my_count, int mode, void* stream)
+{
+    if (!mc || !d_my_desc || (!d_my_count && (my_count < 0 || my_count > mc->cap)) || (mode != CLC_MC_RCCL && mode != CLC_MC_PEER_COPY))
+        return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_gather_enqueue: bad argument");
+    MC_HIP(mc, hipSetDevice(mc->device));
+    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
+    mc->counts_on_host = false;
+    return mc_exchange(mc, d_my_desc, my_count, d_my_count, mode, st);
+}
+
+int clc_mc_counts(clc_mc* mc, int* h_counts_out, void* stream)
+{
+    if (!mc || !h_counts_out) return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_counts: bad argument");
+    MC_HIP(mc, hipSetDevice(mc->device));
+    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
+    MC_HIP(mc, hipStreamSynchronize(st));
+    const int32_t* h_cnt = mc->h_counts + (size_t)mc->cur * (size_t)(mc->world + 1);
+    for (int c = 0; c < mc->world; ++c) h_counts_out[c] = h_cnt[c];
     return CLC_OK;
 }
 
@@ -267,22 +330,23 @@ int clc_mc_virtual_put(clc_mc* mc, int other_rank, const void* d_desc, int count
         return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_virtual_put: bad argument (only for handles created without an id)");
     MC_HIP(mc, hipSetDevice(mc->device));
     hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
+    // plays another rank's part of the NEXT exchange: its block and count go where that rank's copy / collective would put them
+    const size_t block = (size_t)mc->cap * CLC_DESC_BYTES;
     if (count > 0)
-        MC_HIP(mc, hipMemcpyAsync(mc->d_arena + (size_t)other_rank * (size_t)mc->cap * CLC_DESC_BYTES, d_desc, (size_t)count * CLC_DESC_BYTES,
-                                  hipMemcpyDeviceToDevice, st));
-    mc->h_counts[mc->world] = count;
-    MC_HIP(mc, hipMemcpyAsync(mc->d_counts + other_rank, mc->h_counts + mc->world, sizeof(int32_t), hipMemcpyHostToDevice, st));
+        MC_HIP(mc, hipMemcpyAsync(mc->d_arena + ((size_t)mc->fill * (size_t)mc->world + (size_t)other_rank) * block, d_desc,
+                                  (size_t)count * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
+    int32_t* h_stage = mc->h_counts + (size_t)mc->fill * (size_t)(mc->world + 1) + mc->world;
+    *h_stage = count;
+    MC_HIP(mc, hipMemcpyAsync(mc->d_counts + (size_t)mc->fill * (size_t)(mc->world + 1) + other_rank, h_stage, sizeof(int32_t),
+                              hipMemcpyHostToDevice, st));
     MC_HIP(mc, hipStreamSynchronize(st));
     return CLC_OK;
 }
 
-int clc_mc_match_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares, int share_capacity,
-                     int* n_shares, void* stream)
+// shares -> jobs over buffer `cur`; device_counts: the jobs read the gathered counts themselves (capacity-planned shares)
+static int mc_sweep(clc_mc* mc, const std::vector<int>& counts, bool device_counts, int threshold, int32_t* d_match, int match_capacity,
+                    clc_mc_share* h_shares, int share_capacity, int* n_shares, void* stream)
 {
-    if (!mc || !n_shares || match_capacity < 0 || (match_capacity > 0 && !d_match) || share_capacity < 0 || (share_capacity > 0 && !h_shares))
-        return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_match: bad argument");
-    std::vector<int> counts((size_t)mc->world);
-    for (int c = 0; c < mc->world; ++c) counts[(size_t)c] = mc->h_counts[c];
     const int grain = clc_k2nn_queries_per_block(mc->ctx);
     std::vector<clc_mc_share> shares((size_t)mc->world * (size_t)mc->world + 2);
     int n = 0;
@@ -290,6 +354,8 @@ int clc_mc_match_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capa
     if (rc != CLC_OK) return mc_fail(mc, rc, "mc_match: planning failed");
     if (n > share_capacity) return mc_fail(mc, CLC_ERR_CAPACITY, "mc_match: share array too small");
     std::vector<clc_match_job> jobs((size_t)n);
+    std::vector<const int32_t*> cq, ct;
+    const int32_t* d_cnt = mc->d_counts + (size_t)mc->cur * (size_t)(mc->world + 1);
     uint64_t rows = 0;
     for (int k = 0; k < n; ++k) {
         const clc_mc_share& s = shares[(size_t)k];
@@ -301,13 +367,42 @@ int clc_mc_match_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capa
         jobs[(size_t)k].threshold = (uint32_t)threshold;
         rows += s.nq;
         if (h_shares) h_shares[k] = s;
+        if (device_counts) { cq.push_back(d_cnt + s.first); ct.push_back(d_cnt + s.second); }
     }
     if (rows > (uint64_t)match_capacity) return mc_fail(mc, CLC_ERR_CAPACITY, "mc_match: result buffer too small");
     *n_shares = n;
     if (n == 0) return CLC_OK;
-    rc = clc_match_jobs_dev(mc->ctx, mc->d_arena, jobs.data(), n, d_match, stream);
+    const uint8_t* arena = mc->d_arena + (size_t)mc->cur * (size_t)mc->world * (size_t)mc->cap * CLC_DESC_BYTES;
+    if (device_counts) {
+        std::vector<uint32_t> row0((size_t)n);
+        for (int k = 0; k < n; ++k) row0[(size_t)k] = shares[(size_t)k].q_begin;
+        rc = clc_match_jobs_counted_dev(mc->ctx, arena, jobs.data(), n, cq.data(), ct.data(), row0.data(), d_match, stream);
+    } else rc = clc_match_jobs_dev(mc->ctx, arena, jobs.data(), n, d_match, stream);
     if (rc != CLC_OK) return mc_fail(mc, rc, clc_last_error_string(mc->ctx));
     return CLC_OK;
+}
+
+int clc_mc_match_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares, int share_capacity,
+                     int* n_shares, void* stream)
+{
+    if (!mc || !n_shares || match_capacity < 0 || (match_capacity > 0 && !d_match) || share_capacity < 0 || (share_capacity > 0 && !h_shares))
+        return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_match: bad argument");
+    if (!mc->counts_on_host) return mc_fail(mc, CLC_ERR_STATE, "mc_match: the last exchange was enqueue-only (use clc_mc_match_enqueue_dev, or clc_mc_gather_dev)");
+    std::vector<int> counts((size_t)mc->world);
+    const int32_t* h_cnt = mc->h_counts + (size_t)mc->cur * (size_t)(mc->world + 1);
+    for (int c = 0; c < mc->world; ++c) counts[(size_t)c] = h_cnt[c];
+    return mc_sweep(mc, counts, false, threshold, d_match, match_capacity, h_shares, share_capacity, n_shares, stream);
+}
+
+int clc_mc_match_enqueue_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares, int share_capacity,
+                             int* n_shares, void* stream)
+{
+    if (!mc || !n_shares || match_capacity < 0 || (match_capacity > 0 && !d_match) || share_capacity < 0 || (share_capacity > 0 && !h_shares))
+        return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_match_enqueue: bad argument");
+    // the shares are cut on the block CAPACITY (the same for every step of a handle); the sweep reads the gathered counts from
+    // device memory, answers -1 for planned query rows past a camera's count and sweeps only the train rows that exist
+    const std::vector<int> counts((size_t)mc->world, mc->cap);
+    return mc_sweep(mc, counts, true, threshold, d_match, match_capacity, h_shares, share_capacity, n_shares, stream);
 }
 
 } // extern "C"

@@ -199,6 +199,13 @@ int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, in
  * of it after the multi-GPU all-gather.  h_jobs is host memory. */
 int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs,
                        int njobs, int32_t* d_match, void* stream);
+/* The same with the row counts of the two sets of every job living in DEVICE memory (the sweep reads them; no host
+ * round trip between whatever produced the counts and this call): job j's nq / nt are the PLANNED sizes (grid and result
+ * layout), its query slice starts at row q_row0[j] of a set with *d_cnt_q[j] valid rows, its train set has
+ * min(nt, *d_cnt_t[j]) rows.  Planned query rows past the count are answered -1. */
+int clc_match_jobs_counted_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs, int njobs,
+                               const int32_t* const* d_cnt_q, const int32_t* const* d_cnt_t, const uint32_t* q_row0,
+                               int32_t* d_match, void* stream);
 
 /* Which formulation of the all-pairs sweep a context uses (same results bit for bit, same workspace):
  * CLC_K2NN_MATRIX (default): bits as +-1 FP4 values on the matrix pipe, exact distances in the fp32 accumulator;
@@ -334,15 +341,29 @@ int clc_mc_create(clc_ctx* ctx, const uint8_t id[CLC_MC_ID_BYTES], int world, in
 int clc_mc_virtual_put(clc_mc* mc, int other_rank, const void* d_desc, int count, void* stream);
 int clc_mc_destroy(clc_mc* mc);
 const char* clc_mc_last_error_string(const clc_mc* mc);
-/* The gathered arena [world][maxkp][64 B] (valid for the handle's lifetime). */
+/* The arena [world][maxkp][64 B] the LAST exchange filled (one of the handle's two buffers: it alternates per exchange). */
 int clc_mc_arena(const clc_mc* mc, void** d_arena, int* world, int* maxkp);
 /* Exchange: this rank's descriptors (d_my_desc: a device buffer of maxkp rows, my_count of them valid) go to every
  * rank's arena, the counts come back to the host (h_counts_out: world ints, nullable).  Synchronises the stream. */
 int clc_mc_gather_dev(clc_mc* mc, const void* d_my_desc, int my_count, int mode, int* h_counts_out, void* stream);
 /* Sweep this rank's shares of the gathered arena (enqueue only): d_match receives the runs back to back
- * (share.out_offset), h_shares the shares themselves. */
+ * (share.out_offset), h_shares the shares themselves.  Needs the counts on the host: follows clc_mc_gather_dev. */
 int clc_mc_match_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares,
                      int share_capacity, int* n_shares, void* stream);
+/* The same step WITHOUT a host synchronisation between the exchange and the sweep (a streaming host enqueues step after
+ * step): clc_mc_gather_enqueue_dev only enqueues the exchange -- my_count from the host, or d_my_count != NULL: read on the
+ * device (e.g. the detector's count, clc_detect_buffers), the whole capacity block then travels --, and
+ * clc_mc_match_enqueue_dev cuts the shares on the block CAPACITY (identical for every step of a handle) and lets the sweep
+ * read the gathered counts from device memory: planned query rows past a camera's count are answered -1, train rows past
+ * it are not swept.  Per pair and valid row the result is the serial loop's.  clc_mc_counts synchronises the stream and
+ * returns the counts of the last exchange.
+ * Ordering contract (both gather forms): the arena is double-buffered by step parity, every rank calls the gather the same
+ * number of times, and a rank enqueues step k + 1's exchange on the stream that holds its step-k sweep; then no peer copy
+ * lands in a buffer a sweep still reads (coloc_amd/csrc/multicam.hip, top). */
+int clc_mc_gather_enqueue_dev(clc_mc* mc, const void* d_my_desc, int my_count, const int32_t* d_my_count, int mode, void* stream);
+int clc_mc_match_enqueue_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares,
+                             int share_capacity, int* n_shares, void* stream);
+int clc_mc_counts(clc_mc* mc, int* h_counts_out, void* stream);
 
 /* ---- a-contrario model selection: what the reference actually runs ------------------------------------------------------
  * Localizer::localizeImage calls SfM_Localizer::Localize(P3P_KE_CVPR17, ..., {error_max = +inf, max_iteration = 256})

@@ -233,3 +233,58 @@ def test_two_contexts_two_streams_concurrently(oracle, k2nn_formulation):
         assert np.array_equal(dm[i].cpu().numpy(), oracle.k2nn(data[i][0], data[i][1], 40))
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(1000, 3000), (4880, 9000), (2048, 10000), (10000, 10000)])
+def test_clock_check_grid_padding(gpu_ctx, oracle, k2nn_formulation, nq, nt):
+    """clc_k2nn_clock_check launches the STAMPED build of the matrix sweep; its stamp buffer must cover the launch grid
+    padded to a multiple of 8 query blocks (nq = 1000 -> 4 blocks, 4880 -> 20: neither a multiple of 8).  The matches it
+    leaves behind are the ordinary sweep's, and the sweep that follows finds its workspace armed."""
+    import torch
+    if k2nn_formulation != "matrix":
+        pytest.skip("the stamped diagnostic build exists for the matrix formulation only")
+    Q, T = synth.planted_descriptors(nq, nt, seed=77 + nq)
+    dq, dt = torch.from_numpy(Q).cuda(), torch.from_numpy(T).cuda()
+    out = torch.full((nq,), -9, dtype=torch.int32, device="cuda")
+    guard = torch.full((1 << 16,), 0x5A, dtype=torch.uint8, device="cuda")      # a neighbour a stray stamp would likely hit
+    med, lo, hi, wgs = gpu_ctx.k2nn_clock_check(dq.data_ptr(), nq, dt.data_ptr(), nt, out.data_ptr())
+    torch.cuda.synchronize()
+    assert 0.5 < lo <= med <= hi < 3.0 and wgs > 0
+    want = oracle.k2nn(Q, T, 40)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert bool((guard == 0x5A).all())
+    assert np.array_equal(gpu_ctx.match_2nn(Q, T, 40), want)
+
+
+def test_counted_jobs_read_their_sizes_on_the_device(gpu_ctx, oracle):
+    """clc_match_jobs_counted_dev: planned sizes on the host, actual row counts in device memory (what the multi-camera step
+    uses to avoid a host synchronisation): valid rows as the plain sweep, planned rows past the count -1, an empty train set
+    answers -1 everywhere."""
+    import torch
+    from coloc_amd import abi
+    import ctypes as C
+    cap = 3000
+    A, B = synth.planted_descriptors(2600, 2900, seed=91)
+    arena = np.full((2, cap, 64), 0xC3, np.uint8)
+    arena[0, :len(A)] = A
+    arena[1, :len(B)] = B
+    d_arena = torch.from_numpy(arena).cuda()
+    for na, nb in [(2600, 2900), (1000, 2900), (2600, 37), (0, 2900), (2600, 0), (1, 1)]:
+        cnt = torch.tensor([na, nb], dtype=torch.int32, device="cuda")
+        grain = gpu_ctx.k2nn_queries_per_block
+        # two jobs: the first `split` planned query rows and the rest, as a rank boundary would cut them
+        split = (cap // 2) // grain * grain
+        jobs = (abi.MatchJob * 2)()
+        jobs[0].q_offset, jobs[0].nq, jobs[0].t_offset, jobs[0].nt, jobs[0].out_offset, jobs[0].threshold = 0, split, cap, cap, 0, 40
+        jobs[1].q_offset, jobs[1].nq, jobs[1].t_offset, jobs[1].nt, jobs[1].out_offset, jobs[1].threshold = split, cap - split, cap, cap, split, 40
+        cq = (C.c_void_p * 2)(cnt.data_ptr(), cnt.data_ptr())
+        ct = (C.c_void_p * 2)(cnt.data_ptr() + 4, cnt.data_ptr() + 4)
+        row0 = (C.c_uint32 * 2)(0, split)
+        out = torch.full((cap,), -9, dtype=torch.int32, device="cuda")
+        rc = gpu_ctx.lib.clc_match_jobs_counted_dev(gpu_ctx.h, d_arena.data_ptr(), jobs, 2, cq, ct, row0, out.data_ptr(), None)
+        assert rc == 0, gpu_ctx.lib.clc_last_error_string(gpu_ctx.h)
+        gpu_ctx.sync()
+        got = out.cpu().numpy()
+        want = oracle.k2nn(A[:na], B[:nb], 40) if na and nb else np.full(na, -1, np.int32)
+        assert np.array_equal(got[:na], want), (na, nb)
+        assert (got[na:] == -1).all(), (na, nb)

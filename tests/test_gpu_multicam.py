@@ -93,3 +93,97 @@ def test_c_entry_points_every_rank_of_a_virtual_world(oracle, world, counts):
                     got[q0:q0 + nq] = results[r][off:off + nq]
         assert np.array_equal(got, oracle.k2nn(descs[i], descs[j], 40))
     ctx.close()
+
+
+@pytest.mark.parametrize("world,counts_by_step", [
+    (2, [[3000, 2500], [2800, 3000], [100, 2900]]),
+    (4, [[2000, 1500, 2500, 1800], [2500, 2500, 0, 2100], [1999, 2001, 2003, 1]]),
+    (3, [[700, 0, 1300], [1300, 700, 64]]),
+])
+def test_enqueue_only_steps_with_different_descriptors_every_step(oracle, world, counts_by_step):
+    """The streaming form of the step (clc_mc_gather_enqueue_dev + clc_mc_match_enqueue_dev): no host synchronisation between
+    the exchange and the sweep, shares cut on the block capacity, the sweep reads the gathered counts on the device.  One
+    rehearsal handle per rank lives across the steps; every step brings DIFFERENT descriptors and counts, and the next step's
+    blocks are filed (on a second stream, as a peer's copy would arrive) while the sweep of the current step is still enqueued:
+    the arena is double-buffered by step parity, so every step's result must still be the serial loop's."""
+    import torch
+    from coloc_amd import Context, MultiCam
+    cap = max(max(c) for c in counts_by_step)
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    st_sweep, st_copy = torch.cuda.Stream(), torch.cuda.Stream()
+    steps = []
+    for s, counts in enumerate(counts_by_step):
+        descs = [synth.random_descriptors(n, seed=4000 + 17 * s + c) for c, n in enumerate(counts)]
+        for c in range(1, world):
+            k = min(len(descs[0]), len(descs[c])) // 2
+            descs[c][:k] = descs[0][:k]
+            if k:
+                descs[c][:k, (c + s) % 64] ^= 0x3C
+        dev = [torch.from_numpy(np.ascontiguousarray(np.concatenate([d, np.full((cap - len(d), 64), 0xA5, np.uint8)]))).cuda() for d in descs]
+        d_cnt = [torch.tensor([n], dtype=torch.int32, device="cuda") for n in counts]
+        steps.append((counts, descs, dev, d_cnt))
+    torch.cuda.synchronize()
+    for r in range(world):
+        mc = MultiCam(ctx, world=world, rank=r, maxkp=cap)
+        outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in steps]
+        shares_by_step = []
+
+        def put_others(step):
+            counts, _, dev, _ = steps[step]
+            for o in range(world):
+                if o != r:
+                    mc.virtual_put(o, dev[o].data_ptr(), counts[o], stream=st_copy.cuda_stream)
+
+        put_others(0)
+        for s, (counts, descs, dev, d_cnt) in enumerate(steps):
+            # own block: count from the host on even steps, read on the device (the detector's counter) on odd ones
+            if s % 2 == 0:
+                mc.gather_enqueue_dev(dev[r].data_ptr(), counts[r], mode=s % 2, stream=st_sweep.cuda_stream)
+            else:
+                mc.gather_enqueue_dev(dev[r].data_ptr(), 0, mode=s % 2, stream=st_sweep.cuda_stream, d_my_count=d_cnt[r].data_ptr())
+            shares_by_step.append(mc.match_enqueue_dev(40, outs[s].data_ptr(), cap * world, stream=st_sweep.cuda_stream))
+            if s + 1 < len(steps):
+                put_others(s + 1)          # lands in the OTHER buffer while this step's sweep may still be running
+        assert mc.counts(stream=st_sweep.cuda_stream) == steps[-1][0]
+        torch.cuda.synchronize()
+        want_shares = [(j.pair[0], j.pair[1], j.q_begin, j.nq, j.out_offset)
+                       for j in multicam.shard_pairs([cap] * world, world, r, grain=ctx.k2nn_queries_per_block)]
+        for s, (counts, descs, dev, d_cnt) in enumerate(steps):
+            assert shares_by_step[s] == want_shares          # the capacity plan: the same every step
+            res = outs[s].cpu().numpy()
+            for (a, b, q0, nq, off) in shares_by_step[s]:
+                want = oracle.k2nn(descs[a], descs[b], 40) if counts[a] and counts[b] else np.full(counts[a], -1, np.int32)
+                valid = max(0, min(nq, counts[a] - q0))
+                assert np.array_equal(res[off:off + valid], want[q0:q0 + valid]), (r, s, a, b)
+                assert (res[off + valid:off + nq] == -1).all()       # planned rows past the camera's count
+        mc.close()
+    ctx.close()
+
+
+def test_sync_steps_alternate_buffers(oracle):
+    """clc_mc_gather_dev / clc_mc_match_dev (counts on the host, exact shares) over three steps of different data: the arena
+    pointer alternates between the handle's two buffers and every step's result is the oracle's."""
+    import torch
+    from coloc_amd import Context, MultiCam
+    world, cap = 2, 1500
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    mc = MultiCam(ctx, world=world, rank=1, maxkp=cap)
+    seen = []
+    for s, counts in enumerate([[1500, 1200], [900, 1500], [1500, 1500]]):
+        descs = [synth.random_descriptors(n, seed=5000 + 3 * s + c) for c, n in enumerate(counts)]
+        k = min(counts) // 2
+        descs[1][:k] = descs[0][:k]
+        descs[1][:k, s] ^= 0x11
+        dev = [torch.from_numpy(np.ascontiguousarray(np.concatenate([d, np.zeros((cap - len(d), 64), np.uint8)]))).cuda() for d in descs]
+        mc.virtual_put(0, dev[0].data_ptr(), counts[0])
+        assert mc.gather_dev(dev[1].data_ptr(), counts[1], mode=1) == counts
+        seen.append(mc.arena())
+        out = torch.full((cap * world,), -9, dtype=torch.int32, device="cuda")
+        shares = mc.match_dev(40, out.data_ptr(), cap * world)
+        ctx.sync()
+        want = oracle.k2nn(descs[0], descs[1], 40)
+        for (a, b, q0, nq, off) in shares:
+            assert (a, b) == (0, 1) and np.array_equal(out.cpu().numpy()[off:off + nq], want[q0:q0 + nq])
+    assert seen[0] == seen[2] and seen[0] != seen[1]
+    mc.close()
+    ctx.close()
