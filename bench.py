@@ -98,7 +98,7 @@ def main():
                          "instead of the batched entry point")
     ap.add_argument("--exchange", default="torch", choices=["torch", "clc-rccl", "clc-peer"],
                     help="N > 1 only. torch = torch.distributed all_gather_into_tensor (default). clc-rccl / clc-peer = the C entry points "
-                         "clc_mc_gather_dev + clc_mc_match_dev (ncclAllGather, or IPC peer copies + a 4-byte fence collective); the "
+                         "clc_mc_gather_enqueue_dev + clc_mc_match_enqueue_dev (ncclAllGather, or IPC peer copies + a 4-byte fence collective); the "
                          "rendezvous id travels through torch.distributed.  Not exercised on hardware yet: no multi-GPU box in the build loop")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events)")
     args = ap.parse_args()
@@ -175,8 +175,10 @@ def main():
     def step():
         if mc is not None:
             ctx.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP], [mine.data_ptr()], sptr)
-            mc.gather_dev(mine.data_ptr(), NKP, mode=mc_mode, stream=sptr)
-            mc.match_dev(THR, d_match.data_ptr(), d_match.numel(), stream=sptr)
+            # enqueue only: no host synchronisation between the exchange and the sweep (capacity-planned shares, the sweep
+            # reads the gathered counts on the device; the arena is double-buffered by step parity)
+            mc.gather_enqueue_dev(mine.data_ptr(), NKP, mode=mc_mode, stream=sptr)
+            mc.match_enqueue_dev(THR, d_match.data_ptr(), d_match.numel(), stream=sptr)
             return
         if args.per_camera_launches:
             for k, c in enumerate(cams):
@@ -360,7 +362,7 @@ def main():
             "roofline": roof,
             "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
             "collective": ("none" if world == 1 else (("RCCL all_gather_into_tensor" if mc is None else
-                                                       "clc_mc_gather_dev: " + ("ncclAllGather" if mc_mode == 0 else "IPC peer copies + 4-byte fence all-gather"))
+                                                       "clc_mc_gather_enqueue_dev: " + ("ncclAllGather" if mc_mode == 0 else "IPC peer copies + 4-byte fence all-gather"))
                                                       if args.backend == "nccl" else "REHEARSAL: gloo all_gather staged through host memory")),
             "allgather_us_rank0": allgather_us,
         }
@@ -525,6 +527,68 @@ def main():
                                "p50_ms": float(np.median(te[5:])), "inliers": int(len(r["inliers"])), "iterations": int(r["iterations"]),
                                "fixed_threshold_p50_ms": float(np.median(tf[5:]))}
 
+        def sec_shares():
+            # What the driver's N = 2 / 4 / 8 runs will depend on, measured HERE on one GPU (informational, no collective, no
+            # efficiency claim): every rank's share of the all-pairs sweep of an N-camera world (10k descriptors per camera, the
+            # planner bench.py --gpus N uses), one camera's describe, and BASELINE config[2]'s launch group (4 cameras, 6 pairs).
+            if world != 1:
+                return
+            big = torch.empty((8, NKP, 64), dtype=torch.uint8, device=dev)
+            for c in range(8):
+                big[c].copy_(arena[c & 1])
+            out_buf = torch.empty((8 * NKP,), dtype=torch.int32, device=dev)
+
+            def timed(fn, reps=30):
+                for _ in range(5):
+                    fn()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / reps * 1e6
+
+            one_cam = timed(lambda: ctx.describe_batch_dev(img_ptrs[:1], W, H, W, kp_ptrs[:1], [NKP], [mine.data_ptr()], sptr))
+            shares = {"describe_one_camera_us": one_cam,
+                      "what": "back-to-back launches on one stream, host clock / 30; per-rank sweep = clc_match_jobs_dev over that rank's jobs"}
+            for n_w in (2, 4, 8):
+                cnts = [NKP] * n_w
+                per_rank = []
+                for r in range(n_w):
+                    jb = multicam.jobs_to_abi(multicam.shard_pairs(cnts, n_w, r, grain=ctx.k2nn_queries_per_block), cnts, NKP, THR)
+                    per_rank.append(timed(lambda: ctx.match_jobs_dev(big.data_ptr(), jb, out_buf.data_ptr(), sptr)))
+                pairs_n = len(multicam.exhaustive_pairs(n_w))
+                shares["N%d" % n_w] = {"pairs": pairs_n, "pair_shares_per_rank": pairs_n / n_w,
+                                       "rank_sweep_us": [round(x, 1) for x in per_rank], "rank_sweep_us_max": max(per_rank),
+                                       "step_us_without_exchange": one_cam + max(per_rank),
+                                       "Mmatches_per_s_without_exchange": pairs_n * NKP * NKP / (one_cam + max(per_rank))}
+            out["stages"]["shares"] = shares
+            # config[2]: 4 cameras on ONE GPU, all 6 pairs in one launch group (descriptors of 4 x 10k keypoints at 1280 x 720)
+            W2, H2 = 1280, 720
+            ctx2 = Context(device=dev_index, width=W2, height=H2, maxkp=NKP)
+            try:
+                imgs2 = [torch.from_numpy(np.ascontiguousarray(synth.rect_image(W2, H2, seed=1000, noise_sigma=2.0 + c))).to(dev) for c in range(4)]
+                kp2 = [torch.from_numpy(synth.random_keypoints(NKP, W2, H2, seed=2200 + c).view(np.uint8).reshape(-1, 20).copy()).to(dev)
+                       for c in range(4)]
+                ar2 = torch.zeros((4, NKP, 64), dtype=torch.uint8, device=dev)
+                cnts = [NKP] * 4
+                jb = multicam.jobs_to_abi(multicam.shard_pairs(cnts, 1, 0, grain=ctx2.k2nn_queries_per_block), cnts, NKP, THR)
+                ip, kp_ = [t.data_ptr() for t in imgs2], [t.data_ptr() for t in kp2]
+                dp = [ar2[c].data_ptr() for c in range(4)]
+                t_desc = timed(lambda: ctx2.describe_batch_dev(ip, W2, H2, W2, kp_, cnts, dp, sptr))
+                t_match = timed(lambda: ctx2.match_jobs_dev(ar2.data_ptr(), jb, out_buf.data_ptr(), sptr))
+
+                def both():
+                    ctx2.describe_batch_dev(ip, W2, H2, W2, kp_, cnts, dp, sptr)
+                    ctx2.match_jobs_dev(ar2.data_ptr(), jb, out_buf.data_ptr(), sptr)
+                t_step = timed(both)
+                out["stages"]["config2"] = {"what": "BASELINE config[2] on one GPU: 4 cameras 1280x720 x 10k kp, one pyramid + one CLATCH launch, "
+                                                    "all 6 pairs in one sweep launch (pose: pose_solve)",
+                                            "describe_4_cameras_us": t_desc, "match_6_pairs_us": t_match, "step_us": t_step,
+                                            "Mmatches_per_s": 6 * NKP * NKP / t_step, "Mdesc_per_s": 4 * NKP / t_step}
+            finally:
+                ctx2.close()
+
         def sec_host_path():
             if world == 1:
                 # accepted matches, and the end-to-end rates of the host-buffer entry points (uploads, downloads and
@@ -556,18 +620,25 @@ def main():
                     out["gpu_over_cpu_best_effort_simd"] = out["value"] / out["cpu_baseline"]["best_effort_simd"]["value"]
 
         guarded("clatch_roofline", sec_clatch)
-        guarded("host_path", sec_host_path)
-        guarded("k2nn_ab", sec_k2nn_ab)
-        guarded("two_streams", sec_two_streams)
-        guarded("front_end", sec_front_end)
-        guarded("pose_solve", sec_pose)
-        guarded("two_view", sec_two_view)
-        guarded("cpu_baseline", sec_cpu_baseline)
+        if world == 1:
+            # the side sections belong to the one-GPU line; at N > 1 the other ranks would sit in the teardown barrier below while
+            # rank 0 alone ran them for tens of seconds
+            guarded("host_path", sec_host_path)
+            guarded("k2nn_ab", sec_k2nn_ab)
+            guarded("two_streams", sec_two_streams)
+            guarded("shares", sec_shares)
+            guarded("front_end", sec_front_end)
+            guarded("pose_solve", sec_pose)
+            guarded("two_view", sec_two_view)
+            guarded("cpu_baseline", sec_cpu_baseline)
         if errors:
             out["section_errors"] = errors
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if mc is not None:
+        mc.close()
     ctx.close()
     if world > 1:
+        dist.barrier()                  # nobody tears the group down while another rank still uses it
         dist.destroy_process_group()
     if errors:
         sys.exit(3)

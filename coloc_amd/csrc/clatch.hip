@@ -10,8 +10,9 @@
 //   * (s, c) = clc_sincosf(angle): the correctly rounded fp32 sine / cosine (clc_sincos.h).
 //
 // The ARCHITECTURE is not the reference's (512-thread block per keypoint, 32-lane butterflies):
-//   * one WAVE64 per keypoint and one wave per workgroup: no barrier anywhere, ~14 KB of LDS per
-//     wave, so 11 keypoints are in flight per CU and the hardware dispatcher balances the load.
+//   * one WAVE64 per keypoint and one wave per workgroup: no barrier anywhere, 12.7 KB of LDS per
+//     wave, so 12 keypoints are in flight per CU and the hardware dispatcher balances the load
+//     (and staggers the waves' phases: a persistent grid runs them in lockstep and measured 14 % slower).
 //   * only window rows/cols 5..60 are ever read by the learned patches, so only those 56x56 samples
 //     are gathered (49 steps of an 8x8 lane tile instead of 64: one gather instruction touches a
 //     ~11x11 pixel footprint of the L2-resident level, about a dozen cache lines).
@@ -104,107 +105,123 @@ __device__ __forceinline__ int clamp_i32(int v, int hi)   // min(max(v, 0), hi) 
 
 __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
 {
+    // One keypoint per wave, no loop (the grid is the keypoint count).  Round 3 (tools/clatch_lab.hip, in-kernel stamps): a wave
+    // used to spend 4.7 k of its 21.5 k cycles before its first gather -- it waited for its eight slot-table loads, THEN fetched
+    // the keypoint with a vector load, THEN the level -- so: the table loads are issued first and consumed after the fill (they
+    // are only needed by the tests), the keypoint comes through the scalar unit, and the copy phase is straight-line code with
+    // immediate offsets.  Same bits; 147 -> 89 VGPRs; 69.2 -> 66.8 us per 2 x 10k launch on the same device.
     const uint32_t cam = blockIdx.y;
     const int n_arg = args.cam.n[cam];
     // keypoint count: a launch argument, or (after the GPU detector) read from device memory
     const int n = args.n_dev ? min((int)*args.n_dev, n_arg) : n_arg;
-    if ((int)blockIdx.x >= n) return;
-    const clc_keypoint* __restrict__ kps = args.cam.kps[cam];
-    uint64_t* __restrict__ desc = args.cam.desc[cam];
-    const uint8_t* __restrict__ arena = arena_base + (size_t)cam * args.slot_stride;
+    const int kp = (int)blockIdx.x;
+    if (kp >= n) return;
     __shared__ __attribute__((aligned(16))) uint8_t roi[kWaveLds];
     const uint32_t lane = threadIdx.x;
 
-    // this lane's 8 slots (round j, lane) and, for the output, where bit 64*j + lane was computed
-    uint32_t pa[8], pb[8], pc[8], src[8];
+    // this lane's 8 slot records {a, b, c, src} (round j, lane): in flight during the whole fill
+    uint2 rec[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint2 e = *reinterpret_cast<const uint2*>(k_slots.rec[j * 64 + lane]);
-        pa[j] = e.x & 0xFFFFu; pb[j] = e.x >> 16; pc[j] = e.y & 0xFFFFu;
-        src[j] = e.y >> 16;
-    }
+    for (int j = 0; j < 8; ++j) rec[j] = *reinterpret_cast<const uint2*>(k_slots.rec[j * 64 + lane]);
+
+    // the keypoint is wave-uniform: five dwords through the scalar unit {x, y, score | pad, angle, scale | pad}
+    const uint32_t* __restrict__ kw = reinterpret_cast<const uint32_t*>(args.cam.kps[cam]) + (size_t)kp * 5u;
+    const int px = (int)__builtin_amdgcn_readfirstlane(kw[0]);
+    const int py = (int)__builtin_amdgcn_readfirstlane(kw[1]);
+    const float angle = __uint_as_float(__builtin_amdgcn_readfirstlane(kw[3]));
+    const int scale = (int)(__builtin_amdgcn_readfirstlane(kw[4]) & 0xFFu);
+    static_assert(sizeof(clc_keypoint) == 20 && offsetof(clc_keypoint, angle) == 12 && offsetof(clc_keypoint, scale) == 16, "keypoint wire format");
+    uint64_t* __restrict__ desc = args.cam.desc[cam];
+    const uint8_t* __restrict__ arena = arena_base + (size_t)cam * args.slot_stride;
+    const int lv = min(scale, args.pd.levels - 1);
+    const LevelDesc L = args.pd.lv[lv];
+    const uint8_t* __restrict__ img = arena + L.offset;
+    // (sin, cos) in fp64 per wave costs a few % of this kernel in isolation; preparing it in another launch and loading it here
+    // measured no better in round 2: the load sits at the head of the same dependency chain.
+    float s, c;
+    clc_sincosf(angle, &s, &c);
+    const float fpx = (float)px, fpy = (float)py;
+    const int wmax = (int)L.w - 1, hmax = (int)L.h - 1;
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
 
-    for (int kp = (int)blockIdx.x; kp < n; kp += (int)gridDim.x) {
-        const clc_keypoint pt = kps[kp];                      // wave-uniform
-        const int lv = min((int)pt.scale, args.pd.levels - 1);
-        const LevelDesc L = args.pd.lv[lv];
-        const uint8_t* __restrict__ img = arena + L.offset;
-        // (sin, cos) in fp64 per wave costs ~9 % of this kernel in isolation, but preparing it per LANE in
-        // another launch and loading it here measured 3 % SLOWER: the load sits at the head of the
-        // dependency chain, the arithmetic overlaps with the other waves.
-        float s, c;
-        clc_sincosf(pt.angle, &s, &c);
-        const float fpx = (float)pt.x, fpy = (float)pt.y;
-        const int wmax = (int)L.w - 1, hmax = (int)L.h - 1;
-
-        // ---- window fill: tile (by, bx) covers rows 5+8*by.., cols 5+8*bx.. with an 8x8 lane tile
-        float xc[kTiles], xs[kTiles], ys[kTiles], yc[kTiles];
+    // ---- window fill: tile (by, bx) covers rows 5+8*by.., cols 5+8*bx.. with an 8x8 lane tile
+    float xc[kTiles], xs[kTiles], ys[kTiles], yc[kTiles];
 #pragma unroll
-        for (int b = 0; b < kTiles; ++b) {
-            const float xo = (float)(kTile0 + b * 8 + dx - 32);
-            const float yo = (float)(kTile0 + b * 8 + dy - 32);
-            xc[b] = xo * c; xs[b] = xo * s;
-            ys[b] = yo * s; yc[b] = yo * c;
-        }
-        // (A clamp-free variant for keypoints >= 42 px inside the level was measured 17 % SLOWER -- the
-        // second copy of the unrolled fill costs more in instruction fetch than the two v_med3 save.)
-#pragma unroll
-        for (int by = 0; by < kTiles; ++by) {
-#pragma unroll
-            for (int bx = 0; bx < kTiles; ++bx) {
-                const float fx = (fpx + (xc[bx] - ys[by])) + 0.5f;   // CLATCH.cu:166
-                const float fy = (fpy + (xs[bx] + yc[by])) + 0.5f;
-                const int sx = clamp_i32((int)fx, wmax);
-                const int sy = clamp_i32((int)fy, hmax);
-                const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
-                roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = img[off];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- shifted copies 1..3: copy_k[i] = win[i + k]
-#pragma unroll 2
-        for (int i = (int)lane; i < kWinDwords; i += 64) {
-            const u32x2_a4 d = *reinterpret_cast<const u32x2_a4*>(roi + 4 * i);
-            *reinterpret_cast<uint32_t*>(roi + kCopyBase[1] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 1);
-            *reinterpret_cast<uint32_t*>(roi + kCopyBase[2] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 2);
-            *reinterpret_cast<uint32_t*>(roi + kCopyBase[3] + 4 * i) = __builtin_amdgcn_alignbyte(d.y, d.x, 3);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // ---- 512 tests, 8 per lane
-        uint32_t bits8 = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            uint32_t aa = 0, cc = 0, ab = 0, cb = 0;
-#pragma unroll
-            for (int row = 0; row < 8; ++row) {
-                const u32x2_a4 A = lds_read8(roi + pa[j] + row * kStride);
-                const u32x2_a4 B = lds_read8(roi + pb[j] + row * kStride);
-                const u32x2_a4 C = lds_read8(roi + pc[j] + row * kStride);
-                aa = udot4(A.x, A.x, aa); aa = udot4(A.y, A.y, aa);
-                cc = udot4(C.x, C.x, cc); cc = udot4(C.y, C.y, cc);
-                ab = udot4(A.x, B.x, ab); ab = udot4(A.y, B.y, ab);
-                cb = udot4(C.x, B.x, cb); cb = udot4(C.y, B.y, cb);
-            }
-            const int32_t S = ((int32_t)aa - (int32_t)cc) - 2 * ((int32_t)ab - (int32_t)cb);
-            bits8 |= (S < 0 ? 1u : 0u) << j;
-        }
-        // ---- back to descriptor order: output round j, lane l <- bit of triplet 64*j + l
-        uint64_t mine = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src[j] & 0xFFu), (int)bits8);
-            const uint64_t bits = __ballot((got >> (src[j] >> 8)) & 1u);
-            if (lane == (uint32_t)j) mine = bits;
-        }
-        if (lane < 8u) desc[(size_t)kp * 8u + lane] = mine;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    for (int b = 0; b < kTiles; ++b) {
+        const float xo = (float)(kTile0 + b * 8 + dx - 32);
+        const float yo = (float)(kTile0 + b * 8 + dy - 32);
+        xc[b] = xo * c; xs[b] = xo * s;
+        ys[b] = yo * s; yc[b] = yo * c;
     }
+    // (A clamp-free variant for keypoints >= 42 px inside the level was measured 17 % SLOWER in round 1 -- the second copy of the
+    // unrolled fill costs more in instruction fetch than the two v_med3 save; round 3's stamps put the clamps at 0.5 k of the
+    // fill's 7 k cycles.)
+#pragma unroll
+    for (int by = 0; by < kTiles; ++by) {
+#pragma unroll
+        for (int bx = 0; bx < kTiles; ++bx) {
+            const float fx = (fpx + (xc[bx] - ys[by])) + 0.5f;   // CLATCH.cu:166
+            const float fy = (fpy + (xs[bx] + yc[by])) + 0.5f;
+            const int sx = clamp_i32((int)fx, wmax);
+            const int sy = clamp_i32((int)fy, hmax);
+            const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
+            roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = img[off];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- shifted copies 1..3: copy_k[i] = win[i + k]; all thirteen reads first, then the stores
+    {
+        constexpr int kIters = (kWinDwords + 63) / 64;
+        u32x2_a4 d[kIters];
+#pragma unroll
+        for (int k = 0; k < kIters; ++k) {
+            const int i = (int)lane + 64 * k;
+            if (k < kIters - 1 || i < kWinDwords) d[k] = *reinterpret_cast<const u32x2_a4*>(roi + 4 * i);
+        }
+#pragma unroll
+        for (int k = 0; k < kIters; ++k) {
+            const int i = (int)lane + 64 * k;
+            if (k < kIters - 1 || i < kWinDwords) {
+                *reinterpret_cast<uint32_t*>(roi + kCopyBase[1] + 4 * i) = __builtin_amdgcn_alignbyte(d[k].y, d[k].x, 1);
+                *reinterpret_cast<uint32_t*>(roi + kCopyBase[2] + 4 * i) = __builtin_amdgcn_alignbyte(d[k].y, d[k].x, 2);
+                *reinterpret_cast<uint32_t*>(roi + kCopyBase[3] + 4 * i) = __builtin_amdgcn_alignbyte(d[k].y, d[k].x, 3);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 512 tests, 8 per lane
+    uint32_t bits8 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t pa = rec[j].x & 0xFFFFu, pb = rec[j].x >> 16, pc = rec[j].y & 0xFFFFu;
+        uint32_t aa = 0, cc = 0, ab = 0, cb = 0;
+#pragma unroll
+        for (int row = 0; row < 8; ++row) {
+            const u32x2_a4 A = lds_read8(roi + pa + row * kStride);
+            const u32x2_a4 B = lds_read8(roi + pb + row * kStride);
+            const u32x2_a4 C = lds_read8(roi + pc + row * kStride);
+            aa = udot4(A.x, A.x, aa); aa = udot4(A.y, A.y, aa);
+            cc = udot4(C.x, C.x, cc); cc = udot4(C.y, C.y, cc);
+            ab = udot4(A.x, B.x, ab); ab = udot4(A.y, B.y, ab);
+            cb = udot4(C.x, B.x, cb); cb = udot4(C.y, B.y, cb);
+        }
+        const int32_t S = ((int32_t)aa - (int32_t)cc) - 2 * ((int32_t)ab - (int32_t)cb);
+        bits8 |= (S < 0 ? 1u : 0u) << j;
+    }
+    // ---- back to descriptor order: output round j, lane l <- bit of triplet 64*j + l
+    uint64_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t src = rec[j].y >> 16;
+        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src & 0xFFu), (int)bits8);
+        const uint64_t bits = __ballot((got >> (src >> 8)) & 1u);
+        if (lane == (uint32_t)j) mine = bits;
+    }
+    if (lane < 8u) desc[(size_t)kp * 8u + lane] = mine;
 }
 
 static hipError_t launch_clatch_impl(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
@@ -224,7 +241,7 @@ static hipError_t launch_clatch_impl(const PyramidDesc& pd, const uint8_t* arena
         if (a.cam.n[b] > max_n) max_n = a.cam.n[b];
     }
     if (max_n <= 0) return hipSuccess;
-    const int blocks = max_n < 65536 ? max_n : 65536;   // one wave per keypoint; grid-stride beyond 64k
+    const int blocks = max_n;                           // one wave per keypoint (gridDim.x reaches 2^31 - 1)
     prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
     hipLaunchKernelGGL(clatch_kernel, dim3(blocks, (uint32_t)n_img), dim3(64), 0, stream, a, arena);
     prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);

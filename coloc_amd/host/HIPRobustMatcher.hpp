@@ -105,8 +105,10 @@ inline void motion_from_essential(const openMVG::Mat3& E, std::vector<openMVG::g
     u[2] = cross(u[0], u[1]);                            // det(U) = +1
     const double un = std::sqrt(u[2][0] * u[2][0] + u[2][1] * u[2][1] + u[2][2] * u[2][2]);
     for (int i = 0; i < 3; ++i) u[2][i] /= (un > 0 ? un : 1.0);
+    // every entry of every matrix is assigned: behind the name Mat3 stands Eigen::Matrix3d in the reference tree, whose default
+    // constructor leaves the coefficients uninitialised
     openMVG::Mat3 U, Vt, W;
-    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { U(i, k) = u[k][i]; Vt(k, i) = v[k][i]; }
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { U(i, k) = u[k][i]; Vt(k, i) = v[k][i]; W(i, k) = 0.0; }
     W(0, 1) = -1.0; W(1, 0) = 1.0; W(2, 2) = 1.0;
     const openMVG::Mat3 R[2] = { mul(mul(U, W), Vt), mul(mul(U, transpose(W)), Vt) };
     const openMVG::Vec3 t[2] = { u[2], openMVG::Vec3(-u[2][0], -u[2][1], -u[2][2]) };
@@ -214,13 +216,11 @@ public:
         if (!intrinsics1 || !intrinsics2 || !ctx_) return EXIT_FAILURE;
         const int n = static_cast<int>(x1.cols());
         std::vector<double> p1(2 * static_cast<size_t>(n)), p2(2 * static_cast<size_t>(n));
-        openMVG::Mat3X norm2Dpt_1(3, n), norm2Dpt_2(3, n);               // (*intrinsics)(x): bearing vectors
+        // bearing vectors exactly as the reference asks for them (RobustMatcher.hpp:159): IntrinsicBase::operator()(Mat2X) -> Mat3X
+        const openMVG::Mat3X norm2Dpt_1 = (*intrinsics1)(x1), norm2Dpt_2 = (*intrinsics2)(x2);
         for (int i = 0; i < n; ++i) {
             p1[2 * i] = x1(0, i); p1[2 * i + 1] = x1(1, i);
             p2[2 * i] = x2(0, i); p2[2 * i + 1] = x2(1, i);
-            const openMVG::Vec3 b1 = intrinsics1->bearing(openMVG::Vec2(x1(0, i), x1(1, i)));
-            const openMVG::Vec3 b2 = intrinsics2->bearing(openMVG::Vec2(x2(0, i), x2(1, i)));
-            for (int r = 0; r < 3; ++r) { norm2Dpt_1(r, i) = b1[r]; norm2Dpt_2(r, i) = b2[r]; }
         }
         double K1[9], K2[9], E[9], F[9], emax = 0.0, nfa = 0.0;
         const openMVG::Mat3 k1 = intrinsics1->K(), k2 = intrinsics2->K();

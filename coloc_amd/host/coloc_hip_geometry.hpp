@@ -7,7 +7,7 @@
 //   column-major like Eigen: resize(rows, cols), operator()(r, c), rows(), cols()),
 //   openMVG::geometry::Pose3 (rotation(), center(), translation(); Pose3(R, C)),
 //   openMVG::cameras::Pinhole_Intrinsic_Radial_K3 (ctor (w, h, focal, ppx, ppy, k1, k2, k3), have_disto(),
-//   get_ud_pixel() with OpenMVG's bisection on r^2 (1 + k1 r^2 + k2 r^4 + k3 r^6)^2, operator()(pixel) -> bearing, K()),
+//   get_ud_pixel() with OpenMVG's bisection on r^2 (1 + k1 r^2 + k2 r^4 + k3 r^6)^2, operator()(2 x N pixels) -> 3 x N bearings, K()),
 //   openMVG::sfm::Image_Localizer_Match_Data (pt3D, pt2D, vec_inliers, error_max, max_iteration),
 //   openMVG::sfm::Landmark{X} / Landmarks and the slice of SfM_Data ("Scene") Localizer::setupTracks reads,
 //   coloc::Cov6 (6 x 6 pose covariance, [angle-axis | translation] order as PoseRefiner::refinePose fills it,
@@ -100,12 +100,17 @@ public:
         const double radius = (r2 == 0.0) ? 1.0 : std::sqrt(bisection_radius_solve(r2) / r2);
         return cam2ima(Vec2(radius * c[0], radius * c[1]));
     }
-    // bearing vector of an (undistorted) pixel: (x, y, 1) on the camera plane, normalised
-    Vec3 bearing(const Vec2& p) const
+    // bearing vectors of (undistorted) pixels, 2 x N -> 3 x N: (x, y, 1) on the camera plane, normalised -- the member the
+    // reference calls, IntrinsicBase::operator()(const Mat2X&) (RobustMatcher.hpp:159)
+    Mat operator()(const Mat& p) const
     {
-        const Vec2 c = ima2cam(p);
-        const double n = std::sqrt(c[0] * c[0] + c[1] * c[1] + 1.0);
-        return Vec3(c[0] / n, c[1] / n, 1.0 / n);
+        Mat b(3, p.cols());
+        for (size_t i = 0; i < p.cols(); ++i) {
+            const Vec2 c = ima2cam(Vec2(p(0, i), p(1, i)));
+            const double n = std::sqrt(c[0] * c[0] + c[1] * c[1] + 1.0);
+            b(0, i) = c[0] / n; b(1, i) = c[1] / n; b(2, i) = 1.0 / n;
+        }
+        return b;
     }
     int w() const { return w_; }
     int h() const { return h_; }
