@@ -213,15 +213,23 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
         bits8 |= (S < 0 ? 1u : 0u) << j;
     }
     // ---- back to descriptor order: output round j, lane l <- bit of triplet 64*j + l
-    uint64_t mine = 0;
+    // all eight gathers in flight at once; the sixteen dwords of the descriptor are then dealt to lanes 0..15 with v_writelane
+    // (a ballot lives in a scalar register pair) and leave as ONE 64-byte store -- the select chain this replaces (a v_cmp and two
+    // v_cndmask per word) and its pairwise waits were a third of this stage
+    uint32_t got[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) got[j] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rec[j].y >> 16) & 0xFFu), (int)bits8);
+    uint32_t word = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint32_t src = rec[j].y >> 16;
-        const uint32_t got = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src & 0xFFu), (int)bits8);
-        const uint64_t bits = __ballot((got >> (src >> 8)) & 1u);
-        if (lane == (uint32_t)j) mine = bits;
+        const uint64_t bits = __ballot((got[j] >> (rec[j].y >> 24)) & 1u);
+        // scalar data into lanes 2 j and 2 j + 1.  gfx940-family hazard: a VALU instruction that reads an SGPR the VALU has just
+        // written (the v_cmp behind __ballot) needs two wait states; the compiler pads that for instructions it schedules, not
+        // inside an asm statement (without the s_nop lane 2 j received the PREVIOUS word's bits)
+        asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
+            : "+v"(word) : "s"((uint32_t)bits), "s"((uint32_t)(bits >> 32)), "n"(2 * j), "n"(2 * j + 1));
     }
-    if (lane < 8u) desc[(size_t)kp * 8u + lane] = mine;
+    if (lane < 16u) reinterpret_cast<uint32_t*>(desc)[(size_t)kp * 16u + lane] = word;
 }
 
 static hipError_t launch_clatch_impl(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,

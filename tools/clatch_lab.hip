@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void clatch_lab_kernel(const ClatchArgs args, c
 
 // ---- v3: one keypoint per wave, no loop; scalar keypoint load; slot-table loads issued first and consumed after the fill;
 //      copies unrolled with immediate offsets.  Bit-exact.
-enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_PRIO = 4u, V3_LATEKP = 8u };
+enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_NOGATHER = 4u, V3_NOTEST = 8u, V3_NOSINCOS = 16u, V3_NOCOPY = 32u, V3_NOOUT = 64u, V3_NOCOORD = 128u };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <unsigned V>
 __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
     const LevelDesc L = args.pd.lv[lv];
     const uint8_t* __restrict__ img = arena + L.offset;
     float s, c;
-    clc_sincosf(angle, &s, &c);
+    if (V & V3_NOSINCOS) { s = angle * 0.25f; c = 1.0f - s * s; }
+    else clc_sincosf(angle, &s, &c);
     const float fpx = (float)px, fpy = (float)py;
     const int wmax = (int)L.w - 1, hmax = (int)L.h - 1;
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
@@ -251,14 +252,14 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
             const float fy = (fpy + (xs[bx] + yc[by])) + 0.5f;
             int sx = (int)fx, sy = (int)fy;
             if (!(V & V3_NOCLAMP)) { sx = clamp_i32(sx, wmax); sy = clamp_i32(sy, hmax); }
-            const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
-            roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = img[off];
+            const uint32_t off = (V & V3_NOCOORD) ? (uint32_t)(by * 8 + dy) * L.pitch + (uint32_t)(bx * 8 + dx) + lane : __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
+            roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = (V & V3_NOGATHER) ? (uint8_t)off : img[off];
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (V & V3_STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st[3] = __builtin_amdgcn_s_memtime(); }
-    {
+    if (!(V & V3_NOCOPY)) {
         constexpr int kIters = (kWinDwords + 63) / 64;   // 13
         u32x2_a4 d[kIters];
 #pragma unroll
@@ -281,6 +282,8 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
     if (V & V3_STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st[4] = __builtin_amdgcn_s_memtime(); }
 
     uint32_t bits8 = 0;
+    if (V & V3_NOTEST) bits8 = *reinterpret_cast<const uint32_t*>(roi + 4 * lane) & 0xFFu;
+    else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t pa = rec[j].x & 0xFFFFu, pb = rec[j].x >> 16, pc = rec[j].y & 0xFFFFu;
@@ -300,6 +303,8 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
     }
     if (V & V3_STAMP) { asm volatile("" :: "v"(bits8)); st[5] = __builtin_amdgcn_s_memtime(); }
     uint64_t mine = 0;
+    if (V & V3_NOOUT) mine = bits8 ^ (rec[0].y >> 16);
+    else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint32_t src = rec[j].y >> 16;
@@ -576,6 +581,13 @@ static float time_variant(const char* name, const PyramidDesc& pd, const uint8_t
     auto launch = [&]() {
         const int g = grid ? grid : n;
         if (v3 == 10) hipLaunchKernelGGL(clatch_pool_kernel<0>, dim3(grid ? grid : 256), dim3(64 * kPoolWaves), 0, 0, a, darena);
+        else if (v3 >= 100) {
+            switch (v3 - 100) {
+#define V3CASE(X) case X: hipLaunchKernelGGL(clatch_v3_kernel<X>, dim3(g), dim3(64), dyn_lds, 0, a, darena); break;
+                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72)
+                default: printf("no such v3 variant\n"); exit(1);
+            }
+        }
         else if (v3 == 0) hipLaunchKernelGGL(clatch_v3_kernel<0>, dim3(g), dim3(64), dyn_lds, 0, a, darena);
         else if (v3 == 2) hipLaunchKernelGGL(clatch_v3_kernel<V3_NOCLAMP>, dim3(g), dim3(64), dyn_lds, 0, a, darena);
         else if (production) hipLaunchKernelGGL(clatch_kernel, dim3(g), dim3(64), dyn_lds, 0, a, darena);
@@ -705,6 +717,13 @@ int main(int argc, char** argv)
             time_variant<0>("pool", pd, darena, dk, n, dd, false, 0, 0, 10);
             stamp_report(pd, darena, dk, n, dd, 10);
             time_variant<0>("v3", pd, darena, dk, n, dd, false, 0, 0, 0);
+            if (!interior) {
+                const struct { const char* nm; int v; } abl[] = {
+                    { "v3abl: no gather loads", 4 }, { "v3abl: no tests", 8 }, { "v3abl: no sincos", 16 }, { "v3abl: no copies", 32 }, { "v3abl: no un-permute", 64 },
+                    { "v3abl: no coordinates (gathers stay)", 128 }, { "v3abl: no coordinates, no gathers", 132 }, { "v3abl: no gathers, no tests", 12 },
+                    { "v3abl: no copies, no tests", 36 + 4 }, { "v3abl: no tests, no un-permute", 72 }, { "v3abl: everything off", 252 } };
+                for (auto& e : abl) if (e.v != 40) time_variant<0>(e.nm, pd, darena, dk, n, dd, false, 0, 0, 100 + e.v);
+            }
             stamp_report(pd, darena, dk, n, dd, 1);
             if (interior) { time_variant<0>("v3 noclamp", pd, darena, dk, n, dd, false, 0, 0, 2); stamp_report(pd, darena, dk, n, dd, 2); }
             if (!interior) for (int g : { 3072, 2858, 2560, 2500, 2048, 3334, 4096, 6144 })
