@@ -406,7 +406,7 @@ class Context:
     # -- match
     def set_k2nn_formulation(self, name):
         """"matrix" (FP4 matrix pipe, default) or "popcount" (xor + popcount on the vector ALU): same results."""
-        self._chk(self.lib.clc_k2nn_set_formulation(self.h, {"matrix": 0, "popcount": 1}[name]))
+        self._chk(self.lib.clc_k2nn_set_formulation(self.h, {"matrix": 0, "popcount": 1, "matrix-plain": 2}[name]))
 
     @property
     def k2nn_queries_per_block(self):

@@ -270,7 +270,8 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         if (v > 0) ctx->target_blocks = v;
     }
     if (const char* e = getenv("CLC_K2NN_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
-    if (const char* e = getenv("CLC_K2NN_FORMULATION")) ctx->formulation = (e[0] == 'p' || e[0] == '1') ? K2NN_POPCOUNT : K2NN_MATRIX;
+    if (const char* e = getenv("CLC_K2NN_FORMULATION"))
+        ctx->formulation = (e[0] == 'p' || e[0] == '1') ? K2NN_POPCOUNT : ((e[0] == '2' || strstr(e, "plain")) ? K2NN_MATRIX_PLAIN : K2NN_MATRIX);
     if (dopts) {
         ctx->has_det = true;
         ctx->dopts = *dopts;
@@ -610,9 +611,9 @@ int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4)
 
 int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation)
 {
-    if (!ctx || (formulation != CLC_K2NN_MATRIX && formulation != CLC_K2NN_POPCOUNT))
+    if (!ctx || (formulation != CLC_K2NN_MATRIX && formulation != CLC_K2NN_POPCOUNT && formulation != CLC_K2NN_MATRIX_PLAIN))
         return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_set_formulation: bad argument");
-    ctx->formulation = formulation == CLC_K2NN_POPCOUNT ? K2NN_POPCOUNT : K2NN_MATRIX;
+    ctx->formulation = formulation == CLC_K2NN_POPCOUNT ? K2NN_POPCOUNT : (formulation == CLC_K2NN_MATRIX_PLAIN ? K2NN_MATRIX_PLAIN : K2NN_MATRIX);
     return CLC_OK;
 }
 
@@ -626,7 +627,7 @@ int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t,
 {
     if (!ctx || nq <= 0 || nt <= 0 || !d_q || !d_t || !d_match) return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_clock_check: bad argument");
     if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 15u)) return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_clock_check: misaligned device pointer");
-    if (ctx->formulation != K2NN_MATRIX) return fail(ctx, CLC_ERR_STATE, "k2nn_clock_check: matrix formulation only");
+    if (ctx->formulation == K2NN_POPCOUNT) return fail(ctx, CLC_ERR_STATE, "k2nn_clock_check: matrix formulation only");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     std::vector<K2nnJobDev> jobs(1);

@@ -107,7 +107,7 @@ struct K2nnPlan {
     bool     atomic_merge; // every job fits the 22-bit global train index -> atomic top-2 merge
 };
 // The two formulations of the sweep (k2nn.hip): FP4 matrix pipe (default) and round 1's xor + popcount VALU kernel.
-enum { K2NN_MATRIX = 0, K2NN_POPCOUNT = 1 };
+enum { K2NN_MATRIX = 0, K2NN_POPCOUNT = 1, K2NN_MATRIX_PLAIN = 2 };   // PLAIN: round 2's tile loop (no MFMA / top-2 interleave)
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
 K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true, int formulation = K2NN_MATRIX);
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).

@@ -211,7 +211,8 @@ int clc_match_jobs_counted_dev(clc_ctx* ctx, const void* d_desc_base, const clc_
  * CLC_K2NN_MATRIX (default): bits as +-1 FP4 values on the matrix pipe, exact distances in the fp32 accumulator;
  * CLC_K2NN_POPCOUNT: xor + popcount on the vector ALU, the literal form of CUDAK2NN.cu:58-66 (kept for A/B timing).
  * Also settable at context creation through the environment, CLC_K2NN_FORMULATION=matrix|popcount. */
-enum { CLC_K2NN_MATRIX = 0, CLC_K2NN_POPCOUNT = 1 };
+enum { CLC_K2NN_MATRIX = 0, CLC_K2NN_POPCOUNT = 1,
+       CLC_K2NN_MATRIX_PLAIN = 2 /* the matrix sweep without its MFMA / top-2 interleave (round 2's loop), for A/B timing */ };
 int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation);
 /* Queries per sweep workgroup of the context's formulation: the grain on which a caller that deals query slices out
  * to several GPUs (clc_match_job.q_offset / nq) should cut them, so that no workgroup is split between two jobs. */

@@ -9,10 +9,11 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["matrix", "popcount"])
+@pytest.fixture(autouse=True, params=["matrix", "popcount", "matrix-plain"])
 def k2nn_formulation(request, gpu_ctx):
-    """Every test of this file runs under both formulations of the sweep (coloc_amd/csrc/k2nn.hip): the FP4
-    matrix-pipe kernel (default) and the xor + popcount kernel; both must equal the oracle bit for bit."""
+    """Every test of this file runs under every formulation of the sweep (coloc_amd/csrc/k2nn.hip): the FP4 matrix-pipe
+    kernel (default: MFMA chains with the top-2 update in their shadow), the xor + popcount kernel, and the matrix kernel
+    with round 2's plain tile loop; all must equal the oracle bit for bit."""
     gpu_ctx.set_k2nn_formulation(request.param)
     yield request.param
     gpu_ctx.set_k2nn_formulation("matrix")
@@ -241,8 +242,8 @@ def test_clock_check_grid_padding(gpu_ctx, oracle, k2nn_formulation, nq, nt):
     padded to a multiple of 8 query blocks (nq = 1000 -> 4 blocks, 4880 -> 20: neither a multiple of 8).  The matches it
     leaves behind are the ordinary sweep's, and the sweep that follows finds its workspace armed."""
     import torch
-    if k2nn_formulation != "matrix":
-        pytest.skip("the stamped diagnostic build exists for the matrix formulation only")
+    if k2nn_formulation == "popcount":
+        pytest.skip("the stamped diagnostic build exists for the matrix formulations only")
     Q, T = synth.planted_descriptors(nq, nt, seed=77 + nq)
     dq, dt = torch.from_numpy(Q).cuda(), torch.from_numpy(T).cuda()
     out = torch.full((nq,), -9, dtype=torch.int32, device="cuda")
