@@ -20,8 +20,13 @@ Per frame and camera (reference include/coloc/coloc.hpp:201-272 intraPoseEstimat
   2. map tracking: the frame's observed descriptors (map descriptors with bit noise + distractors; device-resident
      like the CLATCH output they stand in for) against the map on the GPU (clc_match_map_dev), threshold MatcherOptions.thresh = 60 -> 2D-3D correspondences (GPUMatcher.hpp:174-178,252-271);
   3. clc_pnp_localize: 256 P3P samples -> scored hypotheses -> LM refinement + 6x6 covariance;
-  4. fusion: each camera's position is fused with its neighbour's estimate of it (here: the neighbour's own
-     error-free relative offset, so the fused value can be checked) by covariance intersection.
+  4. inter-camera step (plane scene; reference include/coloc/coloc.hpp:274-392 interPoseEstimator(source, dest)): the two
+     frames' CLATCH outputs matched on the device (computeMatchesPair, :287), a-contrario five-point filter + relative pose from
+     E with the chirality vote (filterMatchesPair, :296), the pair's temporary map triangulated and brought to the global map's
+     scale through the features both maps hold (map matches, threshold 60, :323-336), the destination pose refined against it
+     (:340) and fused with the destination's own estimate by covariance intersection (:362-389).  Nothing is taken from the
+     ground truth; the fused position is CHECKED against the pose the frame was rendered from.
+     (--scene synthetic keeps round 1's stand-in: the neighbour's error-free relative offset.)
 Reports frames/s per camera, per-stage p50 latencies and the position error against ground truth.
 """
 import argparse
@@ -39,6 +44,53 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def rot_y(a):
     import numpy as np
     return np.array([[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]])
+
+
+def motion_from_essential(E):
+    """The four (R, t) candidates of an essential matrix, x2 ~ R x1 + t, |t| = 1 (MotionFromEssential)."""
+    import numpy as np
+    U, _, Vt = np.linalg.svd(E)
+    if np.linalg.det(U) < 0:
+        U = -U
+    if np.linalg.det(Vt) < 0:
+        Vt = -Vt
+    Wm = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    R1, R2, t = U @ Wm @ Vt, U @ Wm.T @ Vt, U[:, 2]
+    return [(R1, t), (R1, -t), (R2, t), (R2, -t)]
+
+
+def triangulate_two_views(R, t, n1, n2):
+    """Points (camera 1's frame) of normalised image points n1, n2 (n x 2) seen by cameras [I|0] and [R|t]: the depths along the two
+    rays that bring them closest (2 x 2 normal equations per point, closed form; the reference's TriangulateDLT differs from it by
+    less than the measurement noise and costs a 4 x 4 SVD per point -- 12 ms per pair in numpy against 0.3).  Returns (X1, depth1, depth2)."""
+    import numpy as np
+    a = np.c_[n1, np.ones(len(n1))] @ R.T            # R [n1; 1]
+    b = np.c_[n2, np.ones(len(n2))]
+    # min | l1 a - l2 b + t |^2
+    aa, bb, ab = (a * a).sum(1), (b * b).sum(1), (a * b).sum(1)
+    at, bt = a @ t, b @ t
+    det = aa * bb - ab * ab
+    det = np.where(np.abs(det) < 1e-18, 1e-18, det)
+    l1 = (-at * bb + bt * ab) / det
+    l2 = (-at * ab + bt * aa) / det
+    X1 = np.c_[n1, np.ones(len(n1))] * l1[:, None]
+    return X1, l1, l2
+
+
+def relative_pose_from_essential(E, K, x1, x2):
+    """RelativePoseFromEssential (RobustMatcher.hpp:176-183): the candidate with most points in front of both cameras.
+    Returns (R, t, X1 (n x 3, camera-1 frame, unit baseline), in_front mask) or None."""
+    import numpy as np
+    Ki = np.linalg.inv(K)
+    n1 = (np.c_[x1, np.ones(len(x1))] @ Ki.T)[:, :2]
+    n2 = (np.c_[x2, np.ones(len(x2))] @ Ki.T)[:, :2]
+    best = None
+    for R, t in motion_from_essential(E):
+        X1, l1, l2 = triangulate_two_views(R, t, n1, n2)
+        ok = (l1 > 0) & (l2 > 0)
+        if best is None or ok.sum() > best[3].sum():
+            best = (R, t, X1, ok)
+    return best if best is not None and best[3].sum() >= 8 else None
 
 
 def main():
@@ -201,6 +253,9 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
     sptr = stream.cuda_stream
     tex = synth.plane_texture(size=2000, seed=77, n_rect=2600)
     centre = np.array([5.0, 5.0])
+    # a gentle relief under the cameras: a flat scene leaves the essential matrix with its planar two-fold ambiguity
+    relief = synth.smooth_relief(centres=((4.2, 4.4, 0.55, 0.9), (6.0, 5.6, 0.45, 0.7), (5.1, 6.3, 0.40, 0.6), (5.9, 4.0, 0.50, 0.8), (3.6, 6.0, 0.45, 0.7)))
+    CAP = 20000
 
     def feature_xy(kps):
         s = np.power(np.float32(1.2), kps["scale"].astype(np.float32))
@@ -208,8 +263,8 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
 
     # the map: one reference view a little higher up, its CLATCH descriptors + the 3-D points under its keypoints
     Rm, tm = synth.look_at_plane_pose(centre, HEIGHT * 1.06)
-    kps_m, desc_m, _ = ctx.detect_and_describe(synth.render_plane(tex, PPU, K, Rm, tm, W, H), capacity=20000)
-    Xmap = synth.backproject_to_plane(feature_xy(kps_m), K, Rm, tm)
+    kps_m, desc_m, _ = ctx.detect_and_describe(synth.render_plane(tex, PPU, K, Rm, tm, W, H, relief=relief), capacity=20000)
+    Xmap = synth.backproject_to_plane(feature_xy(kps_m), K, Rm, tm, relief=relief)
     ctx.set_map(desc_m)
 
     def pose_of(cam, f):
@@ -219,8 +274,11 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
                                         tilt=(0.03 * math.cos(a), 0.03 * math.sin(a) - 0.01 * cam))
         return R, t, -R.T @ t
 
-    frames = {(cam, u): torch.from_numpy(synth.render_plane(tex, PPU, K, *pose_of(cam, u)[:2], W, H)).to(dev)
+    frames = {(cam, u): torch.from_numpy(synth.render_plane(tex, PPU, K, *pose_of(cam, u)[:2], W, H, relief=relief)).to(dev)
               for cam in my_cams for u in range(args.unique_frames)}
+    # what a camera's frame leaves behind for the inter-camera step: its descriptors (device), keypoints, map matches, pose + covariance
+    cam_desc = {cam: torch.zeros((CAP, 64), dtype=torch.uint8, device=dev) for cam in (my_cams if world == 1 else [rank, (rank + 1) % world])}
+    d_pair = torch.empty(CAP, dtype=torch.int32, device=dev)
     d_kps, d_cnt, d_desc = ctx.detect_buffers()
     cnt_view = torch.empty(1, dtype=torch.int32, device=dev)
     d_m = torch.empty(20000, dtype=torch.int32, device=dev)
@@ -231,11 +289,13 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
     def d2d(dst, src, nbytes):
         hip.hipMemcpyAsync(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(nbytes), 3, ctypes.c_void_p(sptr))
 
-    lat = {"front_end": [], "match": [], "pose": [], "fuse": [], "frame": []}
-    pos_err, pos_err_fused, n_inl, n_match, n_kp = [], [], [], [], []
+    lat = {"front_end": [], "match": [], "pose": [], "inter": [], "fuse": [], "frame": []}
+    pos_err, pos_err_fused, pos_err_inter, n_inl, n_match, n_kp, n_pair, n_pair_inl, n_common = [], [], [], [], [], [], [], [], []
+    inter_fail = 0
     est = {}
     t_start = time.perf_counter()
     for f in range(args.frames):
+        est = {}
         for cam in my_cams:
             R, t, C = pose_of(cam, f)
             img = frames[(cam, f % args.unique_frames)]
@@ -265,29 +325,92 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
             Rt, cov = r["Rt"], r["cov"]
             Ce = -Rt[:, :3].T @ Rt[:, 3]
             Cc = Rt[:, :3].T @ cov[3:, 3:] @ Rt[:, :3]
-            est[cam] = (Ce, Cc, C)
+            d2d(cam_desc[cam].data_ptr(), d_desc, n * 64)       # the frame's descriptors stay on the device for the pair match
+            est[cam] = dict(C=Ce, cov=Cc, gt=C, Rt=Rt, n=n, xy=feature_xy(kps), m=m)
             lat["front_end"].append(t1 - t0); lat["match"].append(t2 - t1); lat["pose"].append(t3 - t2); lat["frame"].append(t3 - t0)
             pos_err.append(np.linalg.norm(Ce - C)); n_inl.append(len(r["inliers"])); n_match.append(len(sel)); n_kp.append(n)
         if world > 1:
+            # one camera per rank: the inter-camera step of camera `rank` (destination) needs the frame of its source, camera
+            # rank + 1: descriptors, keypoint coordinates, map matches, pose and covariance travel in fixed-capacity blocks
             mine = est.get(rank)
-            buf = torch.zeros(15, dtype=torch.float64, device=dev)
+            blk = torch.zeros((CAP, 7), dtype=torch.float64, device=dev)          # per keypoint: x, y, map match; header in row CAP - 1.. (below)
+            hdr = torch.zeros(32, dtype=torch.float64, device=dev)
             if mine is not None:
-                buf[:3] = torch.from_numpy(mine[0]); buf[3:12] = torch.from_numpy(mine[1].reshape(9)); buf[12:15] = torch.from_numpy(mine[2])
-            allb = torch.zeros((world, 15), dtype=torch.float64, device=dev)
-            dist.all_gather_into_tensor(allb.view(-1), buf)
-            allb = allb.cpu().numpy()
-            est = {c: (allb[c, :3], allb[c, 3:12].reshape(3, 3), allb[c, 12:15]) for c in range(world) if allb[c, 3:12].any()}
+                blk[:mine["n"], 0:2] = torch.from_numpy(mine["xy"]).to(dev)
+                blk[:mine["n"], 2] = torch.from_numpy(mine["m"].astype(np.float64)).to(dev)
+                hdr[0] = mine["n"]; hdr[1:13] = torch.from_numpy(mine["Rt"].reshape(12)).to(dev); hdr[13:22] = torch.from_numpy(mine["cov"].reshape(9)).to(dev)
+                hdr[22:25] = torch.from_numpy(mine["gt"]).to(dev); hdr[25] = 1.0
+            all_desc = torch.empty((world, CAP, 64), dtype=torch.uint8, device=dev)
+            all_blk = torch.empty((world, CAP, 7), dtype=torch.float64, device=dev)
+            all_hdr = torch.empty((world, 32), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(all_desc.view(-1), cam_desc[rank].view(-1))
+            dist.all_gather_into_tensor(all_blk.view(-1), blk.view(-1))
+            dist.all_gather_into_tensor(all_hdr.view(-1), hdr)
+            src = (rank + 1) % world
+            hs = all_hdr[src].cpu().numpy()
+            if hs[25] > 0 and src != rank:
+                ns = int(hs[0])
+                bs = all_blk[src, :ns].cpu().numpy()
+                cam_desc[src].copy_(all_desc[src])
+                Rts = hs[1:13].reshape(3, 4)
+                est[src] = dict(C=-Rts[:, :3].T @ Rts[:, 3], cov=hs[13:22].reshape(3, 3), gt=hs[22:25], Rt=Rts, n=ns, xy=bs[:, 0:2].copy(),
+                                m=bs[:, 2].astype(np.int64))
+        # ---- inter-camera step + fusion: destination = cam, source = its neighbour (coloc.hpp:274-392)
         for cam in my_cams:
             nb = (cam + 1) % n_cams
             if cam not in est or nb not in est or nb == cam:
                 continue
+            S, D = est[nb], est[cam]
             t4 = time.perf_counter()
-            Ce, Cc, Cgt = est[cam]
-            Cn, Ccn, Cngt = est[nb]
-            rel = Cgt - Cngt                                   # the neighbour's (here: exact) relative measurement
-            om, Cf, pf = cov_intersection(Cc, Ccn + 1e-9 * np.eye(3), Ce, Cn + rel)
-            lat["fuse"].append(time.perf_counter() - t4)
-            pos_err_fused.append(np.linalg.norm(pf - Cgt))
+            # computeMatchesPair(source, dest): Q = the source frame's descriptors, T = the destination's (GPUMatcher.hpp:165-172)
+            ctx.match_2nn_dev(cam_desc[nb].data_ptr(), S["n"], cam_desc[cam].data_ptr(), D["n"], 60, d_pair.data_ptr(), sptr)
+            pm = d_pair[:S["n"]].cpu().numpy()
+            q = np.nonzero(pm >= 0)[0]
+            ok = False
+            if len(q) >= 16:
+                x1, x2 = S["xy"][q], D["xy"][pm[q]]
+                # filterMatchesPair: a-contrario five-point + relative pose from E (RobustMatcher.hpp:153-186)
+                e = ctx.essential_acransac(x1, x2, K, K, (W, H), max_iteration=256, seed=f + 1)
+                if e["E"] is not None and len(e["inliers"]) >= 13:
+                    inl = e["inliers"]
+                    rp = relative_pose_from_essential(e["E"], K, x1[inl], x2[inl])
+                    if rp is not None:
+                        Rr, tr, Xtmp, front = rp
+                        qi = q[inl][front]                       # source keypoints of the temporary map's points
+                        Xtmp, x2i = Xtmp[front], x2[inl][front]
+                        # scale of the temporary map against the global one through the features both hold (the source frame's map
+                        # matches, threshold 60): a depth-ratio screen, then the reference's mean of consecutive distance ratios
+                        # (colocUtils.hpp:184-211)
+                        ms = S["m"][qi]
+                        com = np.nonzero(ms >= 0)[0]
+                        scale = None
+                        if len(com) >= 8:
+                            Xg = Xmap[ms[com]]
+                            Xg_s = Xg @ S["Rt"][:, :3].T + S["Rt"][:, 3]
+                            ratio = np.linalg.norm(Xg_s, axis=1) / np.maximum(np.linalg.norm(Xtmp[com], axis=1), 1e-12)
+                            keep = np.abs(ratio / np.median(ratio) - 1.0) < 0.2
+                            com, Xg = com[keep], Xg[keep]
+                            if len(com) >= 8:
+                                d1 = np.linalg.norm(Xg[1:] - Xg[:-1], axis=1)
+                                d2 = np.linalg.norm(Xtmp[com][1:] - Xtmp[com][:-1], axis=1)
+                                good = d2 > 1e-9
+                                scale = float(np.mean(d1[good] / d2[good]))
+                        if scale is not None and np.isfinite(scale) and scale > 0:
+                            # the destination's pose through the source: X_d = R_rel X_s + s t_rel, X_s = R_s X_w + t_s
+                            Rt0 = np.c_[Rr @ S["Rt"][:, :3], Rr @ S["Rt"][:, 3] + scale * tr]
+                            Xw = (scale * Xtmp - S["Rt"][:, 3]) @ S["Rt"][:, :3]           # temporary map in world coordinates
+                            Rt_i, cov_i, rmse_i, _ = ctx.pnp_refine(Xw, x2i, K, Rt0)       # refinePose(tempScene, extrinsics only) :340
+                            Ci = -Rt_i[:, :3].T @ Rt_i[:, 3]
+                            Cci = Rt_i[:, :3].T @ cov_i[3:, 3:] @ Rt_i[:, :3] + S["cov"]     # covInter = currentCov[source] + cov (:366)
+                            t5 = time.perf_counter()
+                            om, Cf, pf = cov_intersection(D["cov"], Cci + 1e-12 * np.eye(3), D["C"], Ci)
+                            t6 = time.perf_counter()
+                            lat["inter"].append(t5 - t4); lat["fuse"].append(t6 - t5)
+                            pos_err_inter.append(np.linalg.norm(Ci - D["gt"])); pos_err_fused.append(np.linalg.norm(pf - D["gt"]))
+                            n_pair.append(len(q)); n_pair_inl.append(len(inl)); n_common.append(len(com))
+                            ok = True
+            if not ok:
+                inter_fail += 1
     wall = time.perf_counter() - t_start
     if rank == 0:
         p50 = lambda v: float(np.median(v) * 1e3) if len(v) else None
@@ -301,7 +424,14 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
                "p50_ms": {k: p50(v) for k, v in lat.items()},
                "keypoints_p50": med(n_kp), "map_matches_p50": med(n_match), "inliers_p50": med(n_inl),
                "position_error_p50": med(pos_err), "position_error_max": float(np.max(pos_err)) if pos_err else None,
-               "position_error_fused_p50": med(pos_err_fused), "camera_height": HEIGHT,
+               "position_error_fused_p50": med(pos_err_fused), "position_error_fused_max": float(np.max(pos_err_fused)) if pos_err_fused else None,
+               "position_error_inter_p50": med(pos_err_inter), "position_error_inter_max": float(np.max(pos_err_inter)) if pos_err_inter else None,
+               "inter_steps": len(pos_err_inter), "inter_failures": inter_fail,
+               "pair_matches_p50": med(n_pair), "pair_inliers_p50": med(n_pair_inl), "common_map_features_p50": med(n_common),
+               "inter_rule": "frame-to-frame K2NN (thr 60) -> a-contrario five-point -> relative pose from E -> scale from the features the "
+                             "temporary and the global map share -> LM refinement of the destination pose -> covariance intersection "
+                             "(coloc.hpp:274-392); nothing taken from the rendered poses",
+               "camera_height": HEIGHT,
                "pose_rule": "a-contrario P3P, 256 iterations, error_max = inf (Localizer.hpp:82-93) + LM refinement",
                "note": "frames are rendered on the host before the loop; everything from the uploaded frame to the fused position is timed"}
         print(json.dumps(out))

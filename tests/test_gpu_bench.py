@@ -83,6 +83,14 @@ def test_streaming_scenario_runs_and_localizes():
     assert d["inliers_p50"] > 0.8 * d["map_matches_p50"]
     assert d["position_error_p50"] < 0.005 * d["camera_height"] and d["position_error_max"] < 0.02 * d["camera_height"]
     assert d["cameras_at_30fps_per_gpu"] > 8
+    # the inter-camera step (coloc.hpp:274-392) is the real chain now -- frame-to-frame match, a-contrario five-point, relative
+    # pose from E, scale from the shared map features, refinement, covariance intersection -- with nothing taken from the rendered
+    # poses: every pair must go through, the neighbour-derived position must land within 2 % of the camera height (median) and
+    # the fused position must stay as good as the camera's own estimate
+    assert d["inter_steps"] == 12 and d["inter_failures"] == 0
+    assert d["pair_matches_p50"] > 500 and d["pair_inliers_p50"] > 0.8 * d["pair_matches_p50"] and d["common_map_features_p50"] > 50
+    assert d["position_error_inter_p50"] < 0.02 * d["camera_height"]
+    assert d["position_error_fused_p50"] < 0.005 * d["camera_height"] and d["position_error_fused_max"] < 0.02 * d["camera_height"]
 
 
 def test_streaming_scenario_synthetic_descriptors():
