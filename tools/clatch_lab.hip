@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void clatch_lab_kernel(const ClatchArgs args, c
 
 // ---- v3: one keypoint per wave, no loop; scalar keypoint load; slot-table loads issued first and consumed after the fill;
 //      copies unrolled with immediate offsets.  Bit-exact.
-enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_NOGATHER = 4u, V3_NOTEST = 8u, V3_NOSINCOS = 16u, V3_NOCOPY = 32u, V3_NOOUT = 64u, V3_NOCOORD = 128u };
+enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_NOGATHER = 4u, V3_NOTEST = 8u, V3_NOSINCOS = 16u, V3_NOCOPY = 32u, V3_NOOUT = 64u, V3_NOCOORD = 128u, V3_G1 = 256u, V3_G64 = 512u, V3_GDW = 1024u };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <unsigned V>
 __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
@@ -252,7 +252,10 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
             const float fy = (fpy + (xs[bx] + yc[by])) + 0.5f;
             int sx = (int)fx, sy = (int)fy;
             if (!(V & V3_NOCLAMP)) { sx = clamp_i32(sx, wmax); sy = clamp_i32(sy, hmax); }
-            const uint32_t off = (V & V3_NOCOORD) ? (uint32_t)(by * 8 + dy) * L.pitch + (uint32_t)(bx * 8 + dx) + lane : __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
+            uint32_t off = (V & V3_NOCOORD) ? (uint32_t)(by * 8 + dy) * L.pitch + (uint32_t)(bx * 8 + dx) : __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
+            if (V & V3_G1) off = (uint32_t)(by * 8) * L.pitch + (uint32_t)(bx * 64) + lane;              // one 64-byte line per instruction
+            if (V & V3_G64) off = (uint32_t)(by * 8 + (int)lane) * L.pitch + (uint32_t)(bx * 8);          // 64 lines per instruction
+            if (V & V3_GDW) off = (uint32_t)(by * 8 + dy) * L.pitch + (uint32_t)(bx * 8 + dx) * 4u;       // 8 lines, lanes 4 bytes apart
             roi[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = (V & V3_NOGATHER) ? (uint8_t)off : img[off];
         }
     }
@@ -584,7 +587,7 @@ static float time_variant(const char* name, const PyramidDesc& pd, const uint8_t
         else if (v3 >= 100) {
             switch (v3 - 100) {
 #define V3CASE(X) case X: hipLaunchKernelGGL(clatch_v3_kernel<X>, dim3(g), dim3(64), dyn_lds, 0, a, darena); break;
-                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72)
+                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72) V3CASE(384) V3CASE(640) V3CASE(1152) V3CASE(392) V3CASE(1160) V3CASE(136) V3CASE(648)
                 default: printf("no such v3 variant\n"); exit(1);
             }
         }
@@ -721,7 +724,10 @@ int main(int argc, char** argv)
                 const struct { const char* nm; int v; } abl[] = {
                     { "v3abl: no gather loads", 4 }, { "v3abl: no tests", 8 }, { "v3abl: no sincos", 16 }, { "v3abl: no copies", 32 }, { "v3abl: no un-permute", 64 },
                     { "v3abl: no coordinates (gathers stay)", 128 }, { "v3abl: no coordinates, no gathers", 132 }, { "v3abl: no gathers, no tests", 12 },
-                    { "v3abl: no copies, no tests", 36 + 4 }, { "v3abl: no tests, no un-permute", 72 }, { "v3abl: everything off", 252 } };
+                    { "v3abl: no copies, no tests", 36 + 4 }, { "v3abl: no tests, no un-permute", 72 }, { "v3abl: everything off", 252 },
+                    { "v3abl: gathers within 1 line", 384 }, { "v3abl: gathers over 64 lines", 640 }, { "v3abl: gathers 8 rows x 32 B", 1152 },
+                    { "v3abl: NO TESTS, gathers within 1 line", 392 }, { "v3abl: NO TESTS, gathers 8 rows x 32 B", 1160 }, { "v3abl: NO TESTS, gathers 8 rows x 8 B", 136 },
+                    { "v3abl: NO TESTS, gathers over 64 lines", 648 } };
                 for (auto& e : abl) if (e.v != 40) time_variant<0>(e.nm, pd, darena, dk, n, dd, false, 0, 0, 100 + e.v);
             }
             stamp_report(pd, darena, dk, n, dd, 1);
