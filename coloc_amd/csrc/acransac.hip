@@ -74,7 +74,7 @@ __device__ __forceinline__ bool acr_gt(const uint64_t ka, const uint32_t ia, con
 // instead of 55 LDS round trips with a workgroup barrier each).
 // The network runs on ONE 64-bit word per element, compared with v_min_f64 / v_max_f64 (two instructions per exchange
 // instead of a 64-bit compare, an index compare and three selects): the residual's bits with the low 13 mantissa bits
-// replaced by the element index (n <= 8192).  That orders by (top 51 bits of the residual, index); the exact (residual,
+// replaced by the element index (13 bits for n <= 8192, 14 up to 16 384).  That orders by (top 51 bits of the residual, index); the exact (residual,
 // index) order differs from it only where two residuals agree in their top 51 bits, so afterwards every element recomputes
 // its exact residual, neighbours are compared exactly, and in the (rare) case of an inversion anywhere in the workgroup
 // the exact-key network below re-sorts -- the result is always the exact lexicographic order.
@@ -164,13 +164,21 @@ __device__ __forceinline__ void acr_bitonic(uint64_t (&key)[E], uint32_t (&idx)[
             } else {
                 const int dt = j / E;                                    // partner thread = tid ^ dt, same e
                 const bool lower = (tid & dt) == 0;
+                uint32_t oidx[E];                                         // EXACT, cross-wave: the partner's indices (second pass through the buffer)
                 if (dt >= 64) {
+                    if (EXACT) {
+                        // the rare exact re-sort stages the indices first, then the keys, through the SAME words: the staging area holds
+                        // one 8-byte word per element (128 KB at 16 384 elements; keys + indices side by side would not fit)
+                        __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < E; ++e) lkey[e * T + tid] = (uint64_t)idx[e];
+                        __syncthreads();
+#pragma unroll
+                        for (int e = 0; e < E; ++e) oidx[e] = (uint32_t)lkey[e * T + (tid ^ dt)];
+                    }
                     __syncthreads();                                      // the previous exchange's reads are done
 #pragma unroll
-                    for (int e = 0; e < E; ++e) {
-                        lkey[e * T + tid] = EXACT ? key[e] : (uint64_t)__double_as_longlong(c[e]);
-                        if (EXACT) lidx[e * T + tid] = idx[e];
-                    }
+                    for (int e = 0; e < E; ++e) lkey[e * T + tid] = EXACT ? key[e] : (uint64_t)__double_as_longlong(c[e]);
                     __syncthreads();
                 }
 #pragma unroll
@@ -179,7 +187,7 @@ __device__ __forceinline__ void acr_bitonic(uint64_t (&key)[E], uint32_t (&idx)[
                     if (EXACT) {
                         uint64_t ok;
                         uint32_t oi;
-                        if (dt >= 64) { ok = lkey[e * T + (tid ^ dt)]; oi = lidx[e * T + (tid ^ dt)]; }
+                        if (dt >= 64) { ok = lkey[e * T + (tid ^ dt)]; oi = oidx[e]; }
                         else {
                             const uint32_t lo = __shfl_xor((uint32_t)key[e], dt), hi = __shfl_xor((uint32_t)(key[e] >> 32), dt);
                             ok = ((uint64_t)hi << 32) | lo;
@@ -206,8 +214,8 @@ __global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, cons
     extern __shared__ unsigned char acr_lds[];
     const int slot = blockIdx.x, tid = threadIdx.x, T = blockDim.x, n = pb.n;
     if (slot >= state->cur_batch * pb.max_models) return;          // the grid covers the largest batch; this round is smaller
-    uint64_t* lkey = reinterpret_cast<uint64_t*>(acr_lds);               // [e][tid] staging of the cross-wave exchanges
-    uint32_t* lidx = reinterpret_cast<uint32_t*>(acr_lds + (size_t)P * 8);
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(acr_lds);               // [e][tid] staging of the cross-wave exchanges (one word per element)
+    uint32_t* lidx = nullptr;
     __shared__ double s_nfa[1024 / 64], s_ek[1024 / 64];
     __shared__ int s_k[1024 / 64], s_cnt[1024 / 64];
     __shared__ uint64_t s_edge_key[1024 / 64];
@@ -229,6 +237,8 @@ __global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, cons
     double c[E];
     int cnt = 0;
     const uint64_t kMaxFinite = 0x7fefffffffffffffull;
+    // the composite sort key keeps the residual's top bits and carries the element index in the low 13 (n <= 8192) or 14 (n <= 16384) ones
+    constexpr uint64_t kIdxMask = E > 8 ? 0x3FFFull : 0x1FFFull;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int i = tid * E + e;
@@ -239,13 +249,13 @@ __global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, cons
             const uint64_t rb = (uint64_t)__double_as_longlong(r);
             bits = rb < kMaxFinite ? rb : kMaxFinite;
         }
-        c[e] = __longlong_as_double((long long)((bits & ~0x1FFFull) | (uint64_t)i));
+        c[e] = __longlong_as_double((long long)((bits & ~kIdxMask) | (uint64_t)i));
     }
     acr_bitonic<E, false>(key, idx, c, P, tid, T, lkey, lidx);
     // exact keys of the elements as they stand now, then the neighbour check
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-        const uint32_t i = (uint32_t)((uint64_t)__double_as_longlong(c[e]) & 0x1FFFull);
+        const uint32_t i = (uint32_t)((uint64_t)__double_as_longlong(c[e]) & kIdxMask);
         if ((int)i < n) { idx[e] = i; key[e] = (uint64_t)__double_as_longlong(residual((int)i)); }
         else { idx[e] = 0xFFFFFFFFu; key[e] = 0x7ff0000000000000ull; }   // padding: +inf, index above every real one
     }
@@ -432,6 +442,7 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
         }
         s.iter += consumed;
         s.rounds += 1;
+        if (B > 0) s.rounds_eval += 1;
         s.last_batch = consumed;
         // next round: while nothing has happened look further ahead per round; after an event the whole reserve goes in one
         if (event_it < B || !s.index_all) s.grow = kAcrMaxBatch;
@@ -514,7 +525,7 @@ __global__ __launch_bounds__(256) void acr_finish_kernel(const AcrProblem pb, co
         r.n_inliers = n_inl;
         r.valid = ok ? s.best_iter : -1;
         r.iterations = s.iter;
-        r.rounds = s.rounds;
+        r.rounds = s.rounds_eval;               // not the sequence number: the round enqueued ahead of the host's knowledge is empty
         *d_res = r;
         if (h_res) *h_res = r;
     }
@@ -535,7 +546,7 @@ static hipError_t acr_launch_nfa(const AcrProblem& pb, int B, int P, const doubl
     }
     const int T = P / E;
     // LDS is only touched by exchanges that cross waves
-    const size_t lds = T > 64 ? (size_t)P * 12 : 0;
+    const size_t lds = T > 64 ? (size_t)P * 8 : 0;
     hipLaunchKernelGGL(acr_nfa_kernel<E>, dim3(B * pb.max_models), dim3(T), lds, stream, pb, P, d_models, d_hyp, d_sorted, d_state);
     return hipGetLastError();
 }
@@ -553,7 +564,8 @@ hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp
     if (P <= 1024) e = acr_launch_nfa<1>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
     else if (P == 2048) e = acr_launch_nfa<2>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
     else if (P == 4096) e = acr_launch_nfa<4>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
-    else e = acr_launch_nfa<8>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
+    else if (P == 8192) e = acr_launch_nfa<8>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
+    else e = acr_launch_nfa<16>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(acr_select_kernel, dim3(1), dim3(256), 0, stream, pb, d_models, (const AcrHyp*)d_hyp, (const uint32_t*)d_sorted,
                        d_state, d_best_inliers, d_index_set, d_samples, h_word);

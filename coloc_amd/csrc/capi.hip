@@ -1276,7 +1276,7 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     if (rounds) *rounds = 0;
     if (h_mask && N > 0) memset(h_mask, 0, (size_t)N);
     if (N <= m || max_iteration == 0) return CLC_OK;                       // ACRANSAC: nData <= sizeSample -> (0, 0), no model
-    if (N > kAcrMaxN) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 8192 correspondences per solve");
+    if (N > kAcrMaxN) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 16384 correspondences per solve");
     if (max_iteration > 500000) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 500000 iterations");
     if (kind == 1 && (img_w <= 0 || img_h <= 0)) return fail(ctx, CLC_ERR_BAD_ARG, "acransac: image size needed for the point-to-line model");
     CLC_HIP(ctx, hipSetDevice(ctx->device));

@@ -169,8 +169,8 @@ hipError_t launch_fivept(const double* d_x1, const double* d_x2, int N, const do
 
 // ---- a-contrario RANSAC (acransac.hip) -----------------------------------------------------------------------
 static constexpr int kAcrMaxBatch = 128;           // iterations evaluated per round
-static constexpr int kAcrMaxN = 8192;              // correspondences per solve: (8 + 4) B x 8192 = 96 KB of LDS per model slot
-static constexpr size_t kAcrMaxLds = (size_t)kAcrMaxN * 12;
+static constexpr int kAcrMaxN = 16384;             // correspondences per solve: 8 B x 16 384 = 128 KB of LDS per model slot (16 elements per thread)
+static constexpr size_t kAcrMaxLds = (size_t)kAcrMaxN * 8;
 struct AcrProblem {        // passed by value to every kernel of a solve
     int kind;              // 0: resection (P3P, [R|t] models of 12 doubles), 1: essential (five-point, {F, E} models of 18)
     int n, m, max_models, model_doubles;
@@ -193,6 +193,8 @@ struct AcrState {          // device resident; the host sees one packed 8-byte w
     int32_t rounds, last_batch;
     int32_t cur_batch;     // iterations the NEXT round evaluates (the solve / nfa kernels read it from here: rounds are enqueued
     int32_t grow;          // one ahead of the host's knowledge); grow = batch size while no event has happened (32, 64, 128)
+    int32_t rounds_eval;   // rounds that evaluated at least one iteration (`rounds` also counts the empty round enqueued ahead)
+    int32_t pad_;
 };
 struct AcrResult {
     double model[18];

@@ -377,7 +377,7 @@ int clc_mc_counts(clc_mc* mc, int* h_counts_out, void* stream);
  * (seed, iteration, index set), coloc_amd/csrc/clc_acr.h.)  Batches of iterations are evaluated per round on the GPU --
  * minimal solves, one sort + NFA scan per model in LDS, a sequential-semantics selection -- with results identical to
  * the iteration-by-iteration loop (oracle/clc_oracle_acr.c).  precision = INFINITY is the reference's setting; a finite
- * value is OpenMVG's upper bound on the inlier residual, in pixels^2.  At most 8192 correspondences per solve.
+ * value is OpenMVG's upper bound on the inlier residual, in pixels^2.  At most 16384 correspondences per solve (CLC_ERR_CAPACITY beyond: the per-model sort runs in one workgroup's LDS).
  *
  * clc_pnp_acransac: h_X N x 3, h_x N x 2 UNDISTORTED pixels, h_K 9 row-major (fx = K[0] scales residuals to the
  * normalised camera plane as ACKernelAdaptorResection_Intrinsics does).  Outputs (nullable): h_Rt 12 doubles [R|t],

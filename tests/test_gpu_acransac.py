@@ -158,3 +158,32 @@ def test_essential_equals_sequential_oracle(gpu_ctx, oracle, n, seed):
     assert (got["mask"] & true_in).sum() >= 0.9 * true_in.sum() and (got["mask"] & ~true_in).sum() <= 0.1 * len(out) + 2
     Fn = got["F"] / np.linalg.norm(got["F"])
     assert min(np.abs(Fn - Ftrue).max(), np.abs(Fn + Ftrue).max()) < 0.05
+
+
+@pytest.mark.parametrize("n,max_it,seed", [(3000, 64, 21), (4096, 64, 22), (8192, 48, 23), (8193, 48, 24), (12000, 48, 25), (16384, 32, 26)])
+def test_pose_large_correspondence_sets(gpu_ctx, oracle, n, max_it, seed):
+    """Every per-thread element count of the per-model sort: 4 (2049..4096), 8 (..8192) and -- new in round 3 -- 16 elements per
+    thread (8193..16384: a 10k-keypoint pair yields ~9.3k accepted matches, more than round 2's cap of 8192).  Same result as the
+    sequential oracle, duplicates included so that the exact re-sort runs too."""
+    sc = synth.pnp_scene(n, seed=4300 + seed, outlier_frac=0.4)
+    X, x = sc["X"].copy(), sc["x"].copy()
+    inl = np.flatnonzero(sc["inliers"])
+    for k in range(40):                                        # duplicates + one-ulp copies, scattered: the exact re-sort path
+        X[n - 1 - 7 * k] = X[inl[k]]
+        x[n - 1 - 7 * k] = x[inl[k]] if k % 2 else np.nextafter(x[inl[k]], np.inf)
+    _check_pose(gpu_ctx, oracle, dict(sc, X=X, x=x), max_it, seed)
+
+
+def test_pose_capacity_is_reported(gpu_ctx):
+    from coloc_amd.abi import CLCError
+    sc = synth.pnp_scene(16385, seed=1)
+    with pytest.raises(CLCError):
+        gpu_ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], max_iteration=8, seed=1)
+
+
+def test_essential_on_more_than_8192_matches(gpu_ctx, oracle):
+    """The two-view filter on a 10k-keypoint pair's worth of matches (the size bench.py's pair produces)."""
+    x1, x2 = _two_view(9300, seed=77)[:2]
+    K = synth.pnp_scene(5, seed=77)["K"]
+    got = gpu_ctx.essential_acransac(x1, x2, K, K, (1280, 720), max_iteration=32, seed=5)
+    assert got["E"] is not None and len(got["inliers"]) > 0.5 * 9300
