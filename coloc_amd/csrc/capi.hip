@@ -36,7 +36,9 @@ struct Profiler {
     {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e = nullptr;
-        (void)hipEventCreate(&e);
+        // timing events need no system-scope release: a default event makes the GPU write its L2 back at every record, inside
+        // the region being timed (the host never reads device data through these events, only their timestamps)
+        if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) (void)hipEventCreate(&e);
         return e;
     }
     void drain()
