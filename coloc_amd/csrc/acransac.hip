@@ -26,6 +26,40 @@
 
 namespace clc {
 
+// where the round that COMPLETES a run leaves the result (round 3: the finish work rides in that round's select launch, and the
+// host returns as soon as the polled word says "done" instead of launching a finish kernel behind the round enqueued ahead)
+struct AcrFinish {
+    uint8_t* d_mask; AcrResult* d_res;                 // device copies (the refinement reads them)
+    uint8_t* h_mask; int32_t* h_inliers; AcrResult* h_res;     // pinned host memory (nullable)
+};
+__device__ __forceinline__ void acr_finish_block(const AcrProblem& pb, const AcrState& s, const uint32_t* __restrict__ best_inliers,
+                                                 const AcrFinish& fin, const int tid, const int T)
+{
+    const bool ok = s.min_nfa < 0.0 && s.n_inliers > 0;
+    const int n_inl = ok ? s.n_inliers : 0;
+    for (int i = tid; i < pb.n; i += T) { fin.d_mask[i] = 0; if (fin.h_mask) fin.h_mask[i] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n_inl; i += T) {
+        const uint32_t p = best_inliers[i];
+        fin.d_mask[p] = 1;
+        if (fin.h_mask) fin.h_mask[p] = 1;
+        if (fin.h_inliers) fin.h_inliers[i] = (int32_t)p;
+    }
+    if (tid == 0) {
+        AcrResult r;
+        for (int e = 0; e < 18; ++e) r.model[e] = ok ? s.model[e] : 0.0;
+        r.min_nfa = s.min_nfa;
+        // unormalizeError: resection sqrt(e) / N1(0,0) -> pixels; essential: the squared pixel distance as it is
+        r.error_max = !ok ? 0.0 : (pb.kind == 0 ? sqrt(s.error_max) / pb.norm : s.error_max);
+        r.n_inliers = n_inl;
+        r.valid = ok ? s.best_iter : -1;
+        r.iterations = s.iter;
+        r.rounds = s.rounds_eval;               // not the sequence number: the round enqueued ahead of the host's knowledge is empty
+        *fin.d_res = r;
+        if (fin.h_res) *fin.h_res = r;
+    }
+}
+
 struct AcrHyp {            // per model slot, written by the nfa kernel
     double nfa;            // min_k NFA(k); +inf for an empty slot
     double e_k;            // the k-th smallest residual (kernel units)
@@ -343,7 +377,7 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
                                                          const AcrHyp* __restrict__ hyp, const uint32_t* __restrict__ sorted_idx,
                                                          AcrState* __restrict__ state, uint32_t* __restrict__ best_inliers,
                                                          uint32_t* __restrict__ index_set, int32_t* __restrict__ samples,
-                                                         unsigned long long* __restrict__ h_word)
+                                                         unsigned long long* __restrict__ h_word, const AcrFinish fin)
 {
     // The loop being replayed is sequential (strict '<' improvements in iteration / solver order, the first iteration
     // that switches the index set ends the batch), but everything in it is a prefix operation over the <= 1280 model
@@ -441,8 +475,7 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
             }
         }
         s.iter += consumed;
-        s.rounds += 1;
-        if (B > 0) s.rounds_eval += 1;
+        if (B > 0) { s.rounds += 1; s.rounds_eval += 1; }      // an empty round (enqueued ahead, after the end) is not a round
         s.last_batch = consumed;
         // next round: while nothing has happened look further ahead per round; after an event the whole reserve goes in one
         if (event_it < B || !s.index_all) s.grow = kAcrMaxBatch;
@@ -484,15 +517,25 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
             }
         }
     }
+    // A round that evaluated nothing (the one enqueued ahead of the host's knowledge, after the run has ended) touches NO host memory:
+    // the host may already be preparing the next solve in the same pinned block.
+    const bool done = B > 0 && s.iter >= s.n_iter;
+    if (done && fin.d_res) {
+        // the run ends here: the result goes out with this launch (best_inliers was written above by this workgroup)
+        __syncthreads();
+        acr_finish_block(pb, s, best_inliers, fin, tid, T);
+        __threadfence_system();                 // every thread: its stores to the pinned result have left before the word says "done"
+    }
+    __syncthreads();
     if (tid == 0) {
         *state = s;
         // what the host needs between rounds, in ONE 8-byte word it polls in pinned memory:
         // [63:49] round number, [48] index set switched, [47:40] iterations consumed, [39:20] n_iter, [19:0] iter
-        if (h_word) {
+        if (h_word && B > 0) {
             const unsigned long long w = ((unsigned long long)((uint32_t)s.rounds & 0x7FFFu) << 49) | ((unsigned long long)(s.index_all ? 0u : 1u) << 48) |
                                          ((unsigned long long)((uint32_t)s.last_batch & 0xFFu) << 40) |
                                          ((unsigned long long)((uint32_t)s.n_iter & 0xFFFFFu) << 20) | (unsigned long long)((uint32_t)s.iter & 0xFFFFFu);
-            __hip_atomic_store(h_word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(h_word, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -504,31 +547,8 @@ __global__ __launch_bounds__(256) void acr_finish_kernel(const AcrProblem pb, co
                                                          int32_t* __restrict__ h_inliers, AcrResult* __restrict__ h_res)
 {
     const AcrState s = *state;
-    const bool ok = s.min_nfa < 0.0 && s.n_inliers > 0;
-    const int n_inl = ok ? s.n_inliers : 0;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x, G = gridDim.x * blockDim.x;
-    // single workgroup: the mask is zeroed, then the inliers are marked
-    for (int i = gid; i < pb.n; i += G) { d_mask[i] = 0; if (h_mask) h_mask[i] = 0; }
-    __syncthreads();
-    for (int i = gid; i < n_inl; i += G) {
-        const uint32_t p = best_inliers[i];
-        d_mask[p] = 1;
-        if (h_mask) h_mask[p] = 1;
-        if (h_inliers) h_inliers[i] = (int32_t)p;
-    }
-    if (gid == 0) {
-        AcrResult r;
-        for (int e = 0; e < 18; ++e) r.model[e] = ok ? s.model[e] : 0.0;
-        r.min_nfa = s.min_nfa;
-        // unormalizeError: resection sqrt(e) / N1(0,0) -> pixels; essential: the squared pixel distance as it is
-        r.error_max = !ok ? 0.0 : (pb.kind == 0 ? sqrt(s.error_max) / pb.norm : s.error_max);
-        r.n_inliers = n_inl;
-        r.valid = ok ? s.best_iter : -1;
-        r.iterations = s.iter;
-        r.rounds = s.rounds_eval;               // not the sequence number: the round enqueued ahead of the host's knowledge is empty
-        *d_res = r;
-        if (h_res) *h_res = r;
-    }
+    const AcrFinish fin{ d_mask, d_res, h_mask, h_inliers, h_res };
+    acr_finish_block(pb, s, best_inliers, fin, (int)threadIdx.x, (int)blockDim.x);        // launched as ONE workgroup
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -553,9 +573,13 @@ static hipError_t acr_launch_nfa(const AcrProblem& pb, int B, int P, const doubl
 
 hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
                             uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, unsigned long long* h_word,
-                            hipStream_t stream)
+                            hipStream_t stream, int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers,
+                            AcrResult* h_res)
 {
-    const int B = kAcrMaxBatch;       // the grid; the kernels take the round's real batch from the device state
+    // the grid covers `batch_bound` iterations (an upper bound of the batch the device state will ask for, <= kAcrMaxBatch); the
+    // kernels take the round's real batch from the device state.  A tight bound matters: a slot workgroup that has nothing to do
+    // still costs its dispatch (512 workgroups of 1024 threads for a 25-iteration reserve round was a third of the nfa launch).
+    const int B = batch_bound < 1 ? 1 : (batch_bound > kAcrMaxBatch ? kAcrMaxBatch : batch_bound);
     int P = 64;
     while (P < pb.n) P <<= 1;
         hipError_t e;
@@ -567,8 +591,9 @@ hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp
     else if (P == 8192) e = acr_launch_nfa<8>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
     else e = acr_launch_nfa<16>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
     if (e != hipSuccess) return e;
+    const AcrFinish fin{ d_mask, d_res, h_mask, h_inliers, h_res };
     hipLaunchKernelGGL(acr_select_kernel, dim3(1), dim3(256), 0, stream, pb, d_models, (const AcrHyp*)d_hyp, (const uint32_t*)d_sorted,
-                       d_state, d_best_inliers, d_index_set, d_samples, h_word);
+                       d_state, d_best_inliers, d_index_set, d_samples, h_word, fin);
     return hipGetLastError();
 }
 

@@ -84,6 +84,7 @@ struct clc_ctx {
     int device = 0;
     std::vector<float> acr_lg;   // (float) log10(k), k = 0 .. : the a-contrario tables are sums over it
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream: the pose refinement behind an a-contrario run (not ordered behind the round enqueued ahead)
     std::string err;
     bool has_det = false, has_mat = false;
     clc_detector_opts dopts{};
@@ -323,6 +324,7 @@ int clc_ctx_destroy(clc_ctx* ctx)
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CLC_OK;
@@ -1379,18 +1381,25 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
     // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
     // select straight into the next round's solve while the host is still polling (a 10 us bubble per round otherwise).
-    auto enqueue_round = [&]() -> int {
+    auto enqueue_round = [&](const int bound) -> int {
         const int32_t* d_cnt = &d_state->cur_batch;
-        if (kind == 0) CLC_HIP(ctx, launch_p3p(d_a, d_b, N, d_K1, d_samples, kAcrMaxBatch, d_models, st, d_cnt));
-        else CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, kAcrMaxBatch, d_models, st, d_cnt));
-        CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st));
+        const int S = bound < 1 ? 1 : (bound > kAcrMaxBatch ? kAcrMaxBatch : bound);
+        if (kind == 0) CLC_HIP(ctx, launch_p3p(d_a, d_b, N, d_K1, d_samples, S, d_models, st, d_cnt));
+        else CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, S, d_models, st, d_cnt));
+        CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st, S, d_mask, d_res,
+                                      p_mask, p_inl, h_res));
         return CLC_OK;
     };
-    rc = enqueue_round();
+    // Upper bound of the batch a round can ask for, from what the host knows when it enqueues it (one or two rounds behind the
+    // device): while the index set has not switched the batch doubles up to kAcrMaxBatch; afterwards it is what is left of the
+    // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
+    const int reserve0 = h_init->reserve;
+    int bound = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
+    rc = enqueue_round(bound);
     if (rc != CLC_OK) return rc;
     uint32_t round = 0;
     for (;;) {
-        rc = enqueue_round();                                          // speculative: round + 2
+        rc = enqueue_round(bound);                                     // speculative: the round after the one being waited for
         if (rc != CLC_OK) return rc;
         // the select kernel publishes one packed word (round number, iterations consumed, iter, n_iter) in pinned memory:
         // poll it (a stream synchronisation costs ~10 us per round); after 2 ms without progress fall back to the
@@ -1408,15 +1417,25 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
                 }
             }
         }
-        if ((int)(w & 0xFFFFFu) >= (int)((w >> 20) & 0xFFFFFu)) break;   // iter >= n_iter: the round enqueued ahead is empty
+        const int iter_k = (int)(w & 0xFFFFFu), n_iter_k = (int)((w >> 20) & 0xFFFFFu);
+        if (iter_k >= n_iter_k) break;                                 // done: the completing round has left the result in pinned memory
+        const bool switched = ((w >> 48) & 1u) != 0;
+        const long left = (long)n_iter_k - iter_k + 4 + (switched ? 0 : reserve0);
+        bound = left > kAcrMaxBatch ? kAcrMaxBatch : (int)left;
         if (round > 0x7000u) return fail(ctx, CLC_ERR_STATE, "acransac: too many rounds");
     }
-    CLC_HIP(ctx, launch_acr_finish(pb, d_state, d_best, d_mask, d_res, p_mask, p_inl, h_res, st));
     prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);
-    if (refine)
-        CLC_HIP(ctx, launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50, d_ref, st,
-                                       &ctx->prof, &d_res->valid, p_ref));
-    CLC_HIP(ctx, hipStreamSynchronize(st));
+    // The result record, mask and inlier list were written by the round that completed the run BEFORE its word (system-scope release /
+    // acquire): no finish launch, and without refinement no stream synchronisation either -- the round enqueued ahead is still in the
+    // stream, evaluates nothing and touches no host memory; anything enqueued later on this stream is ordered behind it.
+    if (refine) {
+        // on the side stream: everything the refinement reads was written by launches that have completed (the word was seen),
+        // and the round still queued on the main stream writes only the a-contrario state and scratch the refinement does not touch
+        if (!ctx->stream2) CLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        CLC_HIP(ctx, launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50, d_ref,
+                                       ctx->stream2, &ctx->prof, &d_res->valid, p_ref));
+        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    }
     const AcrResult r = *h_res;
     if (h_model) {
         if (kind == 0) memcpy(h_model, r.model, sizeof(double) * 12);

@@ -207,9 +207,12 @@ struct AcrResult {
 struct AcrHyp;
 size_t acr_hyp_bytes();
 // nfa + select of one batch (state->cur_batch iterations) whose models are in d_models (max_models slots each)
+// batch_bound: iterations the launch grids cover (>= the batch the device state asks for); d_mask .. h_res: where the round that
+// completes the run leaves mask / inlier list / result record (device copies + pinned host mirrors)
 hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
                             uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, unsigned long long* h_word,
-                            hipStream_t stream);
+                            hipStream_t stream, int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers,
+                            AcrResult* h_res);
 hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
                              uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream);
 
