@@ -101,6 +101,9 @@ def main():
                          "clc_mc_gather_enqueue_dev + clc_mc_match_enqueue_dev (ncclAllGather, or IPC peer copies + a 4-byte fence collective); the "
                          "rendezvous id travels through torch.distributed.  Not exercised on hardware yet: no multi-GPU box in the build loop")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events)")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the informational side sections (other formulation, shares, config[2], front end, pose, two-view, host path): "
+                         "the rocprofv3 passes use it so that a kernel's average in their summaries is the average of the step's own launches")
     args = ap.parse_args()
 
     import numpy as np
@@ -626,7 +629,7 @@ def main():
                     out["gpu_over_cpu_best_effort_simd"] = out["value"] / out["cpu_baseline"]["best_effort_simd"]["value"]
 
         guarded("clatch_roofline", sec_clatch)
-        if world == 1:
+        if world == 1 and not args.headline_only:
             # the side sections belong to the one-GPU line; at N > 1 the other ranks would sit in the teardown barrier below while
             # rank 0 alone ran them for tens of seconds
             guarded("host_path", sec_host_path)
