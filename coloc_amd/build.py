@@ -41,7 +41,8 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    # CLC_EXTRA_FLAGS: extra compiler flags for experiments (e.g. "-DCLC_K2NN_AHEAD=2"); not set in any shipped build
+    cmd = [hipcc_path()] + FLAGS + os.environ.get("CLC_EXTRA_FLAGS", "").split() + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -23,8 +23,18 @@
 // (residual, index), and the same portable log10 in the NFA terms.
 #include "clc_internal.h"
 #include "clc_acr.h"
+#include "p3p.h"
 
 namespace clc {
+
+// -DCLC_ACR_STAMP (experiments only, tools/acr_stamps.py): thread 0 of slot workgroup 0 leaves s_memtime at the phase boundaries of
+// acr_round_kernel in a device array that clc_debug_acr_stamps copies out
+#if defined(CLC_ACR_STAMP)
+__device__ unsigned long long g_acr_stamp[16];
+#define ACR_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_acr_stamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ACR_STAMP(i) do { } while (0)
+#endif
 
 // where the round that COMPLETES a run leaves the result (round 3: the finish work rides in that round's select launch, and the
 // host returns as soon as the polled word says "done" instead of launching a finish kernel behind the round enqueued ahead)
@@ -114,6 +124,7 @@ __device__ __forceinline__ bool acr_gt(const uint64_t ka, const uint32_t ia, con
 // the exact-key network below re-sorts -- the result is always the exact lexicographic order.
 __device__ __forceinline__ double acr_fmin(const double a, const double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ double acr_fmax(const double a, const double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double acr_fmin_plain(const double a, const double b) { return b < a ? b : a; }
 __device__ __forceinline__ double acr_shfl_xor(const double v, const int mask)
 {
     const uint64_t u = (uint64_t)__double_as_longlong(v);
@@ -139,6 +150,49 @@ __device__ __forceinline__ uint32_t acr_lane_xor(const uint32_t v)
     if (D == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);      // row_ror:8
     return __shfl_xor(v, D);
 }
+// Wave-wide reductions and the min-scan on DPP moves only (a __shfl is an LDS-crossbar round trip, ~150-300 cycles per dependent
+// step when 16 waves share the CU: the replay's scan + three reductions and the NFA reduction were 36 such steps each).  Row steps:
+// quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror leave a row's result in all of its 16 lanes; row_bcast:15 / :31 then
+// carry row totals upwards, so lane 63 holds the wave's result (readlane).  `old` is what a lane outside the row mask keeps.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int acr_dpp(const int old, const int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double acr_dpp(const double old, const double v)
+{
+    const uint64_t o = (uint64_t)__double_as_longlong(old), u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)acr_dpp<CTRL, ROW_MASK>((int)(uint32_t)o, (int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)acr_dpp<CTRL, ROW_MASK>((int)(uint32_t)(o >> 32), (int)(uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+constexpr int kDppQuad1 = 0xB1, kDppQuad2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppBcast15 = 0x142, kDppBcast31 = 0x143,
+              kDppWaveShr1 = 0x138;
+__device__ __forceinline__ int acr_wave_min(int v)
+{
+    int o;
+    o = acr_dpp<kDppQuad1>(v, v); v = o < v ? o : v;
+    o = acr_dpp<kDppQuad2>(v, v); v = o < v ? o : v;
+    o = acr_dpp<kDppHalfMirror>(v, v); v = o < v ? o : v;
+    o = acr_dpp<kDppMirror>(v, v); v = o < v ? o : v;
+    o = acr_dpp<kDppBcast15, 0xA>(v, v); v = o < v ? o : v;
+    o = acr_dpp<kDppBcast31, 0xC>(v, v); v = o < v ? o : v;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int acr_wave_max(const int v) { return -acr_wave_min(-v); }
+// inclusive prefix minimum over the 64 lanes (row_shr:1..3, :4, :8 inside a row, then the row totals), and the exclusive one
+template <int SHR>
+__device__ __forceinline__ double acr_row_shr(const double ident, const double v) { return acr_dpp<0x110 + SHR>(ident, v); }
+__device__ __forceinline__ double acr_wave_scan_min(double v, const double ident /* +inf */, double& excl)
+{
+    const double t1 = acr_row_shr<1>(ident, v), t2 = acr_row_shr<2>(ident, v), t3 = acr_row_shr<3>(ident, v);
+    v = acr_fmin_plain(acr_fmin_plain(v, t1), acr_fmin_plain(t2, t3));
+    v = acr_fmin_plain(v, acr_row_shr<4>(ident, v));
+    v = acr_fmin_plain(v, acr_row_shr<8>(ident, v));
+    v = acr_fmin_plain(v, acr_dpp<kDppBcast15, 0xA>(ident, v));
+    v = acr_fmin_plain(v, acr_dpp<kDppBcast31, 0xC>(ident, v));
+    excl = acr_dpp<kDppWaveShr1>(ident, v);
+    return v;
+}
+
 // one in-wave compare-exchange step of the composite-key network: partner thread tid ^ DT (DT < 64), same slot
 template <int E, int DT>
 __device__ __forceinline__ void acr_step_wave(double (&c)[E], const int k, const int tid)
@@ -154,6 +208,10 @@ __device__ __forceinline__ void acr_step_wave(double (&c)[E], const int k, const
         c[e] = keep_min ? lo : hi;
     }
 }
+// (Tried: the direction of a step as a constant lane pattern in scalar registers -- two DPP moves, one 64-bit compare into a lane
+// mask, a scalar xnor, two selects on the mask: 5 vector instructions instead of 9.  With the stage a run-time value (the general
+// network) building the pattern costs more than it saves: sort of a 1 024-element slot 16.0 k -> 24.1 k cycles; with compile-time
+// stages (acr_rank_sort) 14.9 k -> 14.1 k, not worth a second form of the step.)
 
 template <int E, bool EXACT>
 __device__ __forceinline__ void acr_bitonic(uint64_t (&key)[E], uint32_t (&idx)[E], double (&c)[E], const int P, const int tid, const int T,
@@ -240,30 +298,138 @@ __device__ __forceinline__ void acr_bitonic(uint64_t (&key)[E], uint32_t (&idx)[
     }
 }
 
-template <int E>
-__global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, const int P /* = blockDim.x * E, power of two >= n */,
-                                                       const double* __restrict__ models, AcrHyp* __restrict__ hyp,
-                                                       uint32_t* __restrict__ sorted_idx, const AcrState* __restrict__ state)
+// One element per thread (P = T <= 1024): the in-wave stages of the network, then RANK MERGES instead of its cross-wave stages.
+// After stage 64 (run ascending in every wave) each wave holds a sorted run of 64; up to four runs are merged at a time by letting
+// every element find, by binary search in LDS, how many elements of each sibling run are smaller (keys are distinct: the index is
+// part of the key) -- its place in the merged run is the sum.  1 024 elements: 21 in-wave steps + 2 merges (7 and 9 dependent LDS
+// reads, three independent searches in flight, 5 workgroup barriers) instead of 21 + 24 in-wave steps and 10 cross-wave exchanges
+// with 20 barriers: the sort of a P3P slot went from 16.0 k to 14.6-15.0 k cycles (in-kernel stamps, N = 1000) -- the searches are LDS-throughput
+// bound (random 8-byte reads), which is why it is not the 2 x this count suggests.
+// (Tried: one spare word per 16 elements so that the power-of-two strides of a binary search step do not share an LDS bank: the
+// sort went from 14.6 k to 16.4 k cycles -- the merges are not conflict-bound; the index arithmetic cost more than it saved.)
+__device__ __forceinline__ int acr_lower_bound3(const uint64_t* __restrict__ lkey, const int b0, const int b1, const int b2,
+                                                const int n_runs, const int L, const uint64_t x)
 {
-    extern __shared__ unsigned char acr_lds[];
-    const int slot = blockIdx.x, tid = threadIdx.x, T = blockDim.x, n = pb.n;
-    if (slot >= state->cur_batch * pb.max_models) return;          // the grid covers the largest batch; this round is smaller
-    uint64_t* lkey = reinterpret_cast<uint64_t*>(acr_lds);               // [e][tid] staging of the cross-wave exchanges (one word per element)
+    // number of elements < x in up to three sorted runs of length L (a power of two) starting at elements b0, b1, b2, the searches
+    // interleaved
+    int p0 = 0, p1 = 0, p2 = 0;
+    for (int s = L >> 1; s > 0; s >>= 1) {
+        const uint64_t v0 = lkey[b0 + p0 + s - 1], v1 = n_runs > 1 ? lkey[b1 + p1 + s - 1] : 0, v2 = n_runs > 2 ? lkey[b2 + p2 + s - 1] : 0;
+        p0 += v0 < x ? s : 0;
+        p1 += (n_runs > 1 && v1 < x) ? s : 0;
+        p2 += (n_runs > 2 && v2 < x) ? s : 0;
+    }
+    const uint64_t v0 = lkey[b0 + p0], v1 = n_runs > 1 ? lkey[b1 + p1] : 0, v2 = n_runs > 2 ? lkey[b2 + p2] : 0;
+    p0 += v0 < x ? 1 : 0;
+    p1 += (n_runs > 1 && v1 < x) ? 1 : 0;
+    p2 += (n_runs > 2 && v2 < x) ? 1 : 0;
+    return p0 + p1 + p2;
+}
+__device__ __forceinline__ void acr_rank_sort(double& c, const int P, const int tid, const int T, uint64_t* lkey)
+{
+    double cc[1] = { c };
+    // stages 2 .. 32 of the bitonic network (direction by the element's position), stage 64 ascending everywhere
+    acr_step_wave<1, 1>(cc, 2, tid);
+    acr_step_wave<1, 2>(cc, 4, tid); acr_step_wave<1, 1>(cc, 4, tid);
+    acr_step_wave<1, 4>(cc, 8, tid); acr_step_wave<1, 2>(cc, 8, tid); acr_step_wave<1, 1>(cc, 8, tid);
+    acr_step_wave<1, 8>(cc, 16, tid); acr_step_wave<1, 4>(cc, 16, tid); acr_step_wave<1, 2>(cc, 16, tid); acr_step_wave<1, 1>(cc, 16, tid);
+    acr_step_wave<1, 16>(cc, 32, tid); acr_step_wave<1, 8>(cc, 32, tid); acr_step_wave<1, 4>(cc, 32, tid); acr_step_wave<1, 2>(cc, 32, tid);
+    acr_step_wave<1, 1>(cc, 32, tid);
+    const int up = 2048;                                                  // (tid & up) == 0 for every thread: ascending
+    acr_step_wave<1, 32>(cc, up, tid); acr_step_wave<1, 16>(cc, up, tid); acr_step_wave<1, 8>(cc, up, tid); acr_step_wave<1, 4>(cc, up, tid);
+    acr_step_wave<1, 2>(cc, up, tid); acr_step_wave<1, 1>(cc, up, tid);
+    uint64_t x = (uint64_t)__double_as_longlong(cc[0]);
+    if (T > 64) {
+        lkey[tid] = x;
+        __syncthreads();
+        for (int L = 64; L < P;) {
+            const int F = P / L < 4 ? P / L : 4, G = L * F;               // F runs of length L -> one of length G
+            const int base = tid & ~(G - 1), mine = (tid & (G - 1)) / L;  // (uniform over a wave: L >= 64)
+            const int to = base + (tid & (L - 1)) +
+                           acr_lower_bound3(lkey, base + ((mine + 1) % F) * L, base + ((mine + 2) % F) * L, base + ((mine + 3) % F) * L, F - 1, L, x);
+            __syncthreads();                                              // every search has read the runs
+            lkey[to] = x;
+            __syncthreads();
+            x = lkey[tid];
+            L = G;
+        }
+    }
+    c = __longlong_as_double((long long)x);
+}
+
+// What a thread's part of a slot needs from memory that does not depend on the model: its E correspondences and the two table
+// entries of its E positions.  acr_round_kernel loads them before anything else, so that they arrive while wave 0 is still
+// replaying the previous round and solving the sample (resection only; PRE = false: loaded where they are used).
+template <int E>
+struct AcrPre { double a[3 * E], b[2 * E]; float cn[E], ck[E]; };
+template <int E>
+__device__ __forceinline__ void acr_prefetch(const AcrProblem& pb, const int tid, AcrPre<E>& q)
+{
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = tid * E + e < pb.n ? tid * E + e : 0, kk = tid * E + e + 1 <= pb.n ? tid * E + e + 1 : 0;
+        q.a[3 * e] = pb.a[3 * i]; q.a[3 * e + 1] = pb.a[3 * i + 1]; q.a[3 * e + 2] = pb.a[3 * i + 2];
+        q.b[2 * e] = pb.b[2 * i]; q.b[2 * e + 1] = pb.b[2 * i + 1];
+        q.cn[e] = pb.logc_n[kk]; q.ck[e] = pb.logc_k[kk];
+    }
+}
+
+// (NFA, its residual, its k) -- lexicographic minimum on (NFA, k) -- and a count that is summed: kept as four scalars, not a struct
+// (the compiler turns selects between two structs into selects between their stack addresses and the structs stay in scratch)
+__device__ __forceinline__ void acr_best_merge(double& v, double& e, int& k, int& cnt, const double ov, const double oe, const int ok, const int oc)
+{
+    const bool take = ov < v || (ov == v && ok < k);
+    v = take ? ov : v; e = take ? oe : e; k = take ? ok : k;
+    cnt += oc;
+}
+template <int CTRL>
+__device__ __forceinline__ void acr_best_step(double& v, double& e, int& k, int& cnt)
+{
+    const double ov = acr_dpp<CTRL>(v, v), oe = acr_dpp<CTRL>(e, e);
+    const int ok = acr_dpp<CTRL>(k, k), oc = acr_dpp<CTRL>(cnt, cnt);
+    acr_best_merge(v, e, k, cnt, ov, oe, ok, oc);
+}
+__device__ __forceinline__ void acr_best_rows(double& v, double& e, int& k, int& cnt)     // every lane of a 16-lane row ends up with the row's result
+{
+    acr_best_step<kDppQuad1>(v, e, k, cnt);
+    acr_best_step<kDppQuad2>(v, e, k, cnt);
+    acr_best_step<kDppHalfMirror>(v, e, k, cnt);
+    acr_best_step<kDppMirror>(v, e, k, cnt);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void acr_best_bcast(double& v, double& e, int& k, int& cnt)    // rows outside the mask merge with (themselves, 0)
+{
+    const double ov = acr_dpp<CTRL, ROW_MASK>(v, v), oe = acr_dpp<CTRL, ROW_MASK>(e, e);
+    const int ok = acr_dpp<CTRL, ROW_MASK>(k, k), oc = acr_dpp<CTRL, ROW_MASK>(0, cnt);
+    acr_best_merge(v, e, k, cnt, ov, oe, ok, oc);
+}
+
+// One model slot, one workgroup of T threads: `model` (global memory or LDS) -> *hyp_slot and the sorted index list out_idx[0..n).
+template <int E, bool PRE = false>
+__device__ __forceinline__ void acr_nfa_body(const AcrProblem& pb, const int P /* = T * E, power of two >= n */, const double* model,
+                                             AcrHyp* __restrict__ hyp_slot, uint32_t* __restrict__ out_idx, const int tid, const int T,
+                                             uint64_t* lkey /* [e][tid] staging of the cross-wave exchanges (one word per element) */,
+                                             const AcrPre<PRE ? E : 1>* pre = nullptr)
+{
+    // E <= 8: the exact residual bits stay in a second LDS array [P] indexed by element, so that after the sort an element's exact
+    // key is one LDS read instead of a gather of its correspondence + the residual arithmetic again (2.3 -> ~0.5 us of the launch)
+    constexpr bool kKeep = E <= 8;
+    uint64_t* lres = lkey + (T > 64 ? P : 0);
+    const int n = pb.n;
     uint32_t* lidx = nullptr;
     __shared__ double s_nfa[1024 / 64], s_ek[1024 / 64];
     __shared__ int s_k[1024 / 64], s_cnt[1024 / 64];
     __shared__ uint64_t s_edge_key[1024 / 64];
     __shared__ uint32_t s_edge_idx[1024 / 64];
-    const double* model = models + (size_t)slot * pb.model_doubles;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
     // an empty slot (the solver marks it with NaNs) never improves anything
     if (model[0] != model[0]) {
-        if (tid == 0) { hyp[slot].nfa = inf; hyp[slot].e_k = 0.0; hyp[slot].k = 0; hyp[slot].n_le = 0; }
+        if (tid == 0) { hyp_slot->nfa = inf; hyp_slot->e_k = 0.0; hyp_slot->k = 0; hyp_slot->n_le = 0; }
         return;
     }
     auto residual = [&](const int i) -> double {
         return pb.kind == 0
-            ? acr_err_resection(model, pb.K1, pb.norm, pb.a[3 * i], pb.a[3 * i + 1], pb.a[3 * i + 2], pb.b[2 * i], pb.b[2 * i + 1])
+            ? acr_err_resection(model, pb.K1v, pb.norm, pb.a[3 * i], pb.a[3 * i + 1], pb.a[3 * i + 2], pb.b[2 * i], pb.b[2 * i + 1])
             : acr_err_epipolar(model, pb.a[2 * i], pb.a[2 * i + 1], pb.b[2 * i], pb.b[2 * i + 1]);
     };
     uint64_t key[E];
@@ -278,19 +444,26 @@ __global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, cons
         const int i = tid * E + e;
         uint64_t bits = kMaxFinite;                                       // padding (and inf / NaN residuals) sort behind every finite one
         if (i < n) {
-            const double r = residual(i);
+            double r;
+            if constexpr (PRE) r = acr_err_resection(model, pb.K1v, pb.norm, pre->a[3 * e], pre->a[3 * e + 1], pre->a[3 * e + 2], pre->b[2 * e], pre->b[2 * e + 1]);
+            else r = residual(i);
             cnt += r <= pb.max_threshold ? 1 : 0;
             const uint64_t rb = (uint64_t)__double_as_longlong(r);
             bits = rb < kMaxFinite ? rb : kMaxFinite;
+            if (kKeep) lres[i] = rb;
         }
         c[e] = __longlong_as_double((long long)((bits & ~kIdxMask) | (uint64_t)i));
     }
-    acr_bitonic<E, false>(key, idx, c, P, tid, T, lkey, lidx);
+    ACR_STAMP(6);
+    if constexpr (E == 1) acr_rank_sort(c[0], P, tid, T, lkey);
+    else acr_bitonic<E, false>(key, idx, c, P, tid, T, lkey, lidx);
+    ACR_STAMP(7);
     // exact keys of the elements as they stand now, then the neighbour check
+    if (kKeep && T > 64) __syncthreads();                                 // (every thread's lres entry is written)
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const uint32_t i = (uint32_t)((uint64_t)__double_as_longlong(c[e]) & kIdxMask);
-        if ((int)i < n) { idx[e] = i; key[e] = (uint64_t)__double_as_longlong(residual((int)i)); }
+        if ((int)i < n) { idx[e] = i; key[e] = kKeep ? lres[i] : (uint64_t)__double_as_longlong(residual((int)i)); }
         else { idx[e] = 0xFFFFFFFFu; key[e] = 0x7ff0000000000000ull; }   // padding: +inf, index above every real one
     }
     bool bad = false;
@@ -311,11 +484,11 @@ __global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, cons
         bad = bad || acr_gt(key[E - 1], idx[E - 1], nk, ni);
     }
     if (__syncthreads_or(bad ? 1 : 0)) acr_bitonic<E, true>(key, idx, c, P, tid, T, lkey, lidx);
+    ACR_STAMP(8);
     // NFA(k) of this thread's own positions k = tid E + e + 1, for m + 1 <= k <= n and e_(k) <= max_threshold; strict '<'
     // keeps the first k
     double best = inf, bek = 0.0;
     int bk = pb.m;
-    uint32_t* out_idx = sorted_idx + (size_t)slot * n;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int kk = tid * E + e + 1;
@@ -323,184 +496,274 @@ __global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, cons
         if (kk > pb.m && kk <= n) {
             const double r = __longlong_as_double((long long)key[e]);
             if (r <= pb.max_threshold) {
-                const double v = clc_acr_nfa(pb.loge0, pb.logalpha0, pb.mult, r, kk, pb.m, pb.logc_n[kk], pb.logc_k[kk]);
+                float cn, ck;
+                if constexpr (PRE) { cn = pre->cn[e]; ck = pre->ck[e]; }
+                else { cn = pb.logc_n[kk]; ck = pb.logc_k[kk]; }
+                const double v = clc_acr_nfa(pb.loge0, pb.logalpha0, pb.mult, r, kk, pb.m, cn, ck);
                 if (v < best) { best = v; bk = kk; bek = r; }
             }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(best, off), oe = __shfl_xor(bek, off);
-        const int ok = __shfl_xor(bk, off);
-        if (ov < best || (ov == best && ok < bk)) { best = ov; bk = ok; bek = oe; }
-        cnt += __shfl_xor(cnt, off);
-    }
-    if ((tid & 63) == 0) { s_nfa[tid >> 6] = best; s_k[tid >> 6] = bk; s_ek[tid >> 6] = bek; s_cnt[tid >> 6] = cnt; }
+    ACR_STAMP(13);
+    // lexicographic minimum of (NFA, k) and the sum of cnt: over the wave on DPP moves (result in lane 63), across the waves through
+    // LDS, where the first row of wave 0 reduces the <= 16 wave results the same way
+    acr_best_rows(best, bek, bk, cnt);
+    acr_best_bcast<kDppBcast15, 0xA>(best, bek, bk, cnt);
+    acr_best_bcast<kDppBcast31, 0xC>(best, bek, bk, cnt);
+    ACR_STAMP(14);
+    if ((tid & 63) == 63) { s_nfa[tid >> 6] = best; s_k[tid >> 6] = bk; s_ek[tid >> 6] = bek; s_cnt[tid >> 6] = cnt; }
     __syncthreads();
-    if (tid == 0) {
-        int total = 0;
-        best = inf; bk = pb.m; bek = 0.0;
-        for (int w = 0; w < (T + 63) / 64; ++w) {
-            if (s_nfa[w] < best || (s_nfa[w] == best && s_k[w] < bk)) { best = s_nfa[w]; bk = s_k[w]; bek = s_ek[w]; }
-            total += s_cnt[w];
+    ACR_STAMP(15);
+    if (tid < 16) {
+        const bool have = tid < (T + 63) / 64;
+        double wv = have ? s_nfa[tid] : inf, we = have ? s_ek[tid] : 0.0;
+        int wk = have ? s_k[tid] : 0x7fffffff, wc = have ? s_cnt[tid] : 0;
+        acr_best_rows(wv, we, wk, wc);
+        if (tid == 0) {
+            hyp_slot->nfa = wv;
+            hyp_slot->k = wk;
+            hyp_slot->e_k = we;
+            hyp_slot->n_le = wc;
         }
-        hyp[slot].nfa = best;
-        hyp[slot].k = bk;
-        hyp[slot].e_k = bek;
-        hyp[slot].n_le = total;
     }
+    ACR_STAMP(9);
+}
+
+// models from memory (the five-point path: fivept_kernel has written them)
+template <int E>
+__global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, const int P, const double* __restrict__ models,
+                                                       AcrHyp* __restrict__ hyp, uint32_t* __restrict__ sorted_idx,
+                                                       const AcrState* __restrict__ state)
+{
+    extern __shared__ unsigned char acr_lds[];
+    const int slot = blockIdx.x;
+    if (slot >= state->cur_batch * pb.max_models) return;          // the grid covers the largest batch; this round is smaller
+    acr_nfa_body<E>(pb, P, models + (size_t)slot * pb.model_doubles, hyp + slot, sorted_idx + (size_t)slot * pb.n, (int)threadIdx.x,
+                    (int)blockDim.x, reinterpret_cast<uint64_t*>(acr_lds));
 }
 
 // ---- select: the sequential semantics over one batch -------------------------------------------------------------
-// block-wide reductions of one int / the inclusive min-scan of one double over 256 threads: wave shuffles + one LDS hop
-__device__ __forceinline__ int acr_block_reduce(int v, const bool take_min, int* s_red, const int tid)
+// The loop being replayed is sequential (strict '<' improvements in iteration / solver order, the first iteration that
+// switches the index set ends the batch), but everything in it is a prefix operation over the <= 1280 model slots: the
+// running minimum is a prefix min, "improved" compares a slot with the prefix before it, the batch ends at the FIRST
+// iteration whose condition holds.  ONE WAVE does it, two iterations (2 M consecutive slots) per lane: a lane-local
+// pass, one min-scan and three reductions across the 64 lanes -- no LDS, no workgroup barrier, so that every workgroup
+// of acr_round_kernel can afford to redo it for itself (below).
+struct AcrCore {           // AcrState without the model: what the replay reads and updates (registers, uniform over the wave)
+    double min_nfa, error_max;
+    int32_t n_inliers, best_iter, iter, n_iter, reserve, n_index, index_all, ac_mode, rounds, last_batch, cur_batch, grow, rounds_eval, evaluated;
+};
+struct AcrPick {           // what the replay of one batch leaves besides the updated state
+    int32_t best_h;        // slot of the model the sequential loop ends up with, -1: no improvement in this batch
+    int32_t copy_index;    // the index set becomes the inliers of the current best model
+    int32_t batch;         // iterations the replayed round had evaluated (0: nothing to replay)
+};
+__device__ __forceinline__ AcrCore acr_core_load(const AcrState* __restrict__ st)
 {
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = take_min ? (o < v ? o : v) : (o > v ? o : v); }
-    __syncthreads();                                               // s_red may still be read from the previous call
-    if ((tid & 63) == 0) s_red[tid >> 6] = v;
-    __syncthreads();
-    int r = s_red[0];
-    for (int w = 1; w < 4; ++w) r = take_min ? (s_red[w] < r ? s_red[w] : r) : (s_red[w] > r ? s_red[w] : r);
-    return r;
+    AcrCore c;
+    c.min_nfa = st->min_nfa; c.error_max = st->error_max; c.n_inliers = st->n_inliers; c.best_iter = st->best_iter; c.iter = st->iter;
+    c.n_iter = st->n_iter; c.reserve = st->reserve; c.n_index = st->n_index; c.index_all = st->index_all; c.ac_mode = st->ac_mode;
+    c.rounds = st->rounds; c.last_batch = st->last_batch; c.cur_batch = st->cur_batch; c.grow = st->grow; c.rounds_eval = st->rounds_eval;
+    c.evaluated = st->evaluated;
+    return c;
 }
-__device__ __forceinline__ double acr_block_scan_min(double v, double* s_part, const int tid)
+__device__ __forceinline__ void acr_core_store(AcrState& st, const AcrCore& c)
 {
-    const int lane = tid & 63;
-    for (int off = 1; off < 64; off <<= 1) { const double o = __shfl_up(v, off); if (lane >= off && o < v) v = o; }
-    __syncthreads();
-    if (lane == 63) s_part[tid >> 6] = v;
-    __syncthreads();
-    for (int w = 0; w < (tid >> 6); ++w) v = s_part[w] < v ? s_part[w] : v;
-    return v;                                                       // inclusive prefix minimum over threads 0..tid
+    st.min_nfa = c.min_nfa; st.error_max = c.error_max; st.n_inliers = c.n_inliers; st.best_iter = c.best_iter; st.iter = c.iter;
+    st.n_iter = c.n_iter; st.reserve = c.reserve; st.n_index = c.n_index; st.index_all = c.index_all; st.ac_mode = c.ac_mode;
+    st.rounds = c.rounds; st.last_batch = c.last_batch; st.cur_batch = c.cur_batch; st.grow = c.grow; st.rounds_eval = c.rounds_eval;
+    st.evaluated = c.evaluated;
 }
 
+__device__ __forceinline__ double acr_readlane(const double v, const int lane /* uniform */)
+{
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)u, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(u >> 32), lane);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// s: the state the batch was drawn from (in) -> the state after it (out); hyp: the batch's slots.  Called by one full wave.
+template <int M>
+__device__ __forceinline__ AcrPick acr_select_wave(const AcrProblem& pb, AcrCore& s, const AcrHyp* __restrict__ hyp, const int lane)
+{
+    static_assert(kAcrMaxBatch == 128, "two iterations per lane");
+    constexpr int C = 2 * M;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    const int B = s.cur_batch, total = B * M, h0 = lane * C;
+    // the one memory round trip: this lane's slots, whole records (k and e_k of the winner come out of registers)
+    double val[C], ek[C];
+    int nle[C], kk[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        // (addresses do not depend on the state: both loads are in flight together; the slot array always has 128 M records)
+        const bool in = h0 + c < total;
+        const AcrHyp* hp = hyp + h0 + c;
+        const double v = hp->nfa;
+        const int nl = hp->n_le;
+        ek[c] = hp->e_k;
+        kk[c] = hp->k;
+        val[c] = in ? v : inf;
+        nle[c] = in ? nl : 0;
+    }
+#if defined(CLC_ACR_STAMP)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ACR_STAMP(11);
+#endif
+    // 1. upper-bound mode gate: slots before the first model with more than 2.5 m residuals under the bound are ignored
+    int first_on = 0;
+    if (!s.ac_mode) {
+        int first_gate = 0x7fffffff;
+#pragma unroll
+        for (int c = C - 1; c >= 0; --c) if ((double)nle[c] > 2.5 * (double)pb.m && h0 + c < total) first_gate = h0 + c;
+        first_on = acr_wave_min(first_gate);
+    }
+    // 2. prefix minimum of the slot values, seeded with the minimum of the previous rounds
+    double lm = inf;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (h0 + c < first_on) val[c] = inf;
+        lm = val[c] < lm ? val[c] : lm;
+    }
+    double run;                                                     // minimum over the lanes before this one
+    acr_wave_scan_min(lm, inf, run);
+    run = s.min_nfa < run ? s.min_nfa : run;
+    bool imp[C];
+    double pre_last[2];                                            // prefix min INCLUDING the last slot of each of the lane's iterations
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        imp[c] = h0 + c < total && val[c] < run;                   // strict: an equal value does not replace the earlier model
+        run = val[c] < run ? val[c] : run;
+        if (c % M == M - 1) pre_last[c / M] = run;
+    }
+    // 3. the first iteration that ends the batch
+    int ev = B;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int it = lane * 2 + j;
+        bool better = false;
+#pragma unroll
+        for (int k = 0; k < M; ++k) better = better || imp[j * M + k];
+        const int cur = s.iter + it;
+        if (it < B && ((better && pre_last[j] < 0.0) || (cur + 1 == s.n_iter && s.reserve)) && it < ev) ev = it;
+    }
+    const int event_it = acr_wave_min(ev), consumed = event_it < B ? event_it + 1 : B;
+    // 4. the last improvement among the consumed slots is the model the sequential loop ends up with
+    int last_imp = -1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) if (h0 + c < consumed * M && imp[c]) last_imp = h0 + c;
+    const int best_h = acr_wave_max(last_imp);
+    ACR_STAMP(12);
+    AcrPick pick;
+    pick.best_h = best_h;
+    pick.copy_index = 0;
+    pick.batch = B;
+    if (!s.ac_mode && first_on < consumed * M) s.ac_mode = 1;
+    if (best_h >= 0) {
+        const int owner = best_h / C, cb = best_h % C;
+        double v = val[0], e = ek[0];
+        int k = kk[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) if (c == cb) { v = val[c]; e = ek[c]; k = kk[c]; }
+        s.min_nfa = acr_readlane(v, owner);
+        s.error_max = acr_readlane(e, owner);
+        s.n_inliers = __builtin_amdgcn_readlane(k, owner);
+        s.best_iter = s.iter + best_h / M;
+    }
+    if (event_it < B) {
+        const int cur = s.iter + event_it;
+        if (s.n_inliers == 0) { s.n_iter++; s.reserve--; }
+        else {
+            pick.copy_index = 1;
+            s.n_index = s.n_inliers;
+            s.index_all = 0;
+            if (s.reserve) { s.n_iter = cur + 1 + s.reserve; s.reserve = 0; }
+        }
+    }
+    s.iter += consumed;
+    if (B > 0) { s.rounds += 1; s.rounds_eval += 1; }            // a launch that found nothing to replay is not a round
+    s.last_batch = consumed;
+    // next round: while nothing has happened look further ahead per round; after an event the whole reserve goes in one
+    if (event_it < B || !s.index_all) s.grow = kAcrMaxBatch;
+    else s.grow = s.grow * 2 > kAcrMaxBatch ? kAcrMaxBatch : s.grow * 2;
+    const int remaining = s.n_iter - s.iter;
+    s.cur_batch = remaining < s.grow ? (remaining > 0 ? remaining : 0) : s.grow;
+    return pick;
+}
+
+// the list the NEXT batch's sample positions map through, as the index set stands after the replay: read from where it
+// came from, not from the copy the keeper is writing at the same time (nullptr: positions are indices)
+__device__ __forceinline__ const uint32_t* acr_sample_source(const AcrCore& s, const AcrPick& pick, const uint32_t* win,
+                                                             const uint32_t* best_inliers, const uint32_t* index_set)
+{
+    return s.index_all ? nullptr : (pick.copy_index ? (win ? win : best_inliers) : index_set);
+}
+
+// The side effects of a replayed batch, by ONE workgroup (all T threads): winner's sorted index list -> best_inliers and (on a switch)
+// the index set, the model, the state record, the word the host polls -- and, when the run ends here, mask / inlier list / result
+// record (system-scope fence before the word).  A launch that replayed nothing (batch == 0) only carries the state forward and
+// touches NO host memory: the host may already be preparing the next solve in the same pinned block.
+__device__ __forceinline__ void acr_keep(const AcrProblem& pb, const AcrCore& c, const AcrPick& pick, const double* __restrict__ models,
+                                         const uint32_t* __restrict__ sorted_idx, const AcrState* st_in, AcrState* st_out,
+                                         uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
+                                         unsigned long long* __restrict__ h_word, const AcrFinish& fin, AcrState& s_full /* LDS */,
+                                         const int tid, const int T)
+{
+    const int best_h = pick.best_h, n_inl = c.n_inliers;
+    if (tid < 18) s_full.model[tid] = best_h >= 0 && tid < pb.model_doubles ? models[(size_t)best_h * pb.model_doubles + tid] : st_in->model[tid];
+    if (tid == 0) acr_core_store(s_full, c);
+    const uint32_t* win = best_h >= 0 ? sorted_idx + (size_t)best_h * pb.n : nullptr;
+    if (win)
+        for (int i = tid; i < n_inl; i += T) {
+            const uint32_t v = win[i];
+            best_inliers[i] = v;
+            if (pick.copy_index) index_set[i] = v;
+        }
+    else if (pick.copy_index)                           // vec_index = vec_inliers of a model found in an earlier round
+        for (int i = tid; i < n_inl; i += T) index_set[i] = best_inliers[i];
+    __syncthreads();                                    // s_full is whole, best_inliers is written
+    const bool done = pick.batch > 0 && c.iter >= c.n_iter;
+    if (done && fin.d_res) {
+        // the run ends here: the result goes out with this launch
+        acr_finish_block(pb, s_full, best_inliers, fin, tid, T);
+        __threadfence_system();                 // every thread: its stores to the pinned result have left before the word says "done"
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *st_out = s_full;
+        // what the host needs between rounds, in ONE 8-byte word it polls in pinned memory:
+        // [63:49] round number, [48] index set switched, [47:40] iterations consumed, [39:20] n_iter, [19:0] iter
+        if (h_word && pick.batch > 0) {
+            const unsigned long long w = ((unsigned long long)((uint32_t)c.rounds & 0x7FFFu) << 49) | ((unsigned long long)(c.index_all ? 0u : 1u) << 48) |
+                                         ((unsigned long long)((uint32_t)c.last_batch & 0xFFu) << 40) |
+                                         ((unsigned long long)((uint32_t)c.n_iter & 0xFFFFFu) << 20) | (unsigned long long)((uint32_t)c.iter & 0xFFFFFu);
+            __hip_atomic_store(h_word, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// select as a launch of its own (the five-point path: fivept_kernel -> acr_nfa_kernel -> this): replay, side effects, and the
+// samples of the next batch for the solver launch that follows
 __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, const double* __restrict__ models,
                                                          const AcrHyp* __restrict__ hyp, const uint32_t* __restrict__ sorted_idx,
                                                          AcrState* __restrict__ state, uint32_t* __restrict__ best_inliers,
                                                          uint32_t* __restrict__ index_set, int32_t* __restrict__ samples,
                                                          unsigned long long* __restrict__ h_word, const AcrFinish fin)
 {
-    // The loop being replayed is sequential (strict '<' improvements in iteration / solver order, the first iteration
-    // that switches the index set ends the batch), but everything in it is a prefix operation over the <= 1280 model
-    // slots: the running minimum is a prefix min, "improved" compares a slot with the prefix before it, the batch ends
-    // at the FIRST iteration whose condition holds.  One workgroup; the kernel is a chain of dependent memory round
-    // trips, so it is written to have as few of them as possible: (state + slots) -> (winner's index list) -> stores.
-    constexpr int kMaxSlots = kAcrMaxBatch * 10;
     constexpr int T = 256;
-    constexpr int kPer = (kMaxSlots + T - 1) / T;
-    __shared__ AcrState s;
-    __shared__ double s_pre[kMaxSlots];                            // prefix min INCLUDING the slot
-    __shared__ unsigned char s_imp[kMaxSlots];
-    __shared__ double s_part[4];
-    __shared__ int s_red[4];
-    __shared__ int s_best_h, s_copy_index;
+    __shared__ AcrCore s_core;
+    __shared__ AcrPick s_pick;
+    __shared__ AcrState s_full;
     const int tid = threadIdx.x;
-    const double inf = __longlong_as_double(0x7ff0000000000000LL);
-    // round trip 1: the state and this thread's slots (loaded for the largest batch; masked below)
-    const int cur_batch = state->cur_batch, ac_mode0 = state->ac_mode, iter0 = state->iter, n_iter0 = state->n_iter, reserve0 = state->reserve;
-    const double min0 = state->min_nfa;
-    const int B = cur_batch, total = B * pb.max_models;
-    const int C = (total + T - 1) / T, h0 = tid * C;
-    double val[kPer];
-    int nle[kPer];
-#pragma unroll
-    for (int c = 0; c < kPer; ++c) {
-        const int h = h0 + c;
-        const bool in = c < C && h < total;
-        val[c] = in ? hyp[h].nfa : inf;
-        nle[c] = in ? hyp[h].n_le : 0;
-    }
-    if (tid == 0) s = *state;
-    // 1. upper-bound mode gate: slots before the first model with more than 2.5 m residuals under the bound are ignored
-    int first_gate = kMaxSlots;
-#pragma unroll
-    for (int c = kPer - 1; c >= 0; --c) if ((double)nle[c] > 2.5 * (double)pb.m && h0 + c < total) first_gate = h0 + c;
-    const int first_on = ac_mode0 ? 0 : acr_block_reduce(first_gate, true, s_red, tid);
-    // 2. prefix minimum of the slot values, seeded with the minimum of the previous rounds
-    double lm = inf;
-#pragma unroll
-    for (int c = 0; c < kPer; ++c) {
-        if (h0 + c < first_on) val[c] = inf;
-        lm = val[c] < lm ? val[c] : lm;
-    }
-    const double incl = acr_block_scan_min(lm, s_part, tid);
-    double run = __shfl_up(incl, 1);
-    if ((tid & 63) == 0) run = tid == 0 ? inf : inf;               // previous wave's total comes through s_part below
-    if ((tid & 63) == 0 && tid > 0) { run = inf; for (int w = 0; w < (tid >> 6); ++w) run = s_part[w] < run ? s_part[w] : run; }
-    run = min0 < run ? min0 : run;
-#pragma unroll
-    for (int c = 0; c < kPer; ++c) {
-        const int h = h0 + c;
-        if (c < C && h < total) {
-            s_imp[h] = val[c] < run ? 1 : 0;                       // strict: an equal value does not replace the earlier model
-            run = val[c] < run ? val[c] : run;
-            s_pre[h] = run;
-        }
+    if (tid < 64) {
+        AcrCore c = acr_core_load(state);
+        const AcrPick pick = pb.max_models == 4 ? acr_select_wave<4>(pb, c, hyp, tid) : acr_select_wave<10>(pb, c, hyp, tid);
+        if (tid == 0) { s_core = c; s_pick = pick; }
     }
     __syncthreads();
-    // 3. the first iteration that ends the batch
-    int ev = B;
-    for (int it = tid; it < B; it += T) {
-        bool better = false;
-        for (int k = 0; k < pb.max_models; ++k) better = better || s_imp[it * pb.max_models + k];
-        const double min_after = s_pre[it * pb.max_models + pb.max_models - 1];
-        const int cur = iter0 + it;
-        if (((better && min_after < 0.0) || (cur + 1 == n_iter0 && reserve0)) && it < ev) ev = it;
-    }
-    const int event_it = acr_block_reduce(ev, true, s_red, tid), consumed = event_it < B ? event_it + 1 : B;
-    // 4. the last improvement among the consumed slots is the model the sequential loop ends up with
-    int last_imp = -1;
-#pragma unroll
-    for (int c = 0; c < kPer; ++c) { const int h = h0 + c; if (c < C && h < consumed * pb.max_models && s_imp[h]) last_imp = h; }
-    const int best_red = acr_block_reduce(last_imp, false, s_red, tid);
-    if (tid == 0) {
-        const int best_h = best_red;
-        int copy_index = 0;
-        if (!s.ac_mode && first_on < consumed * pb.max_models) s.ac_mode = 1;
-        if (best_h >= 0) {
-            const AcrHyp hy = hyp[best_h];
-            s.min_nfa = hy.nfa;
-            s.n_inliers = hy.k;
-            s.error_max = hy.e_k;
-            s.best_iter = s.iter + best_h / pb.max_models;
-            for (int e = 0; e < pb.model_doubles; ++e) s.model[e] = models[(size_t)best_h * pb.model_doubles + e];
-        }
-        if (event_it < B) {
-            const int cur = s.iter + event_it;
-            if (s.n_inliers == 0) { s.n_iter++; s.reserve--; }
-            else {
-                copy_index = 1;
-                s.n_index = s.n_inliers;
-                s.index_all = 0;
-                if (s.reserve) { s.n_iter = cur + 1 + s.reserve; s.reserve = 0; }
-            }
-        }
-        s.iter += consumed;
-        if (B > 0) { s.rounds += 1; s.rounds_eval += 1; }      // an empty round (enqueued ahead, after the end) is not a round
-        s.last_batch = consumed;
-        // next round: while nothing has happened look further ahead per round; after an event the whole reserve goes in one
-        if (event_it < B || !s.index_all) s.grow = kAcrMaxBatch;
-        else s.grow = s.grow * 2 > kAcrMaxBatch ? kAcrMaxBatch : s.grow * 2;
-        const int remaining = s.n_iter - s.iter;
-        s.cur_batch = remaining < s.grow ? (remaining > 0 ? remaining : 0) : s.grow;
-        s_best_h = best_h;
-        s_copy_index = copy_index;
-    }
-    __syncthreads();
-    // round trip 2: the winner's sorted index list feeds best_inliers, (on a switch) the index set, and the next samples
-    const int best_h = s_best_h, n_inl = s.n_inliers, copy_index = s_copy_index;
-    const uint32_t* win = best_h >= 0 ? sorted_idx + (size_t)best_h * pb.n : nullptr;
-    if (win)
-        for (int i = tid; i < n_inl; i += T) {
-            const uint32_t v = win[i];
-            best_inliers[i] = v;
-            if (copy_index) index_set[i] = v;
-        }
-    else if (copy_index)                                // vec_index = vec_inliers of a model found in an earlier round
-        for (int i = tid; i < n_inl; i += T) index_set[i] = best_inliers[i];
-    // the samples of the next round, from the index set as it now stands: positions map through the list just chosen
-    // (read from where it came from, not from the copy being written)
+    const AcrCore s = s_core;
+    const AcrPick pick = s_pick;
     {
-        const uint32_t* src = s.index_all ? nullptr : (copy_index ? (win ? win : best_inliers) : index_set);
+        const uint32_t* win = pick.best_h >= 0 ? sorted_idx + (size_t)pick.best_h * pb.n : nullptr;
+        const uint32_t* src = acr_sample_source(s, pick, win, best_inliers, index_set);
         const int remaining = s.n_iter - s.iter;
         const int nb = remaining < kAcrMaxBatch ? remaining : kAcrMaxBatch;
         for (int it = tid; it < nb; it += T) {
@@ -517,27 +780,93 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
             }
         }
     }
-    // A round that evaluated nothing (the one enqueued ahead of the host's knowledge, after the run has ended) touches NO host memory:
-    // the host may already be preparing the next solve in the same pinned block.
-    const bool done = B > 0 && s.iter >= s.n_iter;
-    if (done && fin.d_res) {
-        // the run ends here: the result goes out with this launch (best_inliers was written above by this workgroup)
-        __syncthreads();
-        acr_finish_block(pb, s, best_inliers, fin, tid, T);
-        __threadfence_system();                 // every thread: its stores to the pinned result have left before the word says "done"
+    acr_keep(pb, s, pick, models, sorted_idx, state, state, best_inliers, index_set, h_word, fin, s_full, tid, T);
+}
+
+// ---- the resection round in ONE launch ------------------------------------------------------------------------------
+// A P3P round used to be three dependent launches (solve 5.8 us, nfa 15 us, select 7.7 us in the kernel trace) of which ~4.4 us
+// EACH is the launch boundary itself (an empty launch in the same chain measures 4.0-4.5 us): 13 of a round's 28 us.  Here a round
+// is one launch, and no workgroup waits for another inside it:
+//   * every workgroup first REPLAYS THE PREVIOUS ROUND for itself (acr_select_wave on wave 0: deterministic, ~1 memory round trip,
+//     the inputs are the previous launch's outputs) -- that tells it this round's batch, iteration numbers and index set;
+//   * slot workgroup (it, root): draws the sample of iteration `it`, solves root `root` of its P3P problem (the shared, not-inlined
+//     p3p_sample_root: same bits as p3p_kernel), then residuals / sort / NFA as before;
+//   * the last workgroup of the grid is the KEEPER: it alone applies the previous round's side effects (acr_keep).
+// Everything a launch writes that a workgroup of the SAME launch might still read lives in two copies indexed by launch parity
+// (state, slots, sorted lists, models); best_inliers / index_set are written by the keeper only in the cases in which the slot
+// workgroups read the other list (acr_sample_source).  The word of round r therefore comes out of launch r + 1 -- early in it, so
+// the host has launch r + 2 enqueued long before r + 1 ends, and the launch that reports "done" is the last one in the stream.
+template <int E>
+__global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
+                                                         const int par, const int P /* = blockDim.x * E */, const AcrProblem pb,
+                                                         uint32_t* __restrict__ sorted /* [2][slots * n] */,
+                                                         double* __restrict__ models /* [2][slots * 12] */,
+                                                         uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
+                                                         unsigned long long* __restrict__ h_word, const AcrFinish fin)
+{
+    extern __shared__ unsigned char acr_lds[];
+    constexpr int kSlots = kAcrMaxBatch * 4;
+    __shared__ AcrCore s_core;
+    __shared__ AcrPick s_pick;
+    __shared__ AcrState s_full;
+    __shared__ double s_model[12];
+    const int tid = threadIdx.x, T = blockDim.x, slot = blockIdx.x;
+    const bool keeper = blockIdx.x == gridDim.x - 1;
+#if defined(CLC_ACR_STAMP)
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    unsigned long long t_replay = 0;
+#endif
+    constexpr bool kPre = E <= 2;                                   // (more elements per thread: the registers are worth more than the latency)
+    AcrPre<kPre ? E : 1> pre;
+    if (kPre && !keeper) acr_prefetch<kPre ? E : 1>(pb, tid, pre);
+    const AcrState* st_in = states + (par ^ 1);
+    const AcrHyp* hyp_in = hyps + (size_t)(par ^ 1) * kSlots;
+    const uint32_t* sorted_in = sorted + (size_t)(par ^ 1) * kSlots * pb.n;
+    const double* models_in = models + (size_t)(par ^ 1) * kSlots * 12;
+    if (tid < 64) {
+        AcrCore c = acr_core_load(st_in);
+        AcrPick pick{ -1, 0, 0 };
+        if (c.evaluated && c.cur_batch > 0) pick = acr_select_wave<4>(pb, c, hyp_in, tid);   // else: the first launch of a run, or a launch after its end
+        c.evaluated = 1;
+        if (tid == 0) { s_core = c; s_pick = pick; }
+#if defined(CLC_ACR_STAMP)
+        t_replay = __builtin_amdgcn_s_memtime();
+#endif
     }
     __syncthreads();
-    if (tid == 0) {
-        *state = s;
-        // what the host needs between rounds, in ONE 8-byte word it polls in pinned memory:
-        // [63:49] round number, [48] index set switched, [47:40] iterations consumed, [39:20] n_iter, [19:0] iter
-        if (h_word && B > 0) {
-            const unsigned long long w = ((unsigned long long)((uint32_t)s.rounds & 0x7FFFu) << 49) | ((unsigned long long)(s.index_all ? 0u : 1u) << 48) |
-                                         ((unsigned long long)((uint32_t)s.last_batch & 0xFFu) << 40) |
-                                         ((unsigned long long)((uint32_t)s.n_iter & 0xFFFFFu) << 20) | (unsigned long long)((uint32_t)s.iter & 0xFFFFFu);
-            __hip_atomic_store(h_word, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    const AcrCore s = s_core;
+    const AcrPick pick = s_pick;
+    if (keeper) {
+        acr_keep(pb, s, pick, models_in, sorted_in, st_in, states + par, best_inliers, index_set, h_word, fin, s_full, tid, T);
+        return;
     }
+    if (slot >= s.cur_batch * 4) return;                            // the grid covers an upper bound of the batch
+    if (tid == 0) {
+#if defined(CLC_ACR_STAMP)
+        if (blockIdx.x == 0) { g_acr_stamp[0] = t_start; g_acr_stamp[1] = t_replay; }
+#endif
+        ACR_STAMP(2);
+        const uint32_t* win = pick.best_h >= 0 ? sorted_in + (size_t)pick.best_h * pb.n : nullptr;
+        const uint32_t* src = acr_sample_source(s, pick, win, best_inliers, index_set);
+        uint32_t pos[3];
+        clc_acr_sample_t<3>(pb.seed, (uint32_t)(s.iter + (slot >> 2)), (uint32_t)s.n_index, pos);
+        int id[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) id[j] = (int)(src ? src[pos[j]] : pos[j]);
+#if defined(CLC_ACR_STAMP)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        ACR_STAMP(3);
+        p3p_sample_root(pb.a, pb.b, pb.K1v, id[0], id[1], id[2], pb.n, slot & 3, s_model);
+        ACR_STAMP(4);
+        double* mo = models + ((size_t)par * kSlots + slot) * 12;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) mo[e] = s_model[e];
+    }
+    __syncthreads();
+    ACR_STAMP(5);
+    acr_nfa_body<E, kPre>(pb, P, s_model, hyps + (size_t)par * kSlots + slot, sorted + ((size_t)par * kSlots + slot) * pb.n, tid, T,
+                          reinterpret_cast<uint64_t*>(acr_lds), &pre);
 }
 
 // ---- finish: mask, inlier list and the result record, straight into pinned host memory ---------------------------
@@ -565,8 +894,8 @@ static hipError_t acr_launch_nfa(const AcrProblem& pb, int B, int P, const doubl
         attr_set[dev] = true;
     }
     const int T = P / E;
-    // LDS is only touched by exchanges that cross waves
-    const size_t lds = T > 64 ? (size_t)P * 8 : 0;
+    // one word per element for the exchanges that cross waves + (E <= 8) one for the exact residual bits
+    const size_t lds = (T > 64 ? (size_t)P * 8 : 0) + (E <= 8 ? (size_t)P * 8 : 0);
     hipLaunchKernelGGL(acr_nfa_kernel<E>, dim3(B * pb.max_models), dim3(T), lds, stream, pb, P, d_models, d_hyp, d_sorted, d_state);
     return hipGetLastError();
 }
@@ -597,6 +926,41 @@ hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp
     return hipGetLastError();
 }
 
+template <int E>
+static hipError_t acr_launch_round_p3p(const AcrProblem& pb, int B, int P, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted,
+                                       double* d_models, uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word,
+                                       const AcrFinish& fin, hipStream_t stream)
+{
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)acr_round_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcrMaxLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    const int T = P / E;
+    const size_t lds = (T > 64 ? (size_t)P * 8 : 0) + (E <= 8 ? (size_t)P * 8 : 0);
+    hipLaunchKernelGGL(acr_round_kernel<E>, dim3(B * 4 + 1 /* the keeper */), dim3(T), lds, stream, d_states, d_hyps, par, P, pb, d_sorted,
+                       d_models, d_best_inliers, d_index_set, h_word, fin);
+    return hipGetLastError();
+}
+
+hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted, double* d_models,
+                                uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word, hipStream_t stream,
+                                int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res)
+{
+    const int B = batch_bound < 1 ? 1 : (batch_bound > kAcrMaxBatch ? kAcrMaxBatch : batch_bound);
+    int P = 64;
+    while (P < pb.n) P <<= 1;
+    const AcrFinish fin{ d_mask, d_res, h_mask, h_inliers, h_res };
+    if (P <= 1024) return acr_launch_round_p3p<1>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (P == 2048) return acr_launch_round_p3p<2>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (P == 4096) return acr_launch_round_p3p<4>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (P == 8192) return acr_launch_round_p3p<8>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    return acr_launch_round_p3p<16>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+}
+
 hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
                              uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream)
 {
@@ -607,3 +971,10 @@ hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, cons
 size_t acr_hyp_bytes() { return sizeof(AcrHyp); }
 
 } // namespace clc
+
+#if defined(CLC_ACR_STAMP)
+extern "C" int clc_debug_acr_stamps(unsigned long long* out16)
+{
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(clc::g_acr_stamp), sizeof(unsigned long long) * 16);
+}
+#endif

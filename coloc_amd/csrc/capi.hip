@@ -1288,11 +1288,14 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k | initial state | first batch's samples ] uploaded
     // in one copy, then scratch
     const size_t samples_d = dbl(sizeof(int32_t) * kAcrMaxBatch * 5);
-    const size_t state_d = dbl(sizeof(AcrState));
+    const size_t state_d = 2 * dbl(sizeof(AcrState));                      // [ copy 0 | copy 1 = the state a run starts from ]
     const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d + samples_d;
-    const size_t models_d = (size_t)kAcrMaxBatch * M * md;
-    const size_t hyp_d = dbl(acr_hyp_bytes() * kAcrMaxBatch * M);
-    const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)kAcrMaxBatch * M * N);
+    // the resection round is ONE launch per round that reads what the launch before it wrote: two copies of state, models, slots
+    // and sorted lists, indexed by launch parity (acransac.hip: acr_round_kernel)
+    const int copies = kind == 0 ? 2 : 1;
+    const size_t models_d = (size_t)copies * kAcrMaxBatch * M * md;
+    const size_t hyp_d = dbl(acr_hyp_bytes() * copies * kAcrMaxBatch * M);
+    const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)copies * kAcrMaxBatch * M * N);
     const size_t idx_d = dbl(sizeof(uint32_t) * (size_t)N);
     const size_t res_d = dbl(sizeof(AcrResult)), mask_d = dbl((size_t)N);
     const size_t ref_d = refine ? dbl(pnp_refine_out_bytes()) : 0;
@@ -1330,9 +1333,11 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     float* h_ck = (float*)(hK + 32 + dbl(sizeof(float) * ((size_t)N + 1)));
     acr_tables(N, m, h_cn, h_ck, ctx->acr_lg);
     // the state ACRANSAC starts from and the first batch's samples (drawn from all data) are part of the upload
-    AcrState* h_init = (AcrState*)(hK + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)));
-    int32_t* h_samples = (int32_t*)((double*)h_init + state_d);
-    memset(h_init, 0, sizeof(AcrState));
+    AcrState* h_states = (AcrState*)(hK + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)));
+    int32_t* h_samples = (int32_t*)((double*)h_states + state_d);
+    memset(h_states, 0, 2 * sizeof(AcrState));
+    // resection: launch 0 (parity 0) reads copy 1; the five-point path keeps its single state in copy 0
+    AcrState* h_init = h_states + (kind == 0 ? 1 : 0);
     h_init->min_nfa = INFINITY; h_init->error_max = INFINITY;
     h_init->best_iter = -1;
     h_init->reserve = max_iteration / 10;
@@ -1341,7 +1346,7 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     h_init->ac_mode = std::isinf(precision) ? 1 : 0;
     h_init->grow = 32;
     h_init->cur_batch = h_init->n_iter < 32 ? h_init->n_iter : 32;
-    {
+    if (kind == 1) {                                   // (the resection round draws its own samples on the device)
         const int nb = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
         for (int it = 0; it < nb; ++it) {
             uint32_t pos[8];
@@ -1365,6 +1370,7 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
         pb.logalpha0 = clc_acr_log10(M_PI);
         pb.mult = 1.0;
         pb.norm = 1.0 / h_K1[0];
+        for (int e = 0; e < 9; ++e) pb.K1v[e] = h_K1[e];
     } else {
         // ACKernelAdaptorEssential: point-to-line, logalpha0 = log10(2 D / A * 0.5) of image 2, error^(1/2)
         const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
@@ -1381,13 +1387,21 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
     // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
     // select straight into the next round's solve while the host is still polling (a 10 us bubble per round otherwise).
+    int launches = 0;
     auto enqueue_round = [&](const int bound) -> int {
         const int32_t* d_cnt = &d_state->cur_batch;
         const int S = bound < 1 ? 1 : (bound > kAcrMaxBatch ? kAcrMaxBatch : bound);
-        if (kind == 0) CLC_HIP(ctx, launch_p3p(d_a, d_b, N, d_K1, d_samples, S, d_models, st, d_cnt));
-        else CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, S, d_models, st, d_cnt));
-        CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st, S, d_mask, d_res,
-                                      p_mask, p_inl, h_res));
+        if (kind == 0) {
+            // one launch: replay of the previous round, this round's samples, P3P, residuals / sort / NFA; the word of round r comes
+            // out of launch r + 1
+            CLC_HIP(ctx, launch_acr_round_p3p(pb, launches & 1, d_state, d_hyp, d_sorted, d_models, d_best, d_index, h_word, st, S, d_mask,
+                                              d_res, p_mask, p_inl, h_res));
+        } else {
+            CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, S, d_models, st, d_cnt));
+            CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st, S, d_mask, d_res,
+                                          p_mask, p_inl, h_res));
+        }
+        ++launches;
         return CLC_OK;
     };
     // Upper bound of the batch a round can ask for, from what the host knows when it enqueues it (one or two rounds behind the
@@ -1395,7 +1409,7 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
     const int reserve0 = h_init->reserve;
     int bound = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
-    rc = enqueue_round(bound);
+    rc = enqueue_round(kind == 0 ? h_init->cur_batch : bound);         // (the resection launch takes its first batch as it stands)
     if (rc != CLC_OK) return rc;
     uint32_t round = 0;
     for (;;) {

@@ -183,6 +183,7 @@ struct AcrProblem {        // passed by value to every kernel of a solve
     double loge0, logalpha0, mult, max_threshold;
     double norm;           // resection: 1 / focal (residuals are scaled to the normalised camera plane); essential: 1
     uint64_t seed;
+    double K1v[9];         // resection: K1 by value -- kernel arguments sit in scalar registers, a load of K1 is a ~1 us round trip
 };
 struct AcrState {          // device resident; the host sees one packed 8-byte word of it after every round
     double min_nfa, error_max;
@@ -194,7 +195,7 @@ struct AcrState {          // device resident; the host sees one packed 8-byte w
     int32_t cur_batch;     // iterations the NEXT round evaluates (the solve / nfa kernels read it from here: rounds are enqueued
     int32_t grow;          // one ahead of the host's knowledge); grow = batch size while no event has happened (32, 64, 128)
     int32_t rounds_eval;   // rounds that evaluated at least one iteration (`rounds` also counts the empty round enqueued ahead)
-    int32_t pad_;
+    int32_t evaluated;     // acr_round_kernel: the slots of the other parity hold a batch of cur_batch iterations to replay (0: a fresh run)
 };
 struct AcrResult {
     double model[18];
@@ -213,6 +214,11 @@ hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp
                             uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, unsigned long long* h_word,
                             hipStream_t stream, int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers,
                             AcrResult* h_res);
+// the resection round as ONE launch (replay of the previous round + P3P + nfa; acransac.hip): d_states / d_hyps / d_sorted / d_models
+// hold two copies, this launch reads copy par ^ 1 and writes copy par; the initial state goes into copy 1 and the first launch has par 0
+hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted, double* d_models,
+                                uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word, hipStream_t stream,
+                                int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res);
 hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
                              uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream);
 

@@ -247,6 +247,46 @@ P3P_HD int p3p_solve(const double X[3][3], const double f[3][3], double* Rt_out)
     return ns;
 }
 
+#if defined(__HIPCC__) || defined(__HIP__)
+// One root of one sample, straight from the correspondence arrays: pose slot `root` (12 doubles [R|t], NaNs when the root has no
+// valid pose or a sample index is out of range) of the P3P problem on points i0, i1, i2 of (X: N x 3 world points, x: N x 2 pixels,
+// K: 3 x 3 row-major).  Shared by p3p_kernel (the hypothesis generator the tests hand to the a-contrario oracle) and
+// acr_round_kernel (which solves its own sample in place); `out` may point to global memory or to LDS.  (As a call to ONE
+// not-inlined body the two would agree bit for bit by construction, but the call costs 140-200 B of callee-saved spills per lane
+// and 6 us per solve; inlined, with aggressive contraction on the same expression trees, they agree as well -- every a-contrario
+// test compares the winning pose bit for bit with the oracle's, which gets its poses from p3p_kernel.)
+static __device__ __forceinline__ void p3p_sample_root(const double* X, const double* x, const double* K, const int i0, const int i1,
+                                                       const int i2, const int N, const int root, double* out)
+{
+    double Xs[3][3], f[3][3];
+    bool ok = true;
+    const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const double ifx = p3p_rcp(fx), ify = p3p_rcp(fy);
+    const int ids[3] = { i0, i1, i2 };
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int p = 0; p < 3; ++p) {
+        int i = ids[p];
+        if (i < 0 || i >= N) { ok = false; i = 0; }
+        Xs[p][0] = X[3 * i]; Xs[p][1] = X[3 * i + 1]; Xs[p][2] = X[3 * i + 2];
+        const double yn = (x[2 * i + 1] - cy) * ify;
+        const double xn = (x[2 * i] - cx - sk * yn) * ifx;
+        const double inrm = p3p_rcp(sqrt(xn * xn + yn * yn + 1.0));
+        f[p][0] = xn * inrm; f[p][1] = yn * inrm; f[p][2] = inrm;
+    }
+    P3PProblem prob;
+    ok = ok && p3p_prepare(Xs, f, prob);
+    double P[12];
+    const bool have = ok && p3p_pose_from_root(prob, Xs, f, root, P);
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int e = 0; e < 12; ++e) out[e] = have ? P[e] : qnan;
+}
+#endif
+
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif

@@ -103,28 +103,8 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int sidx = gid >> 2, root = gid & 3;
     if (sidx >= S || (n_dev && sidx >= *n_dev)) return;
-    double Xs[3][3], f[3][3];
-    bool ok = true;
-    const double fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
-    const double ifx = p3p_rcp(fx), ify = p3p_rcp(fy);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        int i = samples[3 * sidx + p];
-        if (i < 0 || i >= N) { ok = false; i = 0; }
-        Xs[p][0] = X[3 * i]; Xs[p][1] = X[3 * i + 1]; Xs[p][2] = X[3 * i + 2];
-        const double yn = (x[2 * i + 1] - cy) * ify;
-        const double xn = (x[2 * i] - cx - sk * yn) * ifx;
-        const double inrm = p3p_rcp(sqrt(xn * xn + yn * yn + 1.0));
-        f[p][0] = xn * inrm; f[p][1] = yn * inrm; f[p][2] = inrm;
-    }
-    P3PProblem prob;
-    ok = ok && p3p_prepare(Xs, f, prob);
-    double P[12];
-    const bool have = ok && p3p_pose_from_root(prob, Xs, f, root, P);
-    double* out = Rt + (size_t)48 * sidx + 12 * root;
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-#pragma unroll
-    for (int e = 0; e < 12; ++e) out[e] = have ? P[e] : qnan;
+    // slots without a valid pose are NaN (p3p.h: the shared, not-inlined solve of one root)
+    p3p_sample_root(X, x, K, samples[3 * sidx], samples[3 * sidx + 1], samples[3 * sidx + 2], N, root, Rt + (size_t)48 * sidx + 12 * root);
 }
 
 // best hypothesis: most inliers, then lowest cost, then lowest index -- and its inlier mask, in ONE
