@@ -84,7 +84,6 @@ struct clc_ctx {
     int device = 0;
     std::vector<float> acr_lg;   // (float) log10(k), k = 0 .. : the a-contrario tables are sums over it
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // side stream: the pose refinement behind an a-contrario run (not ordered behind the round enqueued ahead)
     std::string err;
     bool has_det = false, has_mat = false;
     clc_detector_opts dopts{};
@@ -324,7 +323,6 @@ int clc_ctx_destroy(clc_ctx* ctx)
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CLC_OK;
@@ -1356,7 +1354,6 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     }
     unsigned long long* h_word = (unsigned long long*)(hp + in_d + state_d);
     AcrResult* h_res = (AcrResult*)(hp + in_d + state_d + 1);
-    uint8_t* p_mask = (uint8_t*)(hp + in_d + state_d + 1 + res_d);
     int32_t* p_inl = (int32_t*)(hp + in_d + state_d + 1 + res_d + mask_d);
     double* p_ref = hp + in_d + state_d + 1 + res_d + mask_d + inl_d;
     __atomic_store_n(h_word, 0ull, __ATOMIC_RELAXED);
@@ -1382,7 +1379,7 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     pb.seed = seed;
 
     hipStream_t st = ctx->stream;
-    CLC_HIP(ctx, hipMemcpyAsync(ctx->d_pnp, hp, in_d * sizeof(double), hipMemcpyHostToDevice, st));
+    CLC_HIP(ctx, launch_acr_stage(hp, ctx->d_pnp, (in_d + 1) & ~(size_t)1, st));      // (both blocks are sized past in_d + 1)
     prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
     // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
     // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
@@ -1395,11 +1392,11 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
             // one launch: replay of the previous round, this round's samples, P3P, residuals / sort / NFA; the word of round r comes
             // out of launch r + 1
             CLC_HIP(ctx, launch_acr_round_p3p(pb, launches & 1, d_state, d_hyp, d_sorted, d_models, d_best, d_index, h_word, st, S, d_mask,
-                                              d_res, p_mask, p_inl, h_res));
+                                              d_res, nullptr, p_inl, h_res));
         } else {
             CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, S, d_models, st, d_cnt));
             CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st, S, d_mask, d_res,
-                                          p_mask, p_inl, h_res));
+                                          nullptr, p_inl, h_res));
         }
         ++launches;
         return CLC_OK;
@@ -1443,19 +1440,30 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     // acquire): no finish launch, and without refinement no stream synchronisation either -- the round enqueued ahead is still in the
     // stream, evaluates nothing and touches no host memory; anything enqueued later on this stream is ordered behind it.
     if (refine) {
-        // on the side stream: everything the refinement reads was written by launches that have completed (the word was seen),
-        // and the round still queued on the main stream writes only the a-contrario state and scratch the refinement does not touch
-        if (!ctx->stream2) CLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        // Behind the launch that completed the run, on the same stream (nothing is queued behind that launch any more: the word of
+        // the last round comes out of the last launch).  The refinement writes its record into pinned memory and sets `ready` last;
+        // the host polls that instead of synchronising the stream (~5 us), with the synchronisation as the fallback after 5 ms.
+        int32_t* ready = (int32_t*)((uint8_t*)p_ref + pnp_refine_ready_offset());
+        __atomic_store_n(ready, 0, __ATOMIC_RELAXED);
         CLC_HIP(ctx, launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50, d_ref,
-                                       ctx->stream2, &ctx->prof, &d_res->valid, p_ref));
-        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+                                       st, &ctx->prof, &d_res->valid, p_ref));
+        const auto t_start = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) {
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(5)) {
+                CLC_HIP(ctx, hipStreamSynchronize(st));
+                if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) return fail(ctx, CLC_ERR_HIP, "acransac: refinement did not complete");
+            }
+        }
     }
     const AcrResult r = *h_res;
     if (h_model) {
         if (kind == 0) memcpy(h_model, r.model, sizeof(double) * 12);
         else { memcpy(h_model, r.model + 9, sizeof(double) * 9); memcpy(h_model + 9, r.model, sizeof(double) * 9); }   // slots hold {F, E}
     }
-    if (h_mask) memcpy(h_mask, p_mask, (size_t)N);
+    // the mask is rebuilt from the inlier list here (h_mask was cleared above): the device does not push N bytes + one scattered byte
+    // per inlier over PCIe for it
+    if (h_mask) for (int i = 0; i < r.n_inliers; ++i) h_mask[p_inl[i]] = 1;
     if (h_inliers && r.n_inliers > 0) memcpy(h_inliers, p_inl, sizeof(int32_t) * (size_t)r.n_inliers);
     if (n_inliers) *n_inliers = r.n_inliers;
     if (error_max) *error_max = r.error_max;

@@ -159,6 +159,7 @@ hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const dou
 // (h_out: pinned host record written INSTEAD of d_out, so that no device-to-host copy command is needed)
 size_t pnp_result_valid_offset();   // byte offset of the int32 "winning hypothesis" (< 0: none) in the ransac result record
 size_t pnp_refine_out_bytes();
+size_t pnp_refine_ready_offset();   // int32 written last by the refinement launch (1), for a host polling a pinned record
 
 // the minimal solvers alone (pnp.hip), for the a-contrario rounds: S samples -> 4 S pose slots / 10 S {F, E} slots
 // d_count (nullable): the number of samples actually solved is min(S, *d_count), read on the device
@@ -219,6 +220,7 @@ hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp
 hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted, double* d_models,
                                 uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word, hipStream_t stream,
                                 int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res);
+hipError_t launch_acr_stage(const double* h_pinned, double* d_dst, size_t n_doubles /* even */, hipStream_t stream);
 hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
                              uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream);
 

@@ -187,6 +187,8 @@ struct RefineOut {
     double rmse;        // sqrt(final_cost / (2 n_used))  (Refiner.hpp:226)
     int32_t iterations;
     int32_t n_used;
+    int32_t ready;      // written LAST (system-scope release): a host that cleared it in a pinned record can poll it instead of
+    int32_t pad_;       // synchronising the stream
 };
 
 __device__ __forceinline__ void rodrigues(const double* w, double* R)
@@ -337,6 +339,9 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
         if (threadIdx.x < 12) out->Rt[threadIdx.x] = 0.0;
         if (threadIdx.x < 36) out->cov[threadIdx.x] = 0.0;
         if (threadIdx.x == 0) { out->cost = 0.0; out->rmse = 0.0; out->iterations = 0; out->n_used = 0; }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&out->ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     extern __shared__ double red[];     // [kRefineSums][kRefineThreads] reduction scratch (dynamic: 116 KB)
@@ -514,6 +519,9 @@ __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double
         out->iterations = it;
         out->n_used = (int32_t)n_used;
     }
+    __threadfence_system();                 // every writer: its stores to the (possibly pinned host) record have left
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&out->ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const double* d_x, const uint8_t* d_mask, int N,
@@ -537,6 +545,7 @@ hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const dou
     return hipGetLastError();
 }
 size_t pnp_refine_out_bytes() { return sizeof(RefineOut); }
+size_t pnp_refine_ready_offset() { return offsetof(RefineOut, ready); }
 
 hipError_t launch_pnp_ransac(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples,
                              int S, double thr2, double* d_Rt /* 48*S */, int32_t* d_count, double* d_cost,
