@@ -500,17 +500,43 @@ def main():
                     t1 = time.perf_counter()
                     ctx.pnp_localize(sc["X"], sc["x"], sc["K"], n_samples=256, seed=it + 1, thr2=16.0)
                     fx.append((time.perf_counter() - t1) * 1e3)
+                # the same two calls straight through the C ABI with the caller's buffers allocated once, as a C++ host makes them
+                # (the Python wrapper above allocates its outputs and converts every argument on each call: 10-15 us)
+                import ctypes as C
+                from coloc_amd.abi import _p
+                Xc, xc_, Kc_ = (np.ascontiguousarray(sc[k], dtype=np.float64) for k in ("X", "x", "K"))
+                Rt_, cov_ = np.zeros(12), np.zeros(36)
+                mk_, inl_ = np.zeros(n_pts, dtype=np.uint8), np.zeros(n_pts, dtype=np.int32)
+                ni_, its_, em_, nfa_, rm_ = C.c_int(), C.c_int(), C.c_double(), C.c_double(), C.c_double()
+                pX, px, pK, pRt, pcov, pmk, pinl = _p(Xc), _p(xc_), _p(Kc_.reshape(9)), _p(Rt_), _p(cov_), _p(mk_), _p(inl_)
+                ca, cl = [], []
+                for it in range(reps):
+                    t1 = time.perf_counter()
+                    rc1 = ctx.lib.clc_pnp_acransac(ctx.h, pX, px, n_pts, pK, 256, it + 1, float("inf"), pRt, pmk, pinl, C.byref(ni_), C.byref(em_),
+                                                   C.byref(nfa_), C.byref(its_))
+                    ca.append((time.perf_counter() - t1) * 1e3)
+                    t1 = time.perf_counter()
+                    rc2 = ctx.lib.clc_pnp_localize_ac(ctx.h, pX, px, n_pts, pK, 256, it + 1, float("inf"), 16.0, pRt, pcov, pmk, pinl, C.byref(ni_),
+                                                      C.byref(em_), C.byref(rm_))
+                    cl.append((time.perf_counter() - t1) * 1e3)
+                    assert rc1 == 0 and rc2 == 0
+                assert ni_.value == len(r2["inliers"]) and np.array_equal(Rt_.reshape(3, 4), r2["Rt"])     # same call, same answer
+                ca, cl = np.sort(ca[5:]), np.sort(cl[5:])
                 pose["N%d" % n_pts] = {"acransac_p50_ms": float(ta[len(ta) // 2]), "acransac_p95_ms": float(ta[int(len(ta) * 0.95)]),
+                                       "c_abi_acransac_p50_ms": float(ca[len(ca) // 2]), "c_abi_with_refine_p50_ms": float(cl[len(cl) // 2]),
+                                       "c_abi_with_refine_p95_ms": float(cl[int(len(cl) * 0.95)]),
                                        "with_refine_p50_ms": float(tl[len(tl) // 2]), "with_refine_p95_ms": float(tl[int(len(tl) * 0.95)]),
                                        "solves": int(len(ta)), "iterations_median": float(np.median(its)), "inliers": int(len(r2["inliers"])),
                                        "precision_found_px": float(r2["error_max"]),
                                        "fixed_threshold_with_refine_p50_ms": float(np.median(fx[5:]))}
             out["pose_solve"] = {"rule": "a-contrario RANSAC (AC-RANSAC, NFA over sorted residuals, no threshold given), P3P minimal solver, "
-                                         "max_iteration 256, then LM/Huber(16) refinement + 6x6 covariance; host buffers in/out",
+                                         "max_iteration 256, then LM/Huber(16) refinement + 6x6 covariance; host buffers in/out; *_p50_ms through the Python "
+                                         "wrapper (coloc_amd.Context.pnp_acransac), c_abi_* = clc_pnp_acransac / clc_pnp_localize_ac called directly",
                                  "fixed_threshold_note": "clc_pnp_localize: 256 samples scored against a given 4 px threshold -- NOT the reference's rule, kept for comparison",
                                  **pose}
             out["pose_solve_p50_ms"] = pose["N1000"]["with_refine_p50_ms"]
             out["pose_acransac_only_p50_ms"] = pose["N1000"]["acransac_p50_ms"]
+            out["pose_solve_p50_ms_c_abi"] = pose["N1000"]["c_abi_with_refine_p50_ms"]
 
         def sec_two_view():
             # two-view filter: a-contrario five-point RANSAC over 1000 correspondences, 30 % outliers

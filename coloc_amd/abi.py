@@ -167,7 +167,9 @@ def load_library():
 
 
 def _p(a):
-    return None if a is None else a.ctypes.data_as(C.c_void_p)
+    # (a.ctypes.data_as(c_void_p) builds two ctypes objects per call, ~2.3 us; a pose solve passes seven pointers.  The caller keeps
+    # the array alive across the call.)
+    return None if a is None else C.c_void_p(a.ctypes.data)
 
 
 def cov_intersection(CA, CB, ca, cb):
