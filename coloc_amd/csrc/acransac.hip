@@ -17,8 +17,9 @@
 //             improvements, the phase-switch rule), stops at the first iteration that changes the index set -- the
 //             iterations after it were sampled speculatively from the old set and are discarded --, updates the device
 //             state, draws the next batch's samples and mirrors the state into pinned host memory.
-// The host only reads that mirror (one stream synchronisation per round) to learn whether another round is needed:
-// typically one round to find the first meaningful model, one or two for the reserve.  Results are identical to the
+// The resection path runs solve + nfa + the select of the PREVIOUS round as ONE launch per round (acr_round_kernel below); the
+// five-point path keeps the three launches.  The host only polls one packed word per round in pinned memory to learn whether
+// another round is needed: one round to find the first meaningful model, then one per improvement in the reserve.  Results are identical to the
 // sequential oracle: same samples, bit-identical residuals (same operation order, no FMA contraction), a total order on
 // (residual, index), and the same portable log10 in the NFA terms.
 #include "clc_internal.h"
