@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--settle-steps", type=int, default=1000,
+                    help="untimed steps BEFORE the W warm-up steps, so that the device clocks have settled when the timed region starts "
+                         "(measured: a timed region of 20 steps behind 5 or 50 warm-up steps runs at 114 us/step, behind 500 or 3000 at "
+                         "100 us/step -- the clocks of an idle MI355X take 5-50 ms of load to come up).  Reported in the JSON line.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sustain-seconds", type=float, default=1.2, help="length of the sustained leg (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -205,6 +209,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clock settling (not part of W or K: the same step, untimed; every rank runs the same count -- a step may hold a collective)
+    for i in range(max(args.settle_steps, 0)):
+        step()
+        if (i & 255) == 255:
+            torch.cuda.synchronize()           # keep the queue bounded
+    fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -351,6 +361,7 @@ def main():
             "value": total_cmp / (dt / args.steps) / 1e6,
             "unit": "Mmatches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle": {"steps": max(args.settle_steps, 0), "what": "untimed steps before the warm-up so that the timed region runs at settled clocks"},
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("fp4 (+-1) x fp4 -> f32 accumulate, exact integers (matrix pipe)" if formulation == "matrix" else "u32 (xor+popcount)")

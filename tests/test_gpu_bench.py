@@ -42,6 +42,8 @@ def test_default_line_has_contract_fields():
     assert d["accepted_matches_per_step"] > 5000                     # the two cameras see the same scene
     assert "acransac" in d["pose_solve"]["rule"].lower() or "a-contrario" in d["pose_solve"]["rule"]
     assert d["pose_solve_p50_ms"] > 0 and "section_errors" not in d
+    assert 0 < d["pose_solve_p50_ms_c_abi"] <= d["pose_solve_p50_ms"] * 1.2      # the same solve without the wrapper's allocations
+    assert d["settle"]["steps"] == 1000                              # the clock-settling steps are reported, not hidden
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["openmvg_ratio_rule"]["value"] > 0
     assert d["value"] > 10 * c["value"]          # north-star target: >= 10x the host-CPU matcher
@@ -51,7 +53,7 @@ def test_two_rank_rehearsal_runs():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FAULT_AFTER="200")   # a hung rank dumps its stacks and exits
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
-           "--backend", "gloo"]
+           "--settle-steps", "6", "--backend", "gloo"]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
@@ -64,7 +66,7 @@ def test_four_rank_rehearsal_runs():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FAULT_AFTER="200")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
            "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "1",
-           "--backend", "gloo", "--sustain-seconds", "0.2"]
+           "--settle-steps", "6", "--backend", "gloo", "--sustain-seconds", "0.2"]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
