@@ -268,6 +268,55 @@ int orc_k2nn_omp_ex(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule
     return nthreads;
 }
 
+/* The same sweep `reps` times inside ONE parallel region, each repetition timed between two team barriers: the figure bench.py's
+ * cpu_baseline quotes.  Timing the call from outside puts the team's wake-up into a 4 ms region. */
+int orc_k2nn_omp_timed(const uint8_t* q, int nq, const uint8_t* t, int nt, int rule, int threshold, float ratio, int kernel,
+                       int reps, int32_t* match_out, double* best_seconds)
+{
+    const int thr = (int)(uint8_t)threshold;
+    const float r2 = ratio * ratio;
+    const int wide = kernel < 0 ? k2nn_pick_kernel() : (kernel == 1 && orc_k2nn_avx512_available());
+    int nthreads = 1;
+    double best = 1e30;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
+#ifdef _OPENMP
+#pragma omp single
+        nthreads = omp_get_num_threads();
+#endif
+        for (int r = 0; r < reps; ++r) {
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+            const double t0 = now_s();
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+            for (int i = 0; i < nq; ++i) {
+                int best_i = -1, best_v = 100000, second_v = 200000;
+#if defined(__x86_64__)
+                if (wide) k2nn_query_avx512(q + (size_t)64 * i, t, nt, &best_i, &best_v, &second_v);
+                else
+#endif
+                    k2nn_query_scalar(q + (size_t)64 * i, t, nt, &best_i, &best_v, &second_v);
+                int ok;
+                if (rule == 0) ok = (nt > 0) && (second_v - best_v > thr);
+                else ok = (nt > 1) && ((float)best_v < r2 * (float)second_v);
+                match_out[i] = ok ? best_i : -1;
+            }                                                     /* (implicit barrier: every thread's share is done) */
+            const double t1 = now_s();
+#ifdef _OPENMP
+#pragma omp master
+#endif
+            if (t1 - t0 < best) best = t1 - t0;
+        }
+    }
+    *best_seconds = best;
+    return nthreads;
+}
+
 /* include/coloc/CPUMatcher.hpp:67-76 (computeMatchesPair), :56-65 (matchMapFeatures), :85-89 (matchSceneWithMap):
  * matching::DistanceRatioMatch(ratio, BRUTE_FORCE_HAMMING, regions_I, regions_J, out).  OpenMVG is an empty, unpinned
  * submodule, so this follows SURVEY.md 8(a) row a-9's statement of it (parity unpinned):

@@ -69,6 +69,18 @@ class Oracle:
                                         C.c_int(int(threshold)), C.c_float(ratio), C.c_int(kernel), _ptr(m))
         return m, nthr
 
+    def k2nn_omp_timed(self, Q, T, rule=0, threshold=40, ratio=0.8, kernel=-1, reps=7):
+        """The same sweep `reps` times inside one parallel region; returns (matches, threads, best seconds of one sweep measured
+        between two team barriers -- no thread wake-up in the figure)."""
+        Q = np.ascontiguousarray(Q, dtype=np.uint8).reshape(-1, 64)
+        T = np.ascontiguousarray(T, dtype=np.uint8).reshape(-1, 64)
+        m = np.empty(Q.shape[0], dtype=np.int32)
+        best = C.c_double(0.0)
+        self.lib.orc_k2nn_omp_timed.restype = C.c_int
+        nthr = self.lib.orc_k2nn_omp_timed(_ptr(Q), C.c_int(Q.shape[0]), _ptr(T), C.c_int(T.shape[0]), C.c_int(rule), C.c_int(int(threshold)),
+                                           C.c_float(ratio), C.c_int(kernel), C.c_int(reps), _ptr(m), C.byref(best))
+        return m, nthr, best.value
+
     def cpumatcher_pair(self, desc_i, xy_i, desc_j, xy_j, ratio=0.8, kernel=-1):
         """CPUMatcher::computeMatchesPair (CPUMatcher.hpp:67-76): regions_I = database, regions_J = queries.
         Returns (pairs[k,2] of (i_, j_), threads)."""

@@ -107,6 +107,15 @@ def test_omp_baseline_kernels_agree(oracle):
             assert np.array_equal(m, want), (nt, kernel)
 
 
+def test_omp_baseline_timed_in_region(oracle):
+    """bench.py's cpu_baseline figure: the same sweep repeated inside one parallel region, timed between team barriers."""
+    Q, T = synth.planted_descriptors(400, 901, seed=9)
+    want = oracle.k2nn(Q, T, 40)
+    for kernel in (0, 1):
+        m, nthr, best = oracle.k2nn_omp_timed(Q, T, rule=0, threshold=40, kernel=kernel, reps=3)
+        assert np.array_equal(m, want) and nthr >= 1 and 0.0 < best < 5.0
+
+
 def test_omp_baseline_matches_k2nn_rule(oracle):
     Q, T = synth.planted_descriptors(500, 800, seed=5)
     m, nthr = oracle.k2nn_omp(Q, T, rule=0, threshold=40)
