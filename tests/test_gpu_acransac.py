@@ -64,6 +64,16 @@ def test_pose_other_shapes_and_outlier_rates(gpu_ctx, oracle, n, outl, max_it, s
     _check_pose(gpu_ctx, oracle, sc, max_it, seed)
 
 
+def test_pose_many_seeds_same_bits_as_p3p_kernel(gpu_ctx, oracle):
+    """acr_round_kernel solves its samples in place (p3p_sample_root inlined into it); the oracle gets its poses from p3p_kernel (the
+    same body inlined into another kernel).  Forty runs with different seeds, sizes and outlier rates: the winning pose -- a direct
+    output of that body -- and everything selected on the residuals of every evaluated pose must agree bit for bit."""
+    for k in range(40):
+        n = (150, 260, 700, 1500)[k % 4]
+        sc = synth.pnp_scene(n, seed=7000 + k, outlier_frac=(0.2, 0.45, 0.7)[k % 3])
+        _check_pose(gpu_ctx, oracle, sc, 256 if k % 2 else 90, seed=100 + k)
+
+
 def test_pose_duplicate_and_nearly_equal_residuals(gpu_ctx, oracle):
     """The GPU sorts 64-bit words made of the top 51 residual bits + the index and repairs the order exactly afterwards.
     Duplicated correspondences (equal residuals: index decides) and copies whose pixel differs by one ulp (residuals
