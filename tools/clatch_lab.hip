@@ -199,7 +199,9 @@ __global__ __launch_bounds__(64) void clatch_lab_kernel(const ClatchArgs args, c
 
 // ---- v3: one keypoint per wave, no loop; scalar keypoint load; slot-table loads issued first and consumed after the fill;
 //      copies unrolled with immediate offsets.  Bit-exact.
-enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_NOGATHER = 4u, V3_NOTEST = 8u, V3_NOSINCOS = 16u, V3_NOCOPY = 32u, V3_NOOUT = 64u, V3_NOCOORD = 128u, V3_G1 = 256u, V3_G64 = 512u, V3_GDW = 1024u };
+enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_NOGATHER = 4u, V3_NOTEST = 8u, V3_NOSINCOS = 16u, V3_NOCOPY = 32u, V3_NOOUT = 64u, V3_NOCOORD = 128u, V3_G1 = 256u, V3_G64 = 512u, V3_GDW = 1024u,
+                  V3_B64 = 2048u /* timing only: every patch row read as an 8-byte-aligned ds_read_b64 (address & ~7) */,
+                  V3_ADDTID = 4096u /* bit-exact: the shifted copies stored with ds_write_addtid_b32 */ };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <unsigned V>
 __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
@@ -270,15 +272,26 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
             const int i = (int)lane + 64 * k;
             if (k < kIters - 1 || i < kWinDwords) d[k] = *reinterpret_cast<const u32x2_a4*>(roi + 4 * i);
         }
+        if (V & V3_ADDTID) {
+            // address = M0[15:0] + offset + 4 * lane: exactly the copies' pattern, and no address register travels to the LDS
+            asm volatile("s_mov_b32 m0, %0" :: "s"((uint32_t)(uintptr_t)roi) : "memory");
+        }
 #pragma unroll
         for (int k = 0; k < kIters; ++k) {
             const int i = (int)lane + 64 * k;
             if (k < kIters - 1 || i < kWinDwords) {
+                if (V & V3_ADDTID) {
+#pragma unroll
+                    for (int sh = 1; sh < 4; ++sh)
+                        asm volatile("ds_write_addtid_b32 %0 offset:%1" :: "v"(__builtin_amdgcn_alignbyte(d[k].y, d[k].x, sh)), "n"(kCopyBase[sh] + 256 * k) : "memory");
+                } else {
                 *reinterpret_cast<uint32_t*>(roi + kCopyBase[1] + 4 * i) = __builtin_amdgcn_alignbyte(d[k].y, d[k].x, 1);
                 *reinterpret_cast<uint32_t*>(roi + kCopyBase[2] + 4 * i) = __builtin_amdgcn_alignbyte(d[k].y, d[k].x, 2);
                 *reinterpret_cast<uint32_t*>(roi + kCopyBase[3] + 4 * i) = __builtin_amdgcn_alignbyte(d[k].y, d[k].x, 3);
+                }
             }
         }
+        if (V & V3_ADDTID) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, -1" ::: "memory");
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -289,13 +302,21 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
     else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint32_t pa = rec[j].x & 0xFFFFu, pb = rec[j].x >> 16, pc = rec[j].y & 0xFFFFu;
+        uint32_t pa = rec[j].x & 0xFFFFu, pb = rec[j].x >> 16, pc = rec[j].y & 0xFFFFu;
+        if (V & V3_B64) { pa &= ~7u; pb &= ~7u; pc &= ~7u; }
         uint32_t aa = 0, cc = 0, ab = 0, cb = 0;
 #pragma unroll
         for (int row = 0; row < 8; ++row) {
-            const u32x2_a4 A = lds_read8(roi + pa + row * kStride);
-            const u32x2_a4 B = lds_read8(roi + pb + row * kStride);
-            const u32x2_a4 C = lds_read8(roi + pc + row * kStride);
+            u32x2_a4 A, B, C;
+            if (V & V3_B64) {
+                const uint2 a8 = *reinterpret_cast<const uint2*>(roi + pa + row * kStride), b8 = *reinterpret_cast<const uint2*>(roi + pb + row * kStride),
+                            c8 = *reinterpret_cast<const uint2*>(roi + pc + row * kStride);
+                A.x = a8.x; A.y = a8.y; B.x = b8.x; B.y = b8.y; C.x = c8.x; C.y = c8.y;
+            } else {
+                A = lds_read8(roi + pa + row * kStride);
+                B = lds_read8(roi + pb + row * kStride);
+                C = lds_read8(roi + pc + row * kStride);
+            }
             aa = udot4(A.x, A.x, aa); aa = udot4(A.y, A.y, aa);
             cc = udot4(C.x, C.x, cc); cc = udot4(C.y, C.y, cc);
             ab = udot4(A.x, B.x, ab); ab = udot4(A.y, B.y, ab);
@@ -587,7 +608,7 @@ static float time_variant(const char* name, const PyramidDesc& pd, const uint8_t
         else if (v3 >= 100) {
             switch (v3 - 100) {
 #define V3CASE(X) case X: hipLaunchKernelGGL(clatch_v3_kernel<X>, dim3(g), dim3(64), dyn_lds, 0, a, darena); break;
-                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72) V3CASE(384) V3CASE(640) V3CASE(1152) V3CASE(392) V3CASE(1160) V3CASE(136) V3CASE(648)
+                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72) V3CASE(384) V3CASE(640) V3CASE(1152) V3CASE(392) V3CASE(1160) V3CASE(136) V3CASE(648) V3CASE(2048) V3CASE(2052) V3CASE(4096) V3CASE(6144) V3CASE(6148)
                 default: printf("no such v3 variant\n"); exit(1);
             }
         }
@@ -729,6 +750,13 @@ int main(int argc, char** argv)
                     { "v3abl: NO TESTS, gathers within 1 line", 392 }, { "v3abl: NO TESTS, gathers 8 rows x 32 B", 1160 }, { "v3abl: NO TESTS, gathers 8 rows x 8 B", 136 },
                     { "v3abl: NO TESTS, gathers over 64 lines", 648 } };
                 for (auto& e : abl) if (e.v != 40) time_variant<0>(e.nm, pd, darena, dk, n, dd, false, 0, 0, 100 + e.v);
+            }
+            if (!interior) {
+                time_variant<0>("v3x: copies by ds_write_addtid (bit-exact)", pd, darena, dk, n, dd, false, 0, 0, 100 + 4096);
+                time_variant<0>("v3x: all rows 8-byte aligned b64 (timing only)", pd, darena, dk, n, dd, false, 0, 0, 100 + 2048);
+                time_variant<0>("v3x: b64 + no gather loads", pd, darena, dk, n, dd, false, 0, 0, 100 + 2052);
+                time_variant<0>("v3x: b64 + addtid", pd, darena, dk, n, dd, false, 0, 0, 100 + 6144);
+                time_variant<0>("v3x: b64 + addtid + no gather loads", pd, darena, dk, n, dd, false, 0, 0, 100 + 6148);
             }
             stamp_report(pd, darena, dk, n, dd, 1);
             if (interior) { time_variant<0>("v3 noclamp", pd, darena, dk, n, dd, false, 0, 0, 2); stamp_report(pd, darena, dk, n, dd, 2); }
