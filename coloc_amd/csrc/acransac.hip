@@ -11,12 +11,13 @@
 // sort on one CPU thread.  Here a ROUND evaluates a batch of B iterations at once:
 //   solve   : the existing minimal solvers (p3p_kernel: one problem per four lanes; fivept_kernel: one per wave) on the
 //             batch's samples -- samples are a pure function of (seed, iteration, index set), see clc_acr.h;
-//   nfa     : one workgroup per model slot: residuals straight into LDS, bitonic sort of (residual bits, index) in LDS,
-//             NFA(k) for every k in parallel, min-reduction -> {nfa, k, e_k} and the sorted index list;
-//   select  : one workgroup replays the SEQUENTIAL semantics over the batch in iteration / solver order (strict '<'
-//             improvements, the phase-switch rule), stops at the first iteration that changes the index set -- the
-//             iterations after it were sampled speculatively from the old set and are discarded --, updates the device
-//             state, draws the next batch's samples and mirrors the state into pinned host memory.
+//   nfa     : one workgroup per model slot: residuals in registers, sort of one 64-bit word per element (residual bits with the
+//             element index in the low mantissa bits) in registers / across lanes / through LDS, exact order restored from the
+//             exact residual bits, NFA(k) for every k in parallel, min-reduction -> {nfa, k, e_k} and the sorted index list;
+//   select  : ONE WAVE replays the SEQUENTIAL semantics over the batch in iteration / solver order (strict '<' improvements,
+//             the phase-switch rule), stops at the first iteration that changes the index set -- the iterations after it were
+//             sampled speculatively from the old set and are discarded; one workgroup then applies the side effects (device
+//             state, best inlier list, index set, the word the host polls, the result record when the run ends).
 // The resection path runs solve + nfa + the select of the PREVIOUS round as ONE launch per round (acr_round_kernel below); the
 // five-point path keeps the three launches.  The host only polls one packed word per round in pinned memory to learn whether
 // another round is needed: one round to find the first meaningful model, then one per improvement in the reserve.  Results are identical to the
