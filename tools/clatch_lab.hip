@@ -201,7 +201,9 @@ __global__ __launch_bounds__(64) void clatch_lab_kernel(const ClatchArgs args, c
 //      copies unrolled with immediate offsets.  Bit-exact.
 enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_NOGATHER = 4u, V3_NOTEST = 8u, V3_NOSINCOS = 16u, V3_NOCOPY = 32u, V3_NOOUT = 64u, V3_NOCOORD = 128u, V3_G1 = 256u, V3_G64 = 512u, V3_GDW = 1024u,
                   V3_B64 = 2048u /* timing only: every patch row read as an 8-byte-aligned ds_read_b64 (address & ~7) */,
-                  V3_ADDTID = 4096u /* bit-exact: the shifted copies stored with ds_write_addtid_b32 */ };
+                  V3_ADDTID = 4096u /* bit-exact: the shifted copies stored with ds_write_addtid_b32 */,
+                  V3_PRIO = 8192u /* bit-exact: s_setprio 3 while the fill issues its gathers, 0 from the copies on */,
+                  V3_PRIO_INV = 16384u /* the other way round: tests at priority 3 */ };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <unsigned V>
 __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
@@ -237,6 +239,7 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
     const int wmax = (int)L.w - 1, hmax = (int)L.h - 1;
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
 
+    if (V & V3_PRIO) __builtin_amdgcn_s_setprio(3);
     float xc[kTiles], xs[kTiles], ys[kTiles], yc[kTiles];
 #pragma unroll
     for (int b = 0; b < kTiles; ++b) {
@@ -264,6 +267,8 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (V & V3_STAMP) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st[3] = __builtin_amdgcn_s_memtime(); }
+    if (V & V3_PRIO) __builtin_amdgcn_s_setprio(0);
+    if (V & V3_PRIO_INV) __builtin_amdgcn_s_setprio(3);
     if (!(V & V3_NOCOPY)) {
         constexpr int kIters = (kWinDwords + 63) / 64;   // 13
         u32x2_a4 d[kIters];
@@ -608,7 +613,7 @@ static float time_variant(const char* name, const PyramidDesc& pd, const uint8_t
         else if (v3 >= 100) {
             switch (v3 - 100) {
 #define V3CASE(X) case X: hipLaunchKernelGGL(clatch_v3_kernel<X>, dim3(g), dim3(64), dyn_lds, 0, a, darena); break;
-                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72) V3CASE(384) V3CASE(640) V3CASE(1152) V3CASE(392) V3CASE(1160) V3CASE(136) V3CASE(648) V3CASE(2048) V3CASE(2052) V3CASE(4096) V3CASE(6144) V3CASE(6148)
+                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72) V3CASE(384) V3CASE(640) V3CASE(1152) V3CASE(392) V3CASE(1160) V3CASE(136) V3CASE(648) V3CASE(2048) V3CASE(2052) V3CASE(4096) V3CASE(6144) V3CASE(6148) V3CASE(8192) V3CASE(16384)
                 default: printf("no such v3 variant\n"); exit(1);
             }
         }
@@ -752,6 +757,8 @@ int main(int argc, char** argv)
                 for (auto& e : abl) if (e.v != 40) time_variant<0>(e.nm, pd, darena, dk, n, dd, false, 0, 0, 100 + e.v);
             }
             if (!interior) {
+                time_variant<0>("v3x: prio 3 during the fill (bit-exact)", pd, darena, dk, n, dd, false, 0, 0, 100 + 8192);
+                time_variant<0>("v3x: prio 3 from the copies on (bit-exact)", pd, darena, dk, n, dd, false, 0, 0, 100 + 16384);
                 time_variant<0>("v3x: copies by ds_write_addtid (bit-exact)", pd, darena, dk, n, dd, false, 0, 0, 100 + 4096);
                 time_variant<0>("v3x: all rows 8-byte aligned b64 (timing only)", pd, darena, dk, n, dd, false, 0, 0, 100 + 2048);
                 time_variant<0>("v3x: b64 + no gather loads", pd, darena, dk, n, dd, false, 0, 0, 100 + 2052);
