@@ -83,6 +83,8 @@ struct K2nnJobDev {
     const int32_t* cnt_q;
     const int32_t* cnt_t;
     uint32_t     q_row0;
+    uint32_t     xcd_rot;     // matrix sweep: the XCD (workgroup id & 7) that takes this job's query block 0 -- the jobs of a launch
+                              // continue round the XCDs where the job before them stopped (k2nn_plan)
 };
 // the sizes a sweep workgroup works with (scalar loads when the counts live in device memory)
 __device__ __forceinline__ uint32_t k2nn_job_nq(const K2nnJobDev& job)

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     // XCD, so an XCD's L2 pulls an eighth of the queries plus the train set instead of all of both (PMC, 10k x 10k:
     // 10.1 MB fetched with the plain order = 8 x (Q + T)).  The grid is padded to a multiple of 8 query blocks.
     const uint32_t within = blockIdx.x >> 3;
-    const uint32_t qblock = (blockIdx.x & 7u) + 8u * (within / job.splits);
+    const uint32_t qblock = ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within / job.splits);
     const uint32_t split = within % job.splits;
     if (qblock >= job.qblocks) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -687,10 +687,22 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
     // slots, 3 workgroups per CU), so that the whole grid runs as ONE round -- a partial second round costs a full
     // round's time at a fraction of the machine
     uint32_t want = mx ? (uint32_t)target_blocks / total_qblocks : ((uint32_t)target_blocks + total_qblocks - 1) / total_qblocks;
+    if (mx) {
+        // Every split of a query block runs on ONE XCD (the kernel's XCD-aware order), so the round must also fit per XCD: an eighth
+        // of the slots against the most query blocks any XCD takes.  34 query blocks (8.5 k queries) at 768 / 34 = 22 splits put
+        // 5 x 22 = 110 workgroups on the 96 slots of XCDs 0 and 1 -- a second round there, measured 33 us instead of 26 for such a
+        // grid.  Jobs continue round the XCDs where the previous one stopped (xcd_rot), so the maximum is ceil(total / 8).
+        const uint32_t per_xcd = (total_qblocks + 7u) / 8u;
+        const uint32_t fit = (uint32_t)target_blocks / 8u / per_xcd;
+        if (fit < want) want = fit;
+    }
     if (want < 1) want = 1;
     size_t off = 0;
+    uint32_t rot = 0;
     for (int j = 0; j < njobs; ++j) {
         K2nnJobDev& jb = jobs[j];
+        jb.xcd_rot = mx ? rot : 0u;
+        rot = (rot + jb.qblocks) & 7u;
         uint32_t splits = want;
         // popcount: >= 16 train vectors per wave; matrix: >= 2 tiles of 32 per workgroup
         const uint32_t min_per = mx ? 64u : 16u * kWaves;
