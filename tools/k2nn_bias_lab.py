@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Experiment: one 10k x 10k pair as TWO jobs of one launch (early query blocks / late query blocks) with their own split counts
-(CLC_K2NN_SPLITS_PER_JOB), so that the workgroups dispatched third onto their CU get less work.  usage: k2nn_bias_lab.py qsplit sA sB"""
+(CLC_K2NN_SPLITS_PER_JOB), so that the workgroups dispatched third onto their CU get less work.  usage: k2nn_bias_lab.py qsplit sA sB
+NOTE: the planner hook that read CLC_K2NN_SPLITS_PER_JOB was an experiment and is NOT in the tree (result: profiles/r03_k2nn_pipelined_pmc.txt);
+without it both jobs get the planner's own split count and this script only times the two-job form of the pair."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch, synth
