@@ -203,7 +203,8 @@ enum : unsigned { V3_STAMP = 1u, V3_NOCLAMP = 2u, V3_NOGATHER = 4u, V3_NOTEST = 
                   V3_B64 = 2048u /* timing only: every patch row read as an 8-byte-aligned ds_read_b64 (address & ~7) */,
                   V3_ADDTID = 4096u /* bit-exact: the shifted copies stored with ds_write_addtid_b32 */,
                   V3_PRIO = 8192u /* bit-exact: s_setprio 3 while the fill issues its gathers, 0 from the copies on */,
-                  V3_PRIO_INV = 16384u /* the other way round: tests at priority 3 */ };
+                  V3_PRIO_INV = 16384u /* the other way round: tests at priority 3 */,
+                  V3_TILED = 32768u /* timing only: gather addresses as if the level were stored in 2 x 2-pixel dwords */ };
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <unsigned V>
 __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(64) void clatch_v3_kernel(const ClatchArgs args, co
             int sx = (int)fx, sy = (int)fy;
             if (!(V & V3_NOCLAMP)) { sx = clamp_i32(sx, wmax); sy = clamp_i32(sy, hmax); }
             uint32_t off = (V & V3_NOCOORD) ? (uint32_t)(by * 8 + dy) * L.pitch + (uint32_t)(bx * 8 + dx) : __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
+            if (V & V3_TILED) off = (((uint32_t)sy >> 1) * (L.pitch >> 1) + ((uint32_t)sx >> 1)) * 4u + (((uint32_t)sy & 1u) * 2u + ((uint32_t)sx & 1u));
             if (V & V3_G1) off = (uint32_t)(by * 8) * L.pitch + (uint32_t)(bx * 64) + lane;              // one 64-byte line per instruction
             if (V & V3_G64) off = (uint32_t)(by * 8 + (int)lane) * L.pitch + (uint32_t)(bx * 8);          // 64 lines per instruction
             if (V & V3_GDW) off = (uint32_t)(by * 8 + dy) * L.pitch + (uint32_t)(bx * 8 + dx) * 4u;       // 8 lines, lanes 4 bytes apart
@@ -613,7 +615,7 @@ static float time_variant(const char* name, const PyramidDesc& pd, const uint8_t
         else if (v3 >= 100) {
             switch (v3 - 100) {
 #define V3CASE(X) case X: hipLaunchKernelGGL(clatch_v3_kernel<X>, dim3(g), dim3(64), dyn_lds, 0, a, darena); break;
-                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72) V3CASE(384) V3CASE(640) V3CASE(1152) V3CASE(392) V3CASE(1160) V3CASE(136) V3CASE(648) V3CASE(2048) V3CASE(2052) V3CASE(4096) V3CASE(6144) V3CASE(6148) V3CASE(8192) V3CASE(16384)
+                V3CASE(4) V3CASE(8) V3CASE(16) V3CASE(32) V3CASE(64) V3CASE(128) V3CASE(132) V3CASE(12) V3CASE(252) V3CASE(6) V3CASE(140) V3CASE(36) V3CASE(72) V3CASE(384) V3CASE(640) V3CASE(1152) V3CASE(392) V3CASE(1160) V3CASE(136) V3CASE(648) V3CASE(2048) V3CASE(2052) V3CASE(4096) V3CASE(6144) V3CASE(6148) V3CASE(8192) V3CASE(16384) V3CASE(32768) V3CASE(32776)
                 default: printf("no such v3 variant\n"); exit(1);
             }
         }
@@ -757,6 +759,9 @@ int main(int argc, char** argv)
                 for (auto& e : abl) if (e.v != 40) time_variant<0>(e.nm, pd, darena, dk, n, dd, false, 0, 0, 100 + e.v);
             }
             if (!interior) {
+                time_variant<0>("v3x: 2x2-tiled gather addresses (timing only)", pd, darena, dk, n, dd, false, 0, 0, 100 + 32768);
+                time_variant<0>("v3x: NO TESTS, 2x2-tiled gather addresses", pd, darena, dk, n, dd, false, 0, 0, 100 + 32776);
+                time_variant<0>("v3x: NO TESTS, real gathers", pd, darena, dk, n, dd, false, 0, 0, 100 + 8);
                 time_variant<0>("v3x: prio 3 during the fill (bit-exact)", pd, darena, dk, n, dd, false, 0, 0, 100 + 8192);
                 time_variant<0>("v3x: prio 3 from the copies on (bit-exact)", pd, darena, dk, n, dd, false, 0, 0, 100 + 16384);
                 time_variant<0>("v3x: copies by ds_write_addtid (bit-exact)", pd, darena, dk, n, dd, false, 0, 0, 100 + 4096);
