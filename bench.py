@@ -76,6 +76,106 @@ def cpu_baseline(desc_q, desc_t, xy_q, xy_t):
     return out
 
 
+def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_match, n_out, mine, arena, counts,
+                      img_ptrs, kp_ptrs, sptr, mc_headline):
+    """bench.py --gpus N, after the headline measurement: the same step through clc_mc_gather_enqueue_dev + clc_mc_match_enqueue_dev
+    with the RCCL all-gather (clc-rccl) and with IPC peer copies (clc-peer); each leg's matches are compared with the headline
+    exchange's, each is timed over 20 steps (max over ranks).  With --backend gloo (ranks sharing a GPU: no communicator possible) the
+    legs run on rehearsal handles -- the other ranks' blocks are filed from the gathered arena -- so that this control flow is covered
+    by the CPU-launchable rehearsal.  Returns {leg: {us_per_step, identical} | {error}}."""
+    import threading
+    from coloc_amd import MultiCam
+    real = args.backend == "nccl"
+    flag_dev = dev if real else "cpu"
+    out = {}
+
+    def all_ok(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def watchdog():
+        sys.stderr.write("bench.py: an exchange leg did not return within its limit (rank %d); legs so far: %s\n" % (rank, json.dumps(out)))
+        sys.stderr.flush()
+        if rank == 0:
+            print(json.dumps({"metric": "Mmatches/s (512-bit Hamming comparisons) at 10k kp/img, describe+match step", "value": None,
+                              "error": "exchange leg hung", "exchange_legs": out}), flush=True)
+        os._exit(4)
+
+    # the reference result: one more step of the headline exchange
+    step()
+    fence()
+    want = d_match[:n_out].clone()
+    for leg, mode in (("clc-rccl", 0), ("clc-peer", 1)):
+        if mc_headline is not None and args.exchange == leg:
+            out[leg] = {"note": "this is the headline exchange of this run"}
+            continue
+        timer = threading.Timer(float(os.environ.get("BENCH_LEG_LIMIT", "90")), watchdog)
+        timer.daemon = True
+        timer.start()
+        mcx, err = None, None
+        box = [None]
+        if real:
+            if rank == 0:
+                try:
+                    box[0] = MultiCam.unique_id()
+                except Exception as exc:                 # e.g. no librccl to dlopen: every rank must still leave the broadcast
+                    box[0] = "unique_id: " + repr(exc)
+            dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], str):
+            err = box[0]
+        else:
+            try:
+                mcx = MultiCam(ctx, world=world, rank=rank, maxkp=NKP, unique_id=box[0])
+            except Exception as exc:
+                err = "create: " + repr(exc)
+        if not all_ok(err is None):
+            out[leg] = {"error": err or "another rank could not create its handle"}
+        else:
+            if real and mode == 1:
+                try:
+                    mcx.open_peers(stream=sptr)
+                except Exception as exc:
+                    err = "open_peers: " + repr(exc)
+            if not all_ok(err is None):
+                out[leg] = {"error": err or "another rank could not map the peers' arenas"}
+            else:
+                got = torch.full_like(d_match, -9)
+
+                def leg_step():
+                    ctx.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP], [mine.data_ptr()], sptr)
+                    if not real:
+                        for o in range(world):
+                            if o != rank:
+                                mcx.virtual_put(o, arena[o].data_ptr(), counts[o], stream=sptr)
+                    mcx.gather_enqueue_dev(mine.data_ptr(), NKP, mode=mode, stream=sptr)
+                    mcx.match_enqueue_dev(THR, got.data_ptr(), got.numel(), stream=sptr)
+                try:
+                    for _ in range(3):
+                        leg_step()
+                    fence()
+                    same = bool(torch.equal(want, got[:n_out]))
+                    t0 = time.perf_counter()
+                    for _ in range(20):
+                        leg_step()
+                    fence()
+                    us = (time.perf_counter() - t0) / 20 * 1e6
+                    same = same and bool(torch.equal(want, got[:n_out]))
+                except Exception as exc:
+                    err, same, us = "step: " + repr(exc), False, 0.0
+                t = torch.tensor([us, 0.0 if same else 1.0], dtype=torch.float64, device=flag_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                out[leg] = {"us_per_step": float(t[0].item()), "identical": bool(t[1].item() == 0.0),
+                            "exchange": ("ncclAllGather" if mode == 0 else "IPC peer copies + 4-byte fence all-gather") if real
+                                        else "REHEARSAL handle (blocks filed with clc_mc_virtual_put)"}
+                if err:
+                    out[leg]["error"] = err
+        if mcx is not None:
+            mcx.close()
+        timer.cancel()
+    return out
+
+
 def main():
     if os.environ.get("BENCH_FAULT_AFTER"):          # debugging aid: dump every thread's stack and exit if the run takes this long
         import faulthandler
@@ -100,6 +200,8 @@ def main():
                     help="N > 1 only. torch = torch.distributed all_gather_into_tensor (default). clc-rccl / clc-peer = the C entry points "
                          "clc_mc_gather_enqueue_dev + clc_mc_match_enqueue_dev (ncclAllGather, or IPC peer copies + a 4-byte fence collective); the "
                          "rendezvous id travels through torch.distributed.  Not exercised on hardware yet: no multi-GPU box in the build loop")
+    ap.add_argument("--no-exchange-legs", action="store_true",
+                    help="N > 1 only: skip the informational legs that run the same step through clc-rccl and clc-peer and compare the matches")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the informational side sections (other formulation, shares, config[2], front end, pose, two-view, host path): "
@@ -205,6 +307,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # cold leg: W warm-up steps, then 20 timed steps, BEFORE any clock settling -- what a driver that only does `--warmup W` would see
+    # (reported as value_cold / ms_per_step_cold; every rank runs the same steps)
+    cold_steps = 20
+    for _ in range(args.warmup):
+        step()
+    fence()
+    tc = time.perf_counter()
+    for _ in range(cold_steps):
+        step()
+    fence()
+    dt_cold = time.perf_counter() - tc
     # clock settling (not part of W or K: the same step, untimed; every rank runs the same count -- a step may hold a collective)
     for i in range(max(args.settle_steps, 0)):
         step()
@@ -284,15 +397,28 @@ def main():
             dist.all_gather_into_tensor(arena.view(-1), mine.view(-1))
         torch.cuda.synchronize()
         allgather_us = (time.perf_counter() - tg) / 20 * 1e6
-    tmax = torch.tensor([dt, sustained["seconds"] if sustained else 0.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    tmax = torch.tensor([dt, sustained["seconds"] if sustained else 0.0, dt_cold], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax[0].item())
+    dt_cold = float(tmax[2].item())
     if sustained:
         sustained["seconds"] = float(tmax[1].item())
         sustained["ms_per_step"] = sustained["seconds"] / sustained["steps"] * 1e3
     ms_per_step = dt / args.steps * 1e3
     errors = []
+
+    # ---- N > 1: the product's own exchange entry points beside the headline's (informational, guarded) ------------------
+    # Every rank walks the same sequence; after each phase that can fail on ONE rank (communicator, IPC mapping, the steps) the
+    # ranks agree on the outcome through torch.distributed before anyone enters the next collective, and a watchdog ends the
+    # process (rank 0 prints the line first) if a leg does not come back.
+    exchange_legs = None
+    if world > 1 and not args.no_exchange_legs:
+        exchange_legs = run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_match, n_out, mine, arena, counts,
+                                          img_ptrs, kp_ptrs, sptr, mc)
+        for k, v in exchange_legs.items():
+            if isinstance(v, dict) and (v.get("error") or v.get("identical") is False):
+                errors.append("exchange_legs." + k)
 
     if rank == 0:
         def avg_us(name, src=None):
@@ -358,6 +484,9 @@ def main():
             "unit": "Mmatches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "settle": {"steps": max(args.settle_steps, 0), "what": "untimed steps before the warm-up so that the timed region runs at settled clocks"},
+            "warmup_effective": args.warmup + cold_steps + max(args.settle_steps, 0) + args.warmup,
+            "value_cold": total_cmp / (dt_cold / cold_steps) / 1e6, "ms_per_step_cold": dt_cold / cold_steps * 1e3,
+            "cold_what": "%d timed steps straight behind the first %d warm-up steps of the process, before the settle steps" % (cold_steps, args.warmup),
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("fp4 (+-1) x fp4 -> f32 accumulate, exact integers (matrix pipe)" if formulation == "matrix" else "u32 (xor+popcount)")
@@ -381,6 +510,7 @@ def main():
                                                        "clc_mc_gather_enqueue_dev: " + ("ncclAllGather" if mc_mode == 0 else "IPC peer copies + 4-byte fence all-gather"))
                                                       if args.backend == "nccl" else "REHEARSAL: gloo all_gather staged through host memory")),
             "allgather_us_rank0": allgather_us,
+            "exchange_legs": exchange_legs,
         }
         # Everything below is reported next to the headline line and never takes it down: each section runs guarded, a
         # failure is recorded under its own key -- and makes the process exit non-zero AFTER the line is printed.

@@ -51,7 +51,7 @@ EXPORTS = [
     "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
-    "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put",
+    "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
     "clc_mc_gather_enqueue_dev", "clc_mc_match_enqueue_dev", "clc_mc_counts", "clc_match_jobs_counted_dev",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
@@ -154,6 +154,7 @@ def load_library():
     lib.clc_mc_arena.argtypes = [vp, C.POINTER(vp), ip, ip]
     lib.clc_mc_gather_dev.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.clc_mc_virtual_put.argtypes = [vp, ci, vp, ci, vp]
+    lib.clc_mc_open_peers.argtypes = [vp, vp]
     lib.clc_mc_match_dev.argtypes = [vp, ci, vp, ci, vp, ci, ip, vp]
     lib.clc_mc_gather_enqueue_dev.argtypes = [vp, vp, ci, vp, ci, vp]
     lib.clc_mc_match_enqueue_dev.argtypes = [vp, ci, vp, ci, vp, ci, ip, vp]
@@ -235,6 +236,10 @@ class MultiCam:
 
     def virtual_put(self, other_rank, d_desc, count, stream=None):
         self._chk(self.lib.clc_mc_virtual_put(self.h, int(other_rank), d_desc, int(count), stream))
+
+    def open_peers(self, stream=None):
+        """Collective: map the peers' arenas now (the first peer-copy exchange would do it otherwise)."""
+        self._chk(self.lib.clc_mc_open_peers(self.h, stream))
 
     def match_dev(self, threshold, d_match, capacity, stream=None):
         cap = self.world * self.world + 2

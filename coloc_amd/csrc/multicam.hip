@@ -76,6 +76,11 @@ Rccl& rccl()
     return r;
 }
 
+// A count travels to the device BY VALUE, as the argument of a one-thread launch.  (Round 3 staged it in one pinned word per buffer and
+// copied that asynchronously: the copy reads its source when it EXECUTES, so a host running two steps ahead -- the enqueue-only gather
+// never synchronises -- rewrote the word of the same parity before the earlier copy had run.)
+__global__ void mc_set_count_kernel(int32_t* __restrict__ dst, const int32_t value) { *dst = value; }
+
 } // namespace
 
 struct clc_mc {
@@ -84,7 +89,7 @@ struct clc_mc {
     ncclComm_t comm = nullptr;
     uint8_t* d_arena = nullptr;            // [2][world][cap][64]: buffer (step & 1) receives step's blocks
     int32_t* d_counts = nullptr;           // [2][world + 1]: the gathered counts of a buffer, this rank's own count at [world]
-    int32_t* h_counts = nullptr;           // pinned, [2][world + 1]: host mirror (+ staging slot at [world])
+    int32_t* h_counts = nullptr;           // pinned, [2][world + 1]: host mirror of the gathered counts (written by the device only)
     int fill = 0;                          // buffer the NEXT gather (and clc_mc_virtual_put) writes
     int cur = 0;                           // buffer of the last completed gather: what the match entries sweep
     bool counts_on_host = false;           // the last gather synchronised and left the counts in h_counts[cur]
@@ -204,7 +209,8 @@ int clc_mc_create(clc_ctx* ctx, const uint8_t id[CLC_MC_ID_BYTES], int world, in
     auto bail = [&](int code) { clc_mc_destroy(mc); return code; };
     if (hipSetDevice(mc->device) != hipSuccess) return bail(CLC_ERR_HIP);
     mc->is_virtual = world > 1 && !id;      // rehearsal group: no communicator, the caller plays the other ranks (clc_mc_virtual_put)
-    if (world > 1 && id) {
+    if (id) {                                                       // world == 1 with an id: a one-rank communicator (the same RCCL calls as
+                                                                    // world > 1; tests/test_gpu_multicam.py drives the run-time-resolved ABI through it)
         if (!rccl().ok) return bail(CLC_ERR_STATE);                 // no RCCL in this process / on this machine
         ncclUniqueId u;
         memcpy(u.internal, id, CLC_MC_ID_BYTES);
@@ -256,10 +262,10 @@ static int mc_exchange(clc_mc* mc, const void* d_my_desc, int my_count, const in
     const size_t rows = d_my_count ? (size_t)mc->cap : (size_t)my_count;
     if (d_my_count) MC_HIP(mc, hipMemcpyAsync(d_cnt + mc->world, d_my_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     else {
-        h_cnt[mc->world] = my_count;
-        MC_HIP(mc, hipMemcpyAsync(d_cnt + mc->world, h_cnt + mc->world, sizeof(int32_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(mc_set_count_kernel, dim3(1), dim3(1), 0, st, d_cnt + mc->world, (int32_t)my_count);
+        MC_HIP(mc, hipGetLastError());
     }
-    if (mc->world == 1 || mc->is_virtual) {
+    if (!mc->comm) {                                             // one rank without a communicator, or a rehearsal group
         uint8_t* slot = arena + (size_t)mc->rank * block;
         if (rows > 0 && d_my_desc != slot)
             MC_HIP(mc, hipMemcpyAsync(slot, d_my_desc, rows * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
@@ -313,6 +319,15 @@ int clc_mc_gather_enqueue_dev(clc_mc* mc, const void* d_my_desc, int my_count, c
     return mc_exchange(mc, d_my_desc, my_count, d_my_count, mode, st);
 }
 
+int clc_mc_open_peers(clc_mc* mc, void* stream)
+{
+    if (!mc) return CLC_ERR_BAD_ARG;
+    if (!mc->comm && mc->world > 1) return mc_fail(mc, CLC_ERR_STATE, "mc_open_peers: rehearsal handle (no communicator)");
+    MC_HIP(mc, hipSetDevice(mc->device));
+    hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
+    return open_peers(mc, st);
+}
+
 int clc_mc_counts(clc_mc* mc, int* h_counts_out, void* stream)
 {
     if (!mc || !h_counts_out) return mc_fail(mc, CLC_ERR_BAD_ARG, "mc_counts: bad argument");
@@ -335,11 +350,10 @@ int clc_mc_virtual_put(clc_mc* mc, int other_rank, const void* d_desc, int count
     if (count > 0)
         MC_HIP(mc, hipMemcpyAsync(mc->d_arena + ((size_t)mc->fill * (size_t)mc->world + (size_t)other_rank) * block, d_desc,
                                   (size_t)count * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
-    int32_t* h_stage = mc->h_counts + (size_t)mc->fill * (size_t)(mc->world + 1) + mc->world;
-    *h_stage = count;
-    MC_HIP(mc, hipMemcpyAsync(mc->d_counts + (size_t)mc->fill * (size_t)(mc->world + 1) + other_rank, h_stage, sizeof(int32_t),
-                              hipMemcpyHostToDevice, st));
-    MC_HIP(mc, hipStreamSynchronize(st));
+    hipLaunchKernelGGL(mc_set_count_kernel, dim3(1), dim3(1), 0, st, mc->d_counts + (size_t)mc->fill * (size_t)(mc->world + 1) + other_rank,
+                       (int32_t)count);
+    MC_HIP(mc, hipGetLastError());
+    MC_HIP(mc, hipStreamSynchronize(st));                        // a rehearsal entry: on return the "peer's" block has arrived
     return CLC_OK;
 }
 

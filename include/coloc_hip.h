@@ -335,11 +335,16 @@ int clc_mc_plan(const int* counts, int ncams, int world, int rank, int grain, cl
 /* Rank 0 creates the rendezvous id; the HOST application hands it to the other ranks (MPI, a socket, a file ...). */
 int clc_mc_unique_id(uint8_t id[CLC_MC_ID_BYTES]);
 /* Joins the `world`-rank group on ctx's device; maxkp = capacity of a camera's descriptor block (the same on all
- * ranks).  world == 1 needs no id and no RCCL.  world > 1 with id == NULL creates a REHEARSAL handle without a
+ * ranks).  world == 1 needs no id and no RCCL (with an id it builds a one-rank communicator and every exchange goes
+ * through the same RCCL / IPC calls as world > 1).  world > 1 with id == NULL creates a REHEARSAL handle without a
  * communicator: the calling process plays the other ranks with clc_mc_virtual_put (how the one-GPU tests drive every
  * rank's share through this entry); clc_mc_gather_dev then only files the rank's own block. */
 int clc_mc_create(clc_ctx* ctx, const uint8_t id[CLC_MC_ID_BYTES], int world, int rank, int maxkp, clc_mc** out);
 int clc_mc_virtual_put(clc_mc* mc, int other_rank, const void* d_desc, int count, void* stream);
+/* Collective over the group (every rank calls it): exchanges the arenas' IPC handles through the communicator and maps the peers'
+ * arenas, which the first CLC_MC_PEER_COPY exchange would otherwise do.  Calling it up front lets a host learn that the mapping is
+ * not possible on this machine (status != CLC_OK) BEFORE any rank waits in an exchange. */
+int clc_mc_open_peers(clc_mc* mc, void* stream);
 int clc_mc_destroy(clc_mc* mc);
 const char* clc_mc_last_error_string(const clc_mc* mc);
 /* The arena [world][maxkp][64 B] the LAST exchange filled (one of the handle's two buffers: it alternates per exchange). */

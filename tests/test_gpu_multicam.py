@@ -187,3 +187,86 @@ def test_sync_steps_alternate_buffers(oracle):
     assert seen[0] == seen[2] and seen[0] != seen[1]
     mc.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_one_rank_communicator_drives_the_rccl_abi(oracle, mode):
+    """clc_mc_create(world = 1, WITH an id): the run-time-resolved RCCL ABI of multicam.hip (ncclGetUniqueId, ncclCommInitRank with the
+    locally declared 128-byte id passed by value, ncclAllGather with ncclUint8 == 1, ncclCommDestroy) against the box's own librccl, on
+    one GPU.  mode 0 = the RCCL all-gather of block + count, mode 1 = the peer-copy fan-out fenced by the counts' all-gather.  The
+    gathered arena must hold the rank's rows and count, over three enqueue-only steps of different data (both buffers), and a sweep of
+    the gathered block must be the oracle's."""
+    import torch
+    from coloc_amd import Context, MultiCam
+    cap = 2048
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    uid = MultiCam.unique_id()
+    assert len(uid) == 128 and any(uid)
+    mc = MultiCam(ctx, world=1, rank=0, maxkp=cap, unique_id=uid)
+    other = synth.random_descriptors(1500, seed=6100)
+    d_other = torch.from_numpy(other).cuda()
+    st = torch.cuda.Stream()
+    for s, n in enumerate([2048, 1111, 1]):
+        desc = synth.random_descriptors(n, seed=6000 + s)
+        k = min(n, 700)
+        desc[:k] = other[:k]
+        desc[:k, s] ^= 0x81
+        dev = torch.from_numpy(np.ascontiguousarray(np.concatenate([desc, np.full((cap - n, 64), 0x5A, np.uint8)]))).cuda()
+        d_cnt = torch.tensor([n], dtype=torch.int32, device="cuda")
+        if s == 1:
+            mc.gather_enqueue_dev(dev.data_ptr(), 0, mode=mode, stream=st.cuda_stream, d_my_count=d_cnt.data_ptr())
+        else:
+            mc.gather_enqueue_dev(dev.data_ptr(), n, mode=mode, stream=st.cuda_stream)
+        assert mc.match_enqueue_dev(40, 0, 0, stream=st.cuda_stream) == []       # one camera: no pair, nothing to sweep
+        assert mc.counts(stream=st.cuda_stream) == [n]
+        arena = mc.arena()
+        out = torch.full((cap,), -9, dtype=torch.int32, device="cuda")
+        ctx.match_2nn_dev(arena, n, d_other.data_ptr(), len(other), 40, out.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy()[:n], oracle.k2nn(desc, other, 40))
+    mc.close()
+    ctx.close()
+
+
+def test_host_counts_of_four_steps_enqueued_behind_a_backed_up_stream(oracle):
+    """The enqueue-only gather takes the host's count BY VALUE (a one-thread launch): four steps with four different counts are
+    enqueued, without any synchronisation, behind a sweep stream that is deliberately kept busy -- the host is four steps ahead of
+    the device.  (Round 3 staged the count in one pinned word per buffer: steps k and k + 2 share it, and the later count replaced the
+    earlier one before its copy had executed.)  The other rank's block is the same for every step, so it can sit in both buffers."""
+    import torch
+    from coloc_amd import Context, MultiCam
+    world, cap, r = 2, 2000, 0
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    mine = synth.random_descriptors(cap, seed=7000)
+    theirs = synth.random_descriptors(1700, seed=7001)
+    theirs[:900] = mine[:900]
+    theirs[:900, 5] ^= 0x42
+    d_mine = torch.from_numpy(mine).cuda()
+    d_theirs = torch.from_numpy(np.ascontiguousarray(np.concatenate([theirs, np.zeros((cap - len(theirs), 64), np.uint8)]))).cuda()
+    mc = MultiCam(ctx, world=world, rank=r, maxkp=cap)
+    st = torch.cuda.Stream()
+    # the other rank's block into both buffers: put -> gather (flips the buffer) -> put
+    mc.virtual_put(1, d_theirs.data_ptr(), len(theirs), stream=st.cuda_stream)
+    mc.gather_enqueue_dev(d_mine.data_ptr(), 1, mode=0, stream=st.cuda_stream)
+    mc.virtual_put(1, d_theirs.data_ptr(), len(theirs), stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    counts = [2000, 300, 1234, 64]
+    outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in counts]
+    with torch.cuda.stream(st):
+        torch.cuda._sleep(int(2.0e8))                  # ~0.1 s of device time in front of everything that follows
+    shares = []
+    for s, n in enumerate(counts):
+        mc.gather_enqueue_dev(d_mine.data_ptr(), n, mode=s % 2, stream=st.cuda_stream)
+        shares.append(mc.match_enqueue_dev(40, outs[s].data_ptr(), cap * world, stream=st.cuda_stream))
+    assert not st.query()                              # the host really was ahead: nothing of the four steps had finished
+    torch.cuda.synchronize()
+    for s, n in enumerate(counts):
+        want = oracle.k2nn(mine[:n], theirs, 40)
+        res = outs[s].cpu().numpy()
+        for (a, b, q0, nq, off) in shares[s]:
+            assert (a, b) == (0, 1)
+            valid = max(0, min(nq, n - q0))
+            assert np.array_equal(res[off:off + valid], want[q0:q0 + valid]), (s, n)
+            assert (res[off + valid:off + nq] == -1).all()
+    mc.close()
+    ctx.close()
