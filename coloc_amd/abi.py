@@ -48,7 +48,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
@@ -113,6 +113,7 @@ def load_library():
     lib.clc_describe.argtypes = [vp, vp, ci, vp]
     lib.clc_describe_dev.argtypes = [vp, vp, ci, vp, vp]
     lib.clc_describe_batch_dev.argtypes = [vp, ci, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, vp]
+    lib.clc_detect_batch_dev.argtypes = [vp, ci, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, vp]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
     lib.clc_match_2nn_dev.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
@@ -390,6 +391,16 @@ class Context:
         self._chk(self.lib.clc_detect_and_describe(self.h, _p(img), img.shape[1], img.shape[0], _p(kps), _p(desc), cap,
                                                    C.byref(n), C.byref(found)))
         return kps[:n.value], desc[:n.value], found.value
+
+    def detect_batch_dev(self, d_imgs, width, height, pitch, d_kps, d_counts, d_desc=None, stream=None):
+        """Frames of several cameras (lists of device pointers): one pyramid launch, two detector launches and (with d_desc) one
+        CLATCH launch; d_kps[b] holds maxkp keypoints, d_counts[b] a uint32 pair {written, found}, d_desc[b] maxkp x 64 B."""
+        n = len(d_imgs)
+        imgs = (C.c_void_p * n)(*d_imgs)
+        kps = (C.c_void_p * n)(*d_kps)
+        cnt = (C.c_void_p * n)(*d_counts)
+        out = (C.c_void_p * n)(*d_desc) if d_desc is not None else None
+        self._chk(self.lib.clc_detect_batch_dev(self.h, n, imgs, width, height, pitch, kps, cnt, out, stream))
 
     # -- describe
     def describe(self, kps):

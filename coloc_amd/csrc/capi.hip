@@ -97,9 +97,11 @@ struct clc_ctx {
     // detect + describe
     clc_keypoint* d_kps = nullptr;
     uint64_t* d_desc = nullptr;
-    uint8_t* d_score = nullptr;      // arena-shaped FAST score map
-    uint32_t* d_rows = nullptr;      // [row_count | row_off | count(2)]
-    uint32_t total_rows = 0;
+    uint8_t* d_score = nullptr;      // arena-shaped FAST score maps (one per pyramid slot; only keypoint pixels are written and read)
+    uint64_t* d_kpmask = nullptr;    // [slot][tile][16] keypoint bits of a tile row (detect.hip)
+    uint32_t* d_tcount = nullptr;    // [slot][tile] keypoints of a tile
+    uint32_t* d_count = nullptr;     // {written, found} of the context's own keypoint list
+    uint32_t n_tiles = 0;
     bool detected = false;
     // match
     uint8_t* d_q = nullptr;
@@ -247,7 +249,7 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
     *out_ctx = nullptr;
     if (dopts) {
         if (dopts->scale_levels < 1 || dopts->scale_levels > CLC_MAX_LEVELS || dopts->width < 8 || dopts->height < 8 ||
-            !(dopts->scale_factor > 1.0f) || dopts->maxkp == 0)
+            dopts->width > CLC_DETECT_MAX_WIDTH || !(dopts->scale_factor > 1.0f) || dopts->maxkp == 0)
             return CLC_ERR_BAD_ARG;
     }
     if (mopts && mopts->maxkp == 0) return CLC_ERR_BAD_ARG;
@@ -283,9 +285,11 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         CREATE_HIP(hipMalloc((void**)&ctx->d_kps, (size_t)dopts->maxkp * sizeof(clc_keypoint)));
         CREATE_HIP(hipMalloc((void**)&ctx->d_desc, (size_t)dopts->maxkp * CLC_DESC_BYTES));
         CREATE_HIP(hipMalloc((void**)&ctx->d_score, ctx->arena_bytes));
-        ctx->total_rows = detect_total_rows(ctx->pd);
-        CREATE_HIP(hipMalloc((void**)&ctx->d_rows, ((size_t)2 * ctx->total_rows + 4) * sizeof(uint32_t)));
-        CREATE_HIP(hipMemsetAsync(ctx->d_rows, 0, ((size_t)2 * ctx->total_rows + 4) * sizeof(uint32_t), ctx->stream));
+        ctx->n_tiles = detect_total_tiles(ctx->pd);
+        CREATE_HIP(hipMalloc((void**)&ctx->d_kpmask, (size_t)ctx->n_tiles * 16 * sizeof(uint64_t)));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_tcount, (size_t)ctx->n_tiles * sizeof(uint32_t)));
+        CREATE_HIP(hipMalloc((void**)&ctx->d_count, 4 * sizeof(uint32_t)));
+        CREATE_HIP(hipMemsetAsync(ctx->d_count, 0, 4 * sizeof(uint32_t), ctx->stream));
     }
     if (mopts) {
         ctx->has_mat = true;
@@ -318,7 +322,7 @@ int clc_ctx_destroy(clc_ctx* ctx)
     if (!ctx) return CLC_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    void* bufs[] = { ctx->d_arena, ctx->d_kps, ctx->d_desc, ctx->d_score, ctx->d_rows, ctx->d_q, ctx->d_t, ctx->d_m, ctx->d_match,
+    void* bufs[] = { ctx->d_arena, ctx->d_kps, ctx->d_desc, ctx->d_score, ctx->d_kpmask, ctx->d_tcount, ctx->d_count, ctx->d_q, ctx->d_t, ctx->d_m, ctx->d_match,
                      ctx->d_best, ctx->d_second, ctx->d_partial, ctx->d_pnp, ctx->d_pairs };
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -435,7 +439,35 @@ int clc_pyramid_download(clc_ctx* ctx, int level, uint8_t* h_out)
 
 /* ---- detect -------------------------------------------------------------------------------- */
 
-static uint32_t* count_ptr(clc_ctx* ctx) { return ctx->d_rows + (size_t)2 * ctx->total_rows; }
+static uint32_t* count_ptr(clc_ctx* ctx) { return ctx->d_count; }
+
+// room for the pyramids (+ score maps, keypoint masks, tile counts) of n cameras; slot 0 (the current single-image pyramid) does not
+// survive a growth -- every caller rebuilds it
+static int ensure_slots(clc_ctx* ctx, int n, hipStream_t st)
+{
+    if (n <= ctx->arena_slots) return CLC_OK;
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (st != ctx->stream) CLC_HIP(ctx, hipStreamSynchronize(st));
+    uint8_t *arena = nullptr, *score = nullptr;
+    uint64_t* kpmask = nullptr;
+    uint32_t* tcount = nullptr;
+    hipError_t e = hipMalloc((void**)&arena, ctx->arena_bytes * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void**)&score, ctx->arena_bytes * (size_t)n);
+    if (e == hipSuccess) e = hipMalloc((void**)&kpmask, (size_t)n * ctx->n_tiles * 16 * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&tcount, (size_t)n * ctx->n_tiles * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(arena, 0, ctx->arena_bytes * (size_t)n, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        (void)hipFree(arena); (void)hipFree(score); (void)hipFree(kpmask); (void)hipFree(tcount);
+        return fail(ctx, CLC_ERR_HIP, "growing the pyramid arena", e);
+    }
+    ctx->pyramid_valid = false;
+    ctx->detected = false;
+    (void)hipFree(ctx->d_arena); (void)hipFree(ctx->d_score); (void)hipFree(ctx->d_kpmask); (void)hipFree(ctx->d_tcount);
+    ctx->d_arena = arena; ctx->d_score = score; ctx->d_kpmask = kpmask; ctx->d_tcount = tcount;
+    ctx->arena_slots = n;
+    return CLC_OK;
+}
 
 int clc_detect_dev(clc_ctx* ctx, void* stream)
 {
@@ -443,9 +475,50 @@ int clc_detect_dev(clc_ctx* ctx, void* stream)
     if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "detect: context created without detector options");
     if (!ctx->pyramid_valid) return fail(ctx, CLC_ERR_STATE, "detect before pyramid_build");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
-    CLC_HIP(ctx, launch_detect(ctx->pd, ctx->d_arena, ctx->d_score, ctx->dopts.thresh, ctx->dopts.maxkp, ctx->d_rows,
-                               ctx->d_rows + ctx->total_rows, count_ptr(ctx), ctx->d_kps, pick(ctx, stream), &ctx->prof));
+    clc_keypoint* kps[1] = { ctx->d_kps };
+    uint32_t* cnt[1] = { ctx->d_count };
+    CLC_HIP(ctx, launch_detect(ctx->pd, ctx->d_arena, ctx->arena_bytes, 1, ctx->d_score, ctx->d_kpmask, ctx->d_tcount, ctx->dopts.thresh,
+                               ctx->dopts.maxkp, kps, cnt, pick(ctx, stream), &ctx->prof));
     ctx->detected = true;
+    return CLC_OK;
+}
+
+int clc_detect_batch_dev(clc_ctx* ctx, int n_images, const void* const* d_imgs, uint32_t width, uint32_t height, size_t pitch,
+                         clc_keypoint* const* d_kps, uint32_t* const* d_counts, void* const* d_desc, void* stream)
+{
+    if (!ctx || n_images < 0 || (n_images > 0 && (!d_imgs || !d_kps || !d_counts)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "detect_batch: null argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "detect_batch: context created without detector options");
+    if (n_images > CLC_MAX_BATCH) return fail(ctx, CLC_ERR_CAPACITY, "detect_batch: more than CLC_MAX_BATCH images");
+    if (n_images == 0) return CLC_OK;
+    if (width != ctx->dopts.width || height != ctx->dopts.height || pitch < width || pitch > 0xFFFFFFFFull)
+        return fail(ctx, CLC_ERR_BAD_ARG, "detect_batch: image size differs from DetectorOptions width/height");
+    ClatchBatch batch{};
+    const uint8_t* srcs[CLC_MAX_BATCH] = {};
+    const uint32_t* cnts[CLC_MAX_BATCH] = {};
+    for (int b = 0; b < n_images; ++b) {
+        if (!d_imgs[b] || !d_kps[b] || !d_counts[b] || (d_desc && !d_desc[b]))
+            return fail(ctx, CLC_ERR_BAD_ARG, "detect_batch: null image / keypoint / count / descriptor pointer");
+        if (((uintptr_t)d_kps[b] & 3u) || ((uintptr_t)d_counts[b] & 3u) || (d_desc && ((uintptr_t)d_desc[b] & 7u)))
+            return fail(ctx, CLC_ERR_BAD_ARG, "detect_batch: misaligned device pointer");
+        srcs[b] = (const uint8_t*)d_imgs[b];
+        batch.kps[b] = d_kps[b];
+        batch.desc[b] = d_desc ? (uint64_t*)d_desc[b] : nullptr;
+        batch.n[b] = (int)ctx->dopts.maxkp;
+        cnts[b] = d_counts[b];
+    }
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    const int rc = ensure_slots(ctx, n_images, st);
+    if (rc != CLC_OK) return rc;
+    ctx->pyramid_valid = false;
+    CLC_HIP(ctx, launch_pyramid_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, srcs, n_images, (uint32_t)pitch, st, &ctx->prof));
+    ctx->pyramid_valid = true;
+    ctx->detected = false;               // the context's own keypoint list is not the one this call fills
+    CLC_HIP(ctx, launch_detect(ctx->pd, ctx->d_arena, ctx->arena_bytes, n_images, ctx->d_score, ctx->d_kpmask, ctx->d_tcount,
+                               ctx->dopts.thresh, ctx->dopts.maxkp, d_kps, d_counts, st, &ctx->prof));
+    if (d_desc)
+        CLC_HIP(ctx, launch_clatch_counted_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, cnts, n_images, st, &ctx->prof));
     return CLC_OK;
 }
 
@@ -557,19 +630,9 @@ int clc_describe_batch_dev(clc_ctx* ctx, int n_images, const void* const* d_imgs
     }
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    if (n_images > ctx->arena_slots) {
-        // grow the arena to n_images pyramids; slot 0 (the current single-image pyramid) is about to be overwritten anyway
-        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (st != ctx->stream) CLC_HIP(ctx, hipStreamSynchronize(st));
-        uint8_t* grown = nullptr;
-        CLC_HIP(ctx, hipMalloc((void**)&grown, ctx->arena_bytes * (size_t)n_images));
-        hipError_t e = hipMemsetAsync(grown, 0, ctx->arena_bytes * (size_t)n_images, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) { (void)hipFree(grown); return fail(ctx, CLC_ERR_HIP, "describe_batch: arena growth", e); }
-        ctx->pyramid_valid = false;
-        CLC_HIP(ctx, hipFree(ctx->d_arena));
-        ctx->d_arena = grown;
-        ctx->arena_slots = n_images;
+    {
+        const int rc = ensure_slots(ctx, n_images, st);
+        if (rc != CLC_OK) return rc;
     }
     ctx->pyramid_valid = false;
     CLC_HIP(ctx, launch_pyramid_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, srcs, n_images, (uint32_t)pitch, st, &ctx->prof));

@@ -88,7 +88,7 @@ __device__ __forceinline__ u32x2_a4 lds_read8(const uint8_t* p)
 struct ClatchArgs {
     PyramidDesc pd;
     uint32_t slot_stride;                 // bytes between the pyramids of consecutive cameras (blockIdx.y = camera)
-    const uint32_t* n_dev;                // single-camera launches after the GPU detector: keypoint count in device memory
+    const uint32_t* n_dev[kMaxBatch];     // after the GPU detector: a camera's keypoint count in device memory (nullable per camera)
     ClatchBatch cam;
 };
 
@@ -113,7 +113,8 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     const uint32_t cam = blockIdx.y;
     const int n_arg = args.cam.n[cam];
     // keypoint count: a launch argument, or (after the GPU detector) read from device memory
-    const int n = args.n_dev ? min((int)*args.n_dev, n_arg) : n_arg;
+    const uint32_t* __restrict__ n_dev = args.n_dev[cam];
+    const int n = n_dev ? min((int)*n_dev, n_arg) : n_arg;
     const int kp = (int)blockIdx.x;
     if (kp >= n) return;
     __shared__ __attribute__((aligned(16))) uint8_t roi[kWaveLds];
@@ -233,16 +234,16 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
 }
 
 static hipError_t launch_clatch_impl(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
-                                     int n_img, const uint32_t* d_count, hipStream_t stream, Profiler* prof)
+                                     int n_img, const uint32_t* const* d_count, hipStream_t stream, Profiler* prof)
 {
     if (n_img <= 0) return hipSuccess;
     if (n_img > kMaxBatch || slot_stride > 0xFFFFFFFFull) return hipErrorInvalidValue;
     ClatchArgs a;
     a.pd = pd;
     a.slot_stride = (uint32_t)slot_stride;
-    a.n_dev = d_count;
     int max_n = 0;
     for (int b = 0; b < kMaxBatch; ++b) {
+        a.n_dev[b] = (d_count && b < n_img) ? d_count[b] : nullptr;
         a.cam.kps[b] = b < n_img ? batch.kps[b] : nullptr;
         a.cam.desc[b] = b < n_img ? batch.desc[b] : nullptr;
         a.cam.n[b] = b < n_img ? batch.n[b] : 0;
@@ -275,7 +276,13 @@ hipError_t launch_clatch_counted(const PyramidDesc& pd, const uint8_t* arena, co
 {
     ClatchBatch one{};
     one.kps[0] = d_kps; one.desc[0] = d_desc; one.n[0] = max_n;
-    return launch_clatch_impl(pd, arena, 0, one, 1, d_count, stream, prof);
+    return launch_clatch_impl(pd, arena, 0, one, 1, &d_count, stream, prof);
+}
+
+hipError_t launch_clatch_counted_batch(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
+                                       const uint32_t* const* d_count, int n_img, hipStream_t stream, Profiler* prof)
+{
+    return launch_clatch_impl(pd, arena, slot_stride, batch, n_img, d_count, stream, prof);
 }
 
 } // namespace clc

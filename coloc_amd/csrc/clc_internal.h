@@ -50,15 +50,20 @@ hipError_t launch_clatch_batch(const PyramidDesc& pd, const uint8_t* arena, size
                                int n_img, hipStream_t stream, Profiler* prof = nullptr);
 
 // ---- detector (FAST-9 + NMS + orientation) ---------------------------------------------------
-// score: arena-shaped u8 scratch; d_count[0] = keypoints written (<= maxkp), d_count[1] = found.
-hipError_t launch_detect(const PyramidDesc& pd, const uint8_t* arena, uint8_t* score, uint32_t threshold,
-                         uint32_t maxkp, uint32_t* d_row_count, uint32_t* d_row_off, uint32_t* d_count,
-                         clc_keypoint* d_kps, hipStream_t stream, Profiler* prof = nullptr);
-uint32_t detect_total_rows(const PyramidDesc& pd);
+// Two launches for the pyramids of n_img cameras (pyramid b at arena + b * slot_stride, score map b at score + b * slot_stride):
+// d_mask: n_img x detect_total_tiles() x 16 keypoint-mask words, d_tcount: n_img x detect_total_tiles() tile counts (both rewritten
+// by every call: nothing to clear); d_count[b][0] = keypoints written to d_kps[b] (<= maxkp), d_count[b][1] = found.
+hipError_t launch_detect(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, int n_img, uint8_t* score, uint64_t* d_mask,
+                         uint32_t* d_tcount, uint32_t threshold, uint32_t maxkp, clc_keypoint* const* d_kps, uint32_t* const* d_count,
+                         hipStream_t stream, Profiler* prof = nullptr);
+uint32_t detect_total_tiles(const PyramidDesc& pd);
 // CLATCH with the keypoint count read from device memory (no host round trip after detect)
 hipError_t launch_clatch_counted(const PyramidDesc& pd, const uint8_t* arena, const clc_keypoint* d_kps,
                                  const uint32_t* d_count, int max_n, uint64_t* d_desc, hipStream_t stream,
                                  Profiler* prof = nullptr);
+// the same for n_img cameras in one launch: batch.n[b] = capacity of camera b's lists, d_count[b] = its count on the device
+hipError_t launch_clatch_counted_batch(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
+                                       const uint32_t* const* d_count, int n_img, hipStream_t stream, Profiler* prof = nullptr);
 
 // ---- K2NN ------------------------------------------------------------------------------------
 struct K2nnJobDev {

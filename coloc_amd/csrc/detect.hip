@@ -1,5 +1,6 @@
 // detect.hip -- FAST-9 corner detector + 3x3 non-max suppression + intensity-centroid orientation,
-// fully on the GPU, for every pyramid level in one pass.
+// fully on the GPU, for every pyramid level of up to CLC_MAX_BATCH cameras in TWO launches
+// (SURVEY.md 8 row a-8 / f-1).
 //
 // Semantics: reference include/coloc/KFAST.h:164-500 (`KFAST<true,true>`) and
 // include/coloc/FeatureAngle.h:160-246 as called from GPUDetector::detectAndDescribe
@@ -13,184 +14,237 @@
 //     last partial block with (1 << (cols-j-3)) - 1 (:245); when the walk lands exactly on
 //     j == cols-35 the shift count is 32 = a shift by 0 on x86, so the last 32 columns of THAT ROW
 //     are dropped.  Only widths with cols % 16 == 6 can get there (level 6 of a 640-wide pyramid is
-//     214 px wide).  fast_walk_kernel replays the walk for those levels so the output is identical
-//     to the compiled reference (tests compare against oracle/_ref).
+//     214 px wide).  The tiles of such a level that touch its last 35 columns replay the walk for
+//     their own rows first (pre-test bits of the whole row by ballot, then one lane per row walks
+//     them), so the output is identical to the compiled reference (tests compare against oracle/_ref).
 //   * orientation = fastAtan2(sum r*I, sum c*I) over the 37-pixel disc, 7th-order odd polynomial,
 //     fp32 in source order, no FMA contraction.
 //
 // The reference runs this on the CPU after copying every level back to the host and synchronising
-// 8 times per frame (GPUDetector.hpp:262-277); here keypoints never leave HBM: score map -> row
-// counts -> exclusive scan -> ordered emit (+ angle), and CLATCH reads the count from device memory.
+// 8 times per frame (GPUDetector.hpp:262-277); here keypoints never leave HBM.
+//
+// MI355X shape (round 4; round 1's five dependent launches -- score / walk / count / scan / emit, one pixel per thread,
+// one wave per row -- took 40 us of kernels + 4 boundaries for a 640 x 480 frame):
+//   launch A  detect_tile_kernel: one 256-thread workgroup per 64 x 16 tile of a level (all levels, all cameras: ~1000
+//             tiles per 640 x 480 frame).  The tile + 4 px halo is staged into LDS with dword loads; the cardinal
+//             pre-test runs densely over the tile + 1 px border and COMPACTS the survivors (a few % of the pixels) into an
+//             LDS list; the 16-ring test and the corner score then run on that list only, so the expensive path is paid per
+//             candidate, not per wave that holds one; strict 3 x 3 non-max suppression reads the LDS score tile.  Out: one
+//             64-bit keypoint mask per tile row, the tile's keypoint count, and the score byte of each keypoint.
+//   launch B  detect_emit_kernel: one workgroup per 16-row band of a level.  It sums the counts of the tiles in front of
+//             its band (level-major order; <= 13 KB, L2 resident -- no scan launch, no atomics, nothing to re-arm), scans
+//             the band's mask words in (y, x) order and writes the keypoints, orientation included, at their final slots.
 #include "clc_internal.h"
 
 namespace clc {
 
+static constexpr int kTileW = 64, kTileH = 16;
+static constexpr int kImgRows = kTileH + 8, kImgStride = kTileW + 8;        // tile + 3 px ring + 1 px NMS border, each side
+static constexpr int kScRows = kTileH + 2, kScStride = kTileW + 8;          // score tile: column c of the region at byte c + 3
+static constexpr int kRegion = (kTileW + 2) * (kTileH + 2);                 // pixels whose score the tile needs
+static constexpr int kWalkWords = 2 * ((CLC_DETECT_MAX_WIDTH + 63) / 64) + 2; // pre-test bits of a row, as dwords (+ padding)
+
 struct DetectArgs {
     PyramidDesc pd;
-    uint32_t row_begin[CLC_MAX_LEVELS + 1];   // first global row index of each level
-    uint32_t threshold;
-    uint32_t maxkp;
+    uint32_t tile_begin[CLC_MAX_LEVELS + 1];  // first tile of each level (tiles in level, ty, tx order)
+    uint32_t band_begin[CLC_MAX_LEVELS + 1];  // first 16-row band of each level
+    uint32_t tiles_x[CLC_MAX_LEVELS];
+    uint32_t n_tiles, rot;                    // launch A starts at tile `rot` (the first level that replays the walk: its tiles take longest)
+    uint32_t threshold, maxkp;
+    uint32_t slot_stride;                     // bytes between the pyramids / score maps of consecutive cameras
+    clc_keypoint* kps[kMaxBatch];
+    uint32_t* count[kMaxBatch];               // {written, found}
 };
 
-__constant__ const int k_ring_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
-__constant__ const int k_ring_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
-
-__device__ __forceinline__ int level_of_block(const DetectArgs& a, uint32_t blk)
+__device__ __forceinline__ int level_of(const uint32_t* begin, int levels, uint32_t idx)
 {
     int lv = 0;
 #pragma unroll
     for (int i = 1; i < CLC_MAX_LEVELS; ++i)
-        if (i < a.pd.levels && blk >= a.pd.blk_begin[i]) lv = i;
+        if (i < levels && idx >= begin[i]) lv = i;
     return lv;
 }
 
-__device__ __forceinline__ bool fast_pretest(const uint8_t* __restrict__ p, int pitch, int hi, int lo)
+// cardinal pre-test (KFAST.h:230-244): two adjacent of the four compass ring pixels beyond the threshold on the same side
+__device__ __forceinline__ bool pretest4(int c, int p1, int p5, int p9, int p13, int t)
 {
-    const int p9 = p[3 * pitch], p5 = p[3], p1 = p[-3 * pitch], p13 = p[-3];
+    const int hi = min(c + t, 255), lo = max(c - t, 0);
     const bool b = ((p9 > hi) & (p5 > hi)) | ((p5 > hi) & (p1 > hi)) | ((p1 > hi) & (p13 > hi)) | ((p13 > hi) & (p9 > hi));
     const bool d = ((p9 < lo) & (p5 < lo)) | ((p5 < lo) & (p1 < lo)) | ((p1 < lo) & (p13 < lo)) | ((p13 < lo) & (p9 < lo));
     return b | d;
 }
 
-// blk_begin here is rebuilt for the detector: workgroups of 256 pixels over pitch*h bytes of a level
-__global__ __launch_bounds__(256) void fast_score_kernel(const DetectArgs a, const uint8_t* __restrict__ arena,
-                                                         uint8_t* __restrict__ score)
+// ring offsets inside the LDS image tile, relative to the top-left of the pixel's 7 x 7 neighbourhood (all >= 0: immediates)
+#define RING_OFF(k) ((3 + k_dy[k]) * kImgStride + 3 + k_dx[k])
+
+__global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, const uint8_t* __restrict__ arena_base,
+                                                          uint8_t* __restrict__ score_base, uint64_t* __restrict__ mask_base,
+                                                          uint32_t* __restrict__ tcount_base)
 {
-    const int lv = level_of_block(a, blockIdx.x);
+    constexpr int k_dx[16] = { 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1 };
+    constexpr int k_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
+    __shared__ __attribute__((aligned(16))) uint8_t s_img[kImgRows * kImgStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_sc[kScRows * kScStride];
+    __shared__ uint16_t s_cand[kRegion];
+    __shared__ uint32_t s_walk[kScRows][kWalkWords];
+    __shared__ uint32_t s_mask[kTileH][2];
+    __shared__ uint32_t s_drop[kScRows];
+    __shared__ uint32_t s_ncand, s_nkp;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t cam = blockIdx.y;
+    uint32_t tile = blockIdx.x + a.rot;
+    if (tile >= a.n_tiles) tile -= a.n_tiles;
+    const int lv = level_of(a.tile_begin, a.pd.levels, tile);
     const LevelDesc L = a.pd.lv[lv];
-    const uint32_t idx = (blockIdx.x - a.pd.blk_begin[lv]) * 256u + threadIdx.x;
-    if (idx >= L.pitch * L.h) return;
-    const int y = (int)(idx / L.pitch), x = (int)(idx - (uint32_t)y * L.pitch);
-    uint8_t out = 0;
+    const uint32_t tl = tile - a.tile_begin[lv];
+    const int ty = (int)(tl / a.tiles_x[lv]), tx = (int)(tl - (uint32_t)ty * a.tiles_x[lv]);
+    const int x0 = tx * kTileW, y0 = ty * kTileH;
     const int cols = (int)L.w, rows = (int)L.h, pitch = (int)L.pitch;
-    if (x >= 3 && x < cols - 3 && y >= 3 && y < rows - 3) {
-        const uint8_t* __restrict__ p = arena + L.offset + (size_t)y * pitch + x;
-        const int c = *p;
-        const int t = (int)a.threshold;
-        const int hi = min(c + t, 255), lo = max(c - t, 0);
-        if (fast_pretest(p, pitch, hi, lo)) {
-            int ring[16];
-            uint32_t bm = 0, dm = 0;
+    const int t = (int)a.threshold;
+    const uint8_t* __restrict__ img = arena_base + (size_t)cam * a.slot_stride + L.offset;
+
+    // ---- stage the tile (+ 4 px halo) and clear the work areas ---------------------------------
+    for (uint32_t i = tid; i < (uint32_t)(kImgRows * (kImgStride / 4)); i += 256u) {
+        const int r = (int)(i / (kImgStride / 4)), d = (int)(i - (uint32_t)r * (kImgStride / 4));
+        const int gy = y0 - 4 + r, gx = x0 - 4 + 4 * d;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < rows && gx >= 0 && gx < pitch) v = *reinterpret_cast<const uint32_t*>(img + (size_t)gy * pitch + gx);
+        reinterpret_cast<uint32_t*>(s_img)[i] = v;
+    }
+    for (uint32_t i = tid; i < (uint32_t)(kScRows * kScStride / 4); i += 256u) reinterpret_cast<uint32_t*>(s_sc)[i] = 0u;
+    if (tid < (uint32_t)kTileH * 2u) s_mask[tid >> 1][tid & 1u] = 0u;
+    if (tid < (uint32_t)kScRows) s_drop[tid] = 0u;
+    if (tid == 0) { s_ncand = 0u; s_nkp = 0u; }
+
+    // ---- KFAST.h:245 replay: does the walk of row gy land on cols - 35?  (levels of width 6 mod 16, tiles at the right end)
+    const bool walk = (cols % 16 == 6) && cols >= 38 && (x0 + kTileW + 1 >= cols - 35);
+    if (walk) {
+        const int nbits = cols - 7;                         // pre-test bits of columns 3 .. cols - 5
+        const int nchunks = (nbits + 63) >> 6;
+        for (int r = (int)wave; r < kScRows; r += 4) {
+            const int gy = y0 - 1 + r;
+            const bool row_ok = gy >= 3 && gy < rows - 3;
+            const uint8_t* __restrict__ prow = img + (size_t)(row_ok ? gy : 3) * pitch;
+            for (int c = 0; c < nchunks; ++c) {
+                const int x = 3 + 64 * c + (int)lane;
+                bool pre = false;
+                if (row_ok && x <= cols - 5) {
+                    const uint8_t* p = prow + x;
+                    pre = pretest4(p[0], p[-3 * pitch], p[3], p[3 * pitch], p[-3], t);
+                }
+                const uint64_t m = __ballot(pre);
+                if (lane == 0) { s_walk[r][2 * c] = (uint32_t)m; s_walk[r][2 * c + 1] = (uint32_t)(m >> 32); }
+            }
+            if (lane == 0) { s_walk[r][2 * nchunks] = 0u; s_walk[r][2 * nchunks + 1] = 0u; }
+        }
+        __syncthreads();
+        if (tid < (uint32_t)kScRows) {
+            const int gy = y0 - 1 + (int)tid;
+            if (gy >= 3 && gy < rows - 3) {
+                int j = 3;
+                while (j < cols - 35) {
+                    const int bit = j - 3;                  // a multiple of 16
+                    const uint32_t lo = s_walk[tid][bit >> 5], hi = s_walk[tid][(bit >> 5) + 1];
+                    const uint32_t m = (bit & 16) ? ((lo >> 16) | (hi << 16)) : lo;
+                    j += (m != 0u && (m & 0xFFFFu) == 0u) ? 16 : 32;
+                }
+                s_drop[tid] = (j == cols - 35) ? 1u : 0u;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: dense cardinal pre-test over the tile + 1 px border, survivors compacted into s_cand ----
+    for (uint32_t i0 = 0; i0 < (uint32_t)kRegion; i0 += 256u) {
+        const uint32_t i = i0 + tid;
+        const int r = (int)(i / (kTileW + 2)), c = (int)(i - (uint32_t)r * (kTileW + 2));
+        const int gx = x0 - 1 + c, gy = y0 - 1 + r;
+        bool pre = false;
+        if (i < (uint32_t)kRegion && gx >= 3 && gx < cols - 3 && gy >= 3 && gy < rows - 3 && !(s_drop[r] && gx >= cols - 35)) {
+            const uint8_t* p = s_img + (r + 3) * kImgStride + (c + 3);
+            pre = pretest4(p[0], p[-3 * kImgStride], p[3], p[3 * kImgStride], p[-3], t);
+        }
+        const uint64_t m = __ballot(pre);
+        if (m != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (pre) s_cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((r << 8) | c);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: 16-ring test + corner score, one candidate per lane ---------------------------
+    const uint32_t ncand = s_ncand;
+    for (uint32_t i = tid; i < ncand; i += 256u) {
+        const uint32_t rc = s_cand[i];
+        const int r = (int)(rc >> 8), c = (int)(rc & 0xFFu);
+        const uint8_t* q = s_img + r * kImgStride + c;         // top-left of the 7 x 7 neighbourhood
+        const int ctr = q[3 * kImgStride + 3];
+        const int hi = min(ctr + t, 255), lo = max(ctr - t, 0);
+        int ring[16];
+        uint32_t bm = 0, dm = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ring[k] = q[RING_OFF(k)];
+            bm |= (ring[k] > hi ? 1u : 0u) << k;
+            dm |= (ring[k] < lo ? 1u : 0u) << k;
+        }
+        // >= 9 contiguous set bits on the 16-cycle
+        const uint32_t xb = bm | (bm << 16), xd = dm | (dm << 16);
+        uint32_t rb = xb & (xb >> 1); rb &= rb >> 2; rb &= rb >> 4; rb &= xb >> 8;
+        uint32_t rd = xd & (xd >> 1); rd &= rd >> 2; rd &= rd >> 4; rd &= xd >> 8;
+        if (((rb | rd) & 0xFFFFu) != 0u) {
+            // corner score (KFAST.h:300-374): max over the 16 arcs of 9 of max(min(c - ring), -max(c - ring)).
+            // min / max over 9 consecutive = (pairs -> fours -> eights) + one more, shared between neighbouring arcs
+            int v[16], mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = ctr - ring[k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { mn2[k] = min(v[k], v[(k + 1) & 15]); mx2[k] = max(v[k], v[(k + 1) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { mn4[k] = min(mn2[k], mn2[(k + 2) & 15]); mx4[k] = max(mx2[k], mx2[(k + 2) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { mn8[k] = min(mn4[k], mn4[(k + 4) & 15]); mx8[k] = max(mx4[k], mx4[(k + 4) & 15]); }
+            int best = -32768;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                ring[k] = p[k_ring_dy[k] * pitch + k_ring_dx[k]];
-                bm |= (ring[k] > hi ? 1u : 0u) << k;
-                dm |= (ring[k] < lo ? 1u : 0u) << k;
+                const int mn = min(mn8[k], v[(k + 8) & 15]), mx = max(mx8[k], v[(k + 8) & 15]);
+                best = max(best, max(mn, -mx));
             }
-            // >= 9 contiguous set bits on the 16-cycle
-            uint32_t xb = bm | (bm << 16), xd = dm | (dm << 16);
-            uint32_t rb = xb & (xb >> 1); rb &= rb >> 2; rb &= rb >> 4; rb &= xb >> 8;
-            uint32_t rd = xd & (xd >> 1); rd &= rd >> 2; rd &= rd >> 4; rd &= xd >> 8;
-            if (((rb | rd) & 0xFFFFu) != 0u) {
-                // corner score: max over the 16 arcs of 9 of max(min(c - ring), -max(c - ring))
-                int v[24];
-#pragma unroll
-                for (int k = 0; k < 24; ++k) v[k] = c - ring[k & 15];
-                int best = -32768;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    int mn = v[s], mx = v[s];
-#pragma unroll
-                    for (int k = 1; k < 9; ++k) { mn = min(mn, v[s + k]); mx = max(mx, v[s + k]); }
-                    best = max(best, max(mn, -mx));
-                }
-                out = (uint8_t)best;
-            }
+            s_sc[r * kScStride + c + 3] = (uint8_t)best;
         }
     }
-    score[L.offset + idx] = out;
-}
-
-// One wave per row of a level whose width is 6 (mod 16): replay the reference's 32-column walk
-// (KFAST.h:447-455, 259-265) and drop the last 32 columns when it lands on cols-35.
-__global__ __launch_bounds__(64) void fast_walk_kernel(const DetectArgs a, const int lv, const uint8_t* __restrict__ arena,
-                                                       uint8_t* __restrict__ score)
-{
-    const LevelDesc L = a.pd.lv[lv];
-    const int cols = (int)L.w, rows = (int)L.h, pitch = (int)L.pitch;
-    const int y = 3 + (int)blockIdx.x;
-    if (y >= rows - 3) return;
-    const int lane = (int)threadIdx.x;
-    const uint8_t* __restrict__ row = arena + L.offset + (size_t)y * pitch;
-    const int t = (int)a.threshold;
-    int j = 3;
-    while (j < cols - 35) {
-        bool pre = false;
-        if (lane < 32) {
-            const uint8_t* p = row + j + lane;
-            const int c = *p;
-            pre = fast_pretest(p, pitch, min(c + t, 255), max(c - t, 0));
-        }
-        const uint32_t m = (uint32_t)__ballot(pre);
-        if (m != 0u && (m & 0xFFFFu) == 0u) j += 16; else j += 32;
-    }
-    if (j == cols - 35) {
-        uint8_t* s = score + L.offset + (size_t)y * pitch;
-        if (lane < 32) s[cols - 35 + lane] = 0;
-    }
-}
-
-__device__ __forceinline__ bool is_keypoint(const uint8_t* __restrict__ s, int pitch, int x, int y, int cols, int rows)
-{
-    if (x < 3 || x >= cols - 3 || y < 3 || y >= rows - 3) return false;
-    const uint8_t* p = s + (size_t)y * pitch + x;
-    const int sc = *p;
-    if (sc == 0) return false;
-    return (sc > p[-1]) & (sc > p[1]) & (sc > p[-pitch - 1]) & (sc > p[-pitch]) & (sc > p[-pitch + 1]) &
-           (sc > p[pitch - 1]) & (sc > p[pitch]) & (sc > p[pitch + 1]);
-}
-
-__device__ __forceinline__ int level_of_row(const DetectArgs& a, uint32_t grow)
-{
-    int lv = 0;
-#pragma unroll
-    for (int i = 1; i < CLC_MAX_LEVELS; ++i)
-        if (i < a.pd.levels && grow >= a.row_begin[i]) lv = i;
-    return lv;
-}
-
-// pass A: keypoints per row (one wave per row, rows of all levels concatenated)
-__global__ __launch_bounds__(64) void nms_count_kernel(const DetectArgs a, const uint8_t* __restrict__ score,
-                                                       uint32_t* __restrict__ row_count)
-{
-    const uint32_t grow = blockIdx.x;
-    const int lv = level_of_row(a, grow);
-    const LevelDesc L = a.pd.lv[lv];
-    const int y = (int)(grow - a.row_begin[lv]);
-    const uint8_t* __restrict__ s = score + L.offset;
-    uint32_t cnt = 0;
-    for (int x0 = 0; x0 < (int)L.w; x0 += 64) {
-        const bool k = is_keypoint(s, (int)L.pitch, x0 + (int)threadIdx.x, y, (int)L.w, (int)L.h);
-        cnt += (uint32_t)__popcll(__ballot(k));
-    }
-    if (threadIdx.x == 0) row_count[grow] = cnt;
-}
-
-// pass B: exclusive scan over the rows (single workgroup; <= a few thousand rows), total -> count[0..1]
-__global__ __launch_bounds__(1024) void row_scan_kernel(const uint32_t nrows, const uint32_t* __restrict__ row_count,
-                                                        uint32_t* __restrict__ row_off, uint32_t* __restrict__ count,
-                                                        const uint32_t maxkp)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t per = (nrows + 1023u) / 1024u;
-    const uint32_t r0 = threadIdx.x * per, r1 = min(r0 + per, nrows);
-    uint32_t s = 0;
-    for (uint32_t r = r0; r < r1; ++r) s += row_count[r];
-    part[threadIdx.x] = s;
     __syncthreads();
-    for (uint32_t st = 1; st < 1024u; st <<= 1) {
-        const uint32_t v = threadIdx.x >= st ? part[threadIdx.x - st] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+
+    // ---- strict 3 x 3 non-max suppression of the tile's own 64 x 16 pixels (thread = 4 pixels of a row) ----
+    {
+        const int r = (int)(tid >> 4) + 1, d = (int)(tid & 15u);               // region row 1..16, dword d of the interior
+        const uint8_t* srow = s_sc + r * kScStride + 4 + 4 * d;                 // region column c = 1 + 4 d sits at byte c + 3
+        const uint32_t four = *reinterpret_cast<const uint32_t*>(srow);
+        if (four != 0u) {
+            uint8_t* __restrict__ gscore = score_base + (size_t)cam * a.slot_stride + L.offset;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sc = (int)((four >> (8 * k)) & 0xFFu);
+                if (sc == 0) continue;
+                const uint8_t* p = srow + k;
+                const bool kp = (sc > p[-1]) & (sc > p[1]) & (sc > p[-kScStride - 1]) & (sc > p[-kScStride]) & (sc > p[-kScStride + 1]) &
+                                (sc > p[kScStride - 1]) & (sc > p[kScStride]) & (sc > p[kScStride + 1]);
+                if (kp) {
+                    const int xl = 4 * d + k;                                   // column inside the tile
+                    atomicOr(&s_mask[r - 1][xl >> 5], 1u << (xl & 31));
+                    atomicAdd(&s_nkp, 1u);
+                    gscore[(size_t)(y0 + r - 1) * pitch + x0 + xl] = (uint8_t)sc;
+                }
+            }
+        }
     }
-    uint32_t run = part[threadIdx.x] - s;
-    for (uint32_t r = r0; r < r1; ++r) { row_off[r] = run; run += row_count[r]; }
-    if (threadIdx.x == 1023u) {
-        const uint32_t total = part[1023];
-        count[0] = min(total, maxkp);   // keypoints written (level-major order, truncated at capacity)
-        count[1] = total;               // keypoints found
-    }
+    __syncthreads();
+    if (tid < (uint32_t)kTileH)
+        mask_base[((size_t)cam * a.n_tiles + tile) * kTileH + tid] = (uint64_t)s_mask[tid][0] | ((uint64_t)s_mask[tid][1] << 32);
+    if (tid == 0) tcount_base[(size_t)cam * a.n_tiles + tile] = s_nkp;
 }
 
 // include/coloc/FeatureAngle.h:160-177
@@ -213,85 +267,143 @@ __device__ __forceinline__ float fast_atan2(const float y, const float x)
     return r;
 }
 
-// pass C: ordered emit + orientation (FeatureAngle.h:179-246: rows of 3,5,7,7,7,5,3 pixels)
-__global__ __launch_bounds__(64) void nms_emit_kernel(const DetectArgs a, const uint8_t* __restrict__ arena,
-                                                      const uint8_t* __restrict__ score,
-                                                      const uint32_t* __restrict__ row_off, clc_keypoint* __restrict__ kps)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane)
 {
-    const uint32_t grow = blockIdx.x;
-    const int lv = level_of_row(a, grow);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)v, s);
+        if (lane >= (uint32_t)s) v += o;
+    }
+    return v;
+}
+
+// One workgroup per 16-row band: slots of its keypoints = (keypoints of all tiles in front of the band) + scan of the band's
+// mask words in (y, x) order; orientation per keypoint (FeatureAngle.h:179-246: rows of 3,5,7,7,7,5,3 pixels).
+__global__ __launch_bounds__(256) void detect_emit_kernel(const DetectArgs a, const uint8_t* __restrict__ arena_base,
+                                                          const uint8_t* __restrict__ score_base, const uint64_t* __restrict__ mask_base,
+                                                          const uint32_t* __restrict__ tcount_base)
+{
+    __shared__ uint32_t s_part[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t cam = blockIdx.y, band = blockIdx.x;
+    const int lv = level_of(a.band_begin, a.pd.levels, band);
     const LevelDesc L = a.pd.lv[lv];
-    const int y = (int)(grow - a.row_begin[lv]);
-    const uint8_t* __restrict__ s = score + L.offset;
-    const uint8_t* __restrict__ img = arena + L.offset;
-    uint32_t base = row_off[grow];
-    for (int x0 = 0; x0 < (int)L.w; x0 += 64) {
-        const int x = x0 + (int)threadIdx.x;
-        const bool k = is_keypoint(s, (int)L.pitch, x, y, (int)L.w, (int)L.h);
-        const uint64_t m = __ballot(k);
-        if (k) {
-            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << threadIdx.x) - 1ull));
+    const uint32_t ty = band - a.band_begin[lv], ntx = a.tiles_x[lv];
+    const uint32_t t0 = a.tile_begin[lv] + ty * ntx;
+    const uint32_t* __restrict__ tcount = tcount_base + (size_t)cam * a.n_tiles;
+    const uint64_t* __restrict__ mask = mask_base + (size_t)cam * a.n_tiles * kTileH;
+    const uint8_t* __restrict__ img = arena_base + (size_t)cam * a.slot_stride + L.offset;
+    const uint8_t* __restrict__ score = score_base + (size_t)cam * a.slot_stride + L.offset;
+    clc_keypoint* __restrict__ kps = a.kps[cam];
+
+    // this thread's first mask word (loaded before the reduction so that both latencies overlap)
+    const uint32_t nwords = (uint32_t)kTileH * ntx;
+    uint32_t r0 = tid / ntx, tx0 = tid - r0 * ntx;
+    uint64_t m = tid < nwords ? mask[(size_t)(t0 + tx0) * kTileH + r0] : 0ull;
+
+    uint32_t s = 0;
+    for (uint32_t i = tid; i < t0; i += 256u) s += tcount[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o);
+    if (lane == 0) s_part[wave] = s;
+    __syncthreads();
+    uint32_t carry = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    __syncthreads();
+
+    for (uint32_t w0 = 0; w0 < nwords; w0 += 256u) {
+        const uint32_t i = w0 + tid;
+        uint32_t r = r0, tx = tx0;
+        if (w0) {
+            r = i / ntx; tx = i - r * ntx;
+            m = i < nwords ? mask[(size_t)(t0 + tx) * kTileH + r] : 0ull;
+        }
+        const uint32_t c = (uint32_t)__popcll(m);
+        const uint32_t inc = wave_inclusive_scan(c, lane);
+        if (lane == 63u) s_part[wave] = inc;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wave; ++w) before += s_part[w];
+        const uint32_t total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        __syncthreads();
+        uint32_t slot = before + inc - c;
+        const int y = (int)(ty * kTileH + r);
+        while (m != 0ull) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1ull;
             if (slot < a.maxkp) {
+                const int x = (int)(tx * kTileW) + b;
                 int xs = 0, ys = 0;
 #pragma unroll
-                for (int r = -3; r <= 3; ++r) {
-                    const int hw = (r == -3 || r == 3) ? 1 : ((r == -2 || r == 2) ? 2 : 3);
-                    const uint8_t* q = img + (size_t)(y + r) * L.pitch + x;
+                for (int rr = -3; rr <= 3; ++rr) {
+                    const int hw = (rr == -3 || rr == 3) ? 1 : ((rr == -2 || rr == 2) ? 2 : 3);
+                    const uint8_t* q = img + (size_t)(y + rr) * L.pitch + x;
 #pragma unroll
-                    for (int c = -3; c <= 3; ++c) {
-                        if (c < -hw || c > hw) continue;
-                        const int v = q[c];
-                        xs += c * v;
-                        ys += r * v;
+                    for (int cc = -3; cc <= 3; ++cc) {
+                        if (cc < -hw || cc > hw) continue;
+                        const int v = q[cc];
+                        xs += cc * v;
+                        ys += rr * v;
                     }
                 }
                 clc_keypoint kp;
                 kp.x = x; kp.y = y;
-                kp.score = s[(size_t)y * L.pitch + x];
+                kp.score = score[(size_t)y * L.pitch + x];
                 kp.angle = fast_atan2((float)(int16_t)ys, (float)(int16_t)xs);
                 kp.scale = (uint8_t)lv;
                 kps[slot] = kp;
             }
+            ++slot;
         }
-        base += (uint32_t)__popcll(m);
+        carry += total;
+    }
+    // the last band of the camera knows the total
+    if (tid == 0 && lv == a.pd.levels - 1 && band + 1 == a.band_begin[a.pd.levels]) {
+        a.count[cam][0] = min(carry, a.maxkp);   // keypoints written (level-major order, truncated at capacity)
+        a.count[cam][1] = carry;                 // keypoints found
     }
 }
 
-hipError_t launch_detect(const PyramidDesc& pd, const uint8_t* arena, uint8_t* score, uint32_t threshold,
-                         uint32_t maxkp, uint32_t* d_row_count, uint32_t* d_row_off, uint32_t* d_count,
-                         clc_keypoint* d_kps, hipStream_t stream, Profiler* prof)
+uint32_t detect_total_tiles(const PyramidDesc& pd)
 {
+    uint32_t n = 0;
+    for (int i = 0; i < pd.levels; ++i) n += ((pd.lv[i].w + kTileW - 1) / kTileW) * ((pd.lv[i].h + kTileH - 1) / kTileH);
+    return n;
+}
+
+hipError_t launch_detect(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, int n_img, uint8_t* score, uint64_t* d_mask,
+                         uint32_t* d_tcount, uint32_t threshold, uint32_t maxkp, clc_keypoint* const* d_kps, uint32_t* const* d_count,
+                         hipStream_t stream, Profiler* prof)
+{
+    if (n_img <= 0) return hipSuccess;
+    if (n_img > kMaxBatch || slot_stride > 0xFFFFFFFFull) return hipErrorInvalidValue;
     DetectArgs a;
     a.pd = pd;
     a.threshold = threshold & 0xFFu;
     a.maxkp = maxkp;
-    uint32_t blk = 0, rows = 0;
+    a.slot_stride = (uint32_t)slot_stride;
+    uint32_t tiles = 0, bands = 0;
+    a.rot = 0;
+    bool rot_set = false;
     for (int i = 0; i < pd.levels; ++i) {
-        a.pd.blk_begin[i] = blk;
-        blk += (pd.lv[i].pitch * pd.lv[i].h + 255u) / 256u;
-        a.row_begin[i] = rows;
-        rows += pd.lv[i].h;
+        if (pd.lv[i].w > CLC_DETECT_MAX_WIDTH) return hipErrorInvalidValue;
+        a.tile_begin[i] = tiles;
+        a.band_begin[i] = bands;
+        a.tiles_x[i] = (pd.lv[i].w + kTileW - 1) / kTileW;
+        const uint32_t tiles_y = (pd.lv[i].h + kTileH - 1) / kTileH;
+        if (!rot_set && pd.lv[i].w % 16u == 6u && pd.lv[i].w >= 38u) { a.rot = tiles; rot_set = true; }
+        tiles += a.tiles_x[i] * tiles_y;
+        bands += tiles_y;
     }
-    for (int i = pd.levels; i <= CLC_MAX_LEVELS; ++i) { a.pd.blk_begin[i] = blk; a.row_begin[i] = rows; }
+    for (int i = pd.levels; i <= CLC_MAX_LEVELS; ++i) { a.tile_begin[i] = tiles; a.band_begin[i] = bands; if (i < CLC_MAX_LEVELS) a.tiles_x[i] = 1; }
+    a.n_tiles = tiles;
+    for (int b = 0; b < kMaxBatch; ++b) { a.kps[b] = b < n_img ? d_kps[b] : nullptr; a.count[b] = b < n_img ? d_count[b] : nullptr; }
+    if (tiles == 0) return hipSuccess;
     prof_mark(prof, CLC_KERNEL_DETECT, true, stream);
-    hipLaunchKernelGGL(fast_score_kernel, dim3(blk), dim3(256), 0, stream, a, arena, score);
-    for (int i = 0; i < pd.levels; ++i)
-        if (pd.lv[i].w % 16u == 6u && pd.lv[i].h > 6u)
-            hipLaunchKernelGGL(fast_walk_kernel, dim3(pd.lv[i].h - 6u), dim3(64), 0, stream, a, i, arena, score);
-    hipLaunchKernelGGL(nms_count_kernel, dim3(rows), dim3(64), 0, stream, a, (const uint8_t*)score, d_row_count);
-    hipLaunchKernelGGL(row_scan_kernel, dim3(1), dim3(1024), 0, stream, rows, (const uint32_t*)d_row_count, d_row_off,
-                       d_count, maxkp);
-    hipLaunchKernelGGL(nms_emit_kernel, dim3(rows), dim3(64), 0, stream, a, arena, (const uint8_t*)score,
-                       (const uint32_t*)d_row_off, d_kps);
+    hipLaunchKernelGGL(detect_tile_kernel, dim3(tiles, (uint32_t)n_img), dim3(256), 0, stream, a, arena, score, d_mask, d_tcount);
+    hipLaunchKernelGGL(detect_emit_kernel, dim3(bands, (uint32_t)n_img), dim3(256), 0, stream, a, arena, (const uint8_t*)score,
+                       (const uint64_t*)d_mask, (const uint32_t*)d_tcount);
     prof_mark(prof, CLC_KERNEL_DETECT, false, stream);
     return hipGetLastError();
-}
-
-uint32_t detect_total_rows(const PyramidDesc& pd)
-{
-    uint32_t rows = 0;
-    for (int i = 0; i < pd.levels; ++i) rows += pd.lv[i].h;
-    return rows;
 }
 
 } // namespace clc

@@ -39,7 +39,8 @@ extern "C" {
 #define CLC_ABI_VERSION 1
 #define CLC_DESC_BYTES 64
 #define CLC_MAX_LEVELS 8
-#define CLC_MAX_BATCH 8    /* cameras per clc_describe_batch_dev call */
+#define CLC_MAX_BATCH 8    /* cameras per clc_describe_batch_dev / clc_detect_batch_dev call */
+#define CLC_DETECT_MAX_WIDTH 4096   /* widest image the GPU detector takes (its row-walk replay keeps a row's pre-test bits in LDS) */
 
 /* status codes */
 enum {
@@ -164,6 +165,16 @@ int clc_describe_detected_dev(clc_ctx* ctx, void* d_desc, void* stream);
  * upload image -> pyramid -> detect -> describe -> download keypoints + descriptors. */
 int clc_detect_and_describe(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32_t height,
                             clc_keypoint* h_kps, uint8_t* h_desc, int capacity, int* n_written, int* n_found);
+
+/* The device-resident front end for the frames of n_images <= CLC_MAX_BATCH cameras at once (GPUDetector::detectAndDescribe,
+ * GPUDetector.hpp:216-291, once per drone in ColoC::processImages, coloc.hpp:150-163): ONE pyramid launch, TWO detector launches
+ * and -- when d_desc is not NULL -- ONE CLATCH launch for all of them, nothing synchronised, nothing copied back.  d_imgs[b]: u8
+ * width x height device image (pitch bytes per row, the DetectorOptions size); d_kps[b]: room for DetectorOptions.maxkp keypoints;
+ * d_counts[b]: uint32[2] on the device, {written, found}; d_desc[b]: maxkp x 64 B (rows past the count are left alone).  Same
+ * keypoints, order and descriptors as n_images times clc_pyramid_build_dev + clc_detect_dev + clc_describe_detected_dev.  The
+ * pointer arrays themselves are host memory.  Afterwards camera 0's pyramid is the context's current one. */
+int clc_detect_batch_dev(clc_ctx* ctx, int n_images, const void* const* d_imgs, uint32_t width, uint32_t height, size_t pitch,
+                         clc_keypoint* const* d_kps, uint32_t* const* d_counts, void* const* d_desc, void* stream);
 
 /* ---- describe: replaces CLATCH() (CLATCH.h:168) + GPUDetector.hpp:280-290 ------------------ */
 

@@ -97,3 +97,69 @@ def test_detect_and_describe_front_end(oracle):
     assert same_kps(kps, want) and found == len(want)
     assert np.array_equal(desc, oracle.clatch(pyr, want))
     ctx.close()
+
+
+@pytest.mark.parametrize("W,H", [(38, 40), (22, 30), (54, 33), (70, 17), (134, 50), (64, 16), (65, 17), (129, 48), (198, 64), (1286, 40)])
+def test_small_and_edge_sizes(oracle, W, H):
+    """Single level at widths around the tile size (64) and at widths 6 (mod 16) -- 38 is the narrowest image whose walk can land on
+    cols - 35 (every row does, at once), 1286 makes the replay cross many 64-column chunks -- against the oracle (which is pinned to the
+    compiled reference): a noisy checkerboard so that corners sit everywhere, borders and tile seams included."""
+    from coloc_amd import Context
+    from test_oracle_clatch import edge_image
+    img = edge_image(W, H)
+    ctx = Context(device=0, width=W, height=H, maxkp=30000, scale_levels=1)
+    ctx.pyramid_build(img)
+    kps, found = ctx.detect()
+    want = oracle.fast9(img, 40)
+    assert found == len(want)
+    assert np.array_equal(kps["x"], want["x"]) and np.array_equal(kps["y"], want["y"]) and np.array_equal(kps["score"], want["score"])
+    ctx.close()
+
+
+def test_dense_corners_every_tile(oracle):
+    """A frame where a large share of the pixels pass the pre-test (salt-and-pepper noise): the candidate lists of the tiles run long
+    (several passes of the ring stage), all 8 levels."""
+    from coloc_amd import Context
+    W, H = 640, 480
+    rng = np.random.default_rng(77)
+    img = rng.integers(90, 110, size=(H, W)).astype(np.uint8)
+    m = rng.random((H, W))
+    img[m < 0.04] = 255
+    img[m > 0.96] = 0
+    ctx = Context(device=0, width=W, height=H, maxkp=200000)
+    ctx.pyramid_build(img)
+    kps, found = ctx.detect()
+    _, want = oracle_detect(oracle, img)
+    assert found == len(want) and len(want) > 5000
+    assert same_kps(kps, want)
+    ctx.close()
+
+
+@pytest.mark.parametrize("W,H,n", [(640, 480, 4), (214, 161, 8), (1280, 720, 2)])
+def test_detect_batch_equals_single_camera_calls(oracle, W, H, n):
+    """clc_detect_batch_dev (one pyramid launch, two detector launches, one CLATCH launch for n cameras) == the oracle's
+    detect -> describe of every frame: keypoints, order, counts, descriptors.  A second call with the frames in another order reuses
+    the buffers (stale masks / counts of the call before must not leak)."""
+    import torch
+    from coloc_amd import Context
+    from coloc_amd.abi import KP_DTYPE
+    cap = 12000
+    ctx = Context(device=0, width=W, height=H, maxkp=cap)
+    imgs = [synth.rect_image(W, H, seed=1200 + c, noise_sigma=2.0 + c) for c in range(n)]
+    want = [oracle_detect(oracle, im) for im in imgs]
+    d_kps = [torch.zeros((cap, 20), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    d_cnt = [torch.zeros((2,), dtype=torch.int32, device="cuda") for _ in range(n)]
+    d_desc = [torch.zeros((cap, 64), dtype=torch.uint8, device="cuda") for _ in range(n)]
+    for order in (list(range(n)), list(reversed(range(n)))):
+        d_imgs = [torch.from_numpy(imgs[c]).cuda() for c in order]
+        ctx.detect_batch_dev([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [t.data_ptr() for t in d_cnt],
+                             [t.data_ptr() for t in d_desc])
+        ctx.sync()
+        for b, c in enumerate(order):
+            pyr, w = want[c]
+            cnt = d_cnt[b].cpu().numpy()
+            assert cnt[0] == min(len(w), cap) and cnt[1] == len(w)
+            kps = d_kps[b].cpu().numpy().reshape(-1).view(KP_DTYPE)[:cnt[0]]
+            assert same_kps(kps, w[:cnt[0]])
+            assert np.array_equal(d_desc[b].cpu().numpy()[:cnt[0]], oracle.clatch(pyr, w[:cnt[0]]))
+    ctx.close()

@@ -138,6 +138,31 @@ def test_fast9_width_quirk(oracle, ref_feeder):
         assert (len(a) > 0) == expect_any and len(a) == len(b)
 
 
+def edge_image(W, H):
+    """the noisy checkerboard of tests/test_gpu_detect.py::test_small_and_edge_sizes"""
+    rng = np.random.default_rng(W * 1000 + H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = (((yy // 5 + xx // 7) % 2) * 150 + 40 + rng.integers(0, 25, size=(H, W))).astype(np.uint8)
+    img[rng.random((H, W)) < 0.02] = 255
+    return img
+
+
+def test_fast9_edge_sizes_match_compiled_reference(oracle, ref_feeder):
+    """The sizes the GPU detector is tested at around its tile seams and at widths 6 (mod 16) (38 = the narrowest image whose row walk
+    lands on cols - 35): the restatement == the compiled reference there too, so the GPU test's oracle is pinned at those sizes."""
+    dropped = 0
+    for (W, H) in [(38, 40), (22, 30), (54, 33), (70, 17), (134, 50), (64, 16), (65, 17), (129, 48), (198, 64), (1286, 40)]:
+        img = edge_image(W, H)
+        a = oracle.fast9(img, 40)
+        b = ref_feeder.kfast(img, 40, False)
+        assert len(a) == len(b)
+        for f in ("x", "y", "score"):
+            assert np.array_equal(a[f], b[f])
+        if W % 16 == 6 and W >= 38:
+            dropped += int((a["x"] >= W - 35).sum() == 0 or W == 38)
+    assert dropped >= 1
+
+
 def test_features_conversion(oracle):
     kps = synth.random_keypoints(50, 640, 480, seed=3)
     f = oracle.features_from_kps(kps)
