@@ -598,21 +598,49 @@ def main():
         def sec_front_end():
             # GPU-resident front end on a real frame (informational): pyramid -> FAST-9/NMS/orientation ->
             # CLATCH with the keypoint count kept in device memory (no host round trip)
-            ctx.profile_reset()
-            ctx.profile_enable(True)
-            for _ in range(20):
+            def fe():
                 ctx.pyramid_build_dev(imgs[0].data_ptr(), W, H, W, sptr)
                 ctx.detect_dev(sptr)
                 ctx.describe_detected_dev(None, sptr)
+            for _ in range(200):              # the section starts on an idle device: bring the clocks back up, let the host get ahead
+                fe()
             torch.cuda.synchronize()          # rank-0-only section: no collective here
+            ctx.profile_reset()
+            ctx.profile_enable(True)
+            for _ in range(200):
+                fe()
+            torch.cuda.synchronize()
             ctx.profile_enable(False)
             pf = ctx.profile_read()
             _, n_found = ctx.detect(capacity=1)
-            out["front_end"] = {"what": "640x480 synthetic frame, all on device: pyramid + FAST-9/NMS/angle (8 levels) + CLATCH",
+            t1 = time.perf_counter()
+            for _ in range(200):
+                fe()
+            torch.cuda.synchronize()
+            fe_us = (time.perf_counter() - t1) / 200 * 1e6
+            out["front_end"] = {"what": "640x480 synthetic frame, all on device: pyramid + FAST-9/NMS/angle (8 levels, two launches) + CLATCH; "
+                                        "*_us = HIP events around each stage's launches, 200 frames back to back behind 200 untimed ones",
                                 "keypoints": int(n_found),
                                 "pyramid_us": pf["pyramid_kernel"][0] / max(pf["pyramid_kernel"][1], 1) * 1e3,
                                 "detect_us": pf["detect_kernels"][0] / max(pf["detect_kernels"][1], 1) * 1e3,
-                                "clatch_us": pf["clatch_kernel"][0] / max(pf["clatch_kernel"][1], 1) * 1e3}
+                                "clatch_us": pf["clatch_kernel"][0] / max(pf["clatch_kernel"][1], 1) * 1e3,
+                                "frame_us_no_events": fe_us}
+            # the batched entry point on 4 and 8 copies of the camera set (one pyramid, two detector, one CLATCH launch per call)
+            capk = NKP
+            bk = [torch.zeros((capk, 20), dtype=torch.uint8, device=dev) for _ in range(8)]
+            bc = [torch.zeros((2,), dtype=torch.int32, device=dev) for _ in range(8)]
+            bd = [torch.zeros((capk, 64), dtype=torch.uint8, device=dev) for _ in range(8)]
+            for nb in (4, 8):
+                ip = [imgs[i % len(imgs)].data_ptr() for i in range(nb)]
+                args_ = (ip, W, H, W, [t.data_ptr() for t in bk[:nb]], [t.data_ptr() for t in bc[:nb]], [t.data_ptr() for t in bd[:nb]], sptr)
+                for _ in range(20):
+                    ctx.detect_batch_dev(*args_)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(100):
+                    ctx.detect_batch_dev(*args_)
+                torch.cuda.synchronize()
+                out["front_end"]["batch_of_%d_us_per_camera" % nb] = (time.perf_counter() - t1) / 100 / nb * 1e6
 
         def sec_pose():
             # p50 pose-solve (BASELINE metric, config[2] sizes) on host buffers, with the reference's model selection:
@@ -758,6 +786,29 @@ def main():
                                                     "all 6 pairs in one sweep launch (pose: pose_solve)",
                                             "describe_4_cameras_us": t_desc, "match_6_pairs_us": t_match, "step_us": t_step,
                                             "Mmatches_per_s": 6 * NKP * NKP / t_step, "Mdesc_per_s": 4 * NKP / t_step}
+                # the same step with the REAL front end: the four frames' keypoints come from the GPU detector (clc_detect_batch_dev: one
+                # pyramid, two detector and one CLATCH launch), the pairs are matched with the counts read on the device
+                kb = [torch.zeros((NKP, 20), dtype=torch.uint8, device=dev) for _ in range(4)]
+                cb = [torch.zeros((2,), dtype=torch.int32, device=dev) for _ in range(4)]
+                kbp, cbp = [t.data_ptr() for t in kb], [t.data_ptr() for t in cb]
+                prs = multicam.exhaustive_pairs(4)
+                jb2 = [(a_ * NKP, NKP, b_ * NKP, NKP, k_ * NKP, THR) for k_, (a_, b_) in enumerate(prs)]
+                out6 = torch.empty((6 * NKP,), dtype=torch.int32, device=dev)
+
+                def real_step():
+                    ctx2.detect_batch_dev(ip, W2, H2, W2, kbp, cbp, dp, sptr)
+                    ctx2.match_jobs_counted_dev(ar2.data_ptr(), jb2, [cbp[a_] for a_, _ in prs], [cbp[b_] for _, b_ in prs], [0] * 6,
+                                                out6.data_ptr(), sptr)
+                t_front = timed(lambda: ctx2.detect_batch_dev(ip, W2, H2, W2, kbp, cbp, dp, sptr))
+                t_real = timed(real_step)
+                torch.cuda.synchronize()
+                n_kp = [int(t[0].item()) for t in cb]
+                cmp_real = sum(n_kp[a_] * n_kp[b_] for a_, b_ in prs)
+                out["stages"]["config2"]["real_front_end"] = {
+                    "what": "detect -> describe of 4 x 1280x720 rendered-rectangle frames in one batched call + the 6 pair sweeps on the "
+                            "detected keypoints (counts read on the device)",
+                    "keypoints": n_kp, "detect_describe_4_cameras_us": t_front, "step_us": t_real,
+                    "Mmatches_per_s": cmp_real / t_real, "Mdesc_per_s": sum(n_kp) / t_real}
             finally:
                 ctx2.close()
 

@@ -452,6 +452,16 @@ class Context:
         arr = (MatchJob * len(jobs))(*[MatchJob(*j) for j in jobs])
         self._chk(self.lib.clc_match_jobs_dev(self.h, d_desc_base, arr, len(jobs), d_match, stream))
 
+    def match_jobs_counted_dev(self, d_desc_base, jobs, d_cnt_q, d_cnt_t, q_row0, d_match, stream=None):
+        """clc_match_jobs_counted_dev: jobs planned on capacities, the row counts of both sets read on the device (lists of device
+        addresses of int32 counts, one per job); planned query rows past the count are answered -1."""
+        n = len(jobs)
+        arr = (MatchJob * n)(*[MatchJob(*j) for j in jobs])
+        cq = (C.c_void_p * n)(*d_cnt_q)
+        ct = (C.c_void_p * n)(*d_cnt_t)
+        r0 = (C.c_uint32 * n)(*q_row0)
+        self._chk(self.lib.clc_match_jobs_counted_dev(self.h, d_desc_base, arr, n, cq, ct, r0, d_match, stream))
+
     def match_pairs(self, descs, pairs, threshold=40):
         """All listed (first, second) pairs over per-camera descriptor arrays; returns a list of int32 arrays."""
         descs = [np.ascontiguousarray(d, dtype=np.uint8).reshape(-1, 64) for d in descs]

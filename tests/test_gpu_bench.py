@@ -102,3 +102,18 @@ def test_streaming_scenario_synthetic_descriptors():
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
     assert d["position_error_p50"] < 0.01 and d["inliers_p50"] > 500
+
+
+def test_streaming_scenario_two_lanes_same_poses():
+    """Four cameras on the one GPU: the two-lane loop (front end + counted map match of a lane's next camera frame enqueued without a
+    host synchronisation before its current pose solve, two host threads) finds bit for bit the poses of the camera-by-camera loop,
+    and the inter-camera step goes through for every pair."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_stream.py"), "--cams", "4", "--frames", "6"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["mode"].startswith("pipelined") and d["same_poses_both_modes"] is True
+    assert d["localized_frames"] == 24 and d["sequential"]["localized_frames"] == 24
+    assert d["inter_steps"] == 24 and d["inter_failures"] == 0
+    assert d["position_error_p50"] < 0.005 * d["camera_height"] and d["position_error_fused_p50"] < 0.005 * d["camera_height"]
+    assert d["frame_p50_ms"]["pipelined"] > 0 and d["frame_p50_ms"]["sequential"] > 0
