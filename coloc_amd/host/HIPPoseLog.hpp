@@ -11,6 +11,8 @@
 //   * roll/pitch/yaw: Eigen eulerAngles(2, 1, 0) of the rotation, remapped by convertAnglesForLogging
 //     (:36-67, evaluated in float as there) and printed in degrees as float
 //
+// logPosetoPLY / logMaptoPLY (:102-167): the ASCII PLY track and map dumps, same header and vertex lines.
+//
 // Eigen is absent from the snapshot (unpinned): eulerAngles(2,1,0) is restated from Eigen 3.3's published
 // algorithm (first angle in [0, pi]); tests check R == Rz(a0) Ry(a1) Rx(a2) for the returned triple.
 #pragma once
@@ -20,9 +22,12 @@
 #include <cmath>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
+#include <limits>
 #include <ostream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace coloc {
 
@@ -100,6 +105,39 @@ public:
         file.exceptions(file.exceptions() | std::ios::failbit | std::ifstream::badbit);
         writePoseCov(file, idx, source, dest, rotation, center, cov, rmse, nTracks);
         return file.good();
+    }
+
+    // logUtils.hpp:102-120: APPEND one vertex "cx cy cz 0 255 0" (fixed, digits10 + 1 decimals) -- the camera track ColoC collects
+    // (coloc.hpp:185, 243).  Returns stream.good(): TRUE = written, the opposite of the EXIT_* convention above, as in the reference.
+    bool logPosetoPLY(const std::array<double, 3>& center, const std::string& filename)
+    {
+        std::ofstream stream(filename.c_str(), std::ios::out | std::ios::app);
+        if (!stream.is_open()) return false;
+        stream << std::fixed << std::setprecision(std::numeric_limits<double>::digits10 + 1);
+        stream << center[0] << ' ' << center[1] << ' ' << center[2] << ' ' << "0 255 0\n";
+        return stream.good();
+    }
+
+    // logUtils.hpp:122-167: ASCII PLY of a map: header, the centre of every posed view in green, every landmark in white
+    // (coloc.hpp:427).  The scene is handed over as its two point lists (Scene::GetPoses() centres, GetLandmarks() X).
+    bool logMaptoPLY(const std::vector<std::array<double, 3>>& poseCenters, const std::vector<std::array<double, 3>>& landmarks,
+                     const std::string& filename)
+    {
+        std::ofstream stream(filename.c_str(), std::ios::out | std::ios::binary);
+        if (!stream.is_open()) return false;
+        stream << std::fixed << std::setprecision(std::numeric_limits<double>::digits10 + 1);
+        stream << "ply" << '\n' << "format " << "ascii 1.0"
+               << '\n' << "comment generated by coloc"
+               << '\n' << "element vertex " << landmarks.size() + poseCenters.size()
+               << '\n' << "property double x" << '\n' << "property double y" << '\n' << "property double z"
+               << '\n' << "property uchar red" << '\n' << "property uchar green" << '\n' << "property uchar blue"
+               << '\n' << "end_header" << std::endl;
+        for (const auto& c : poseCenters) stream << c[0] << ' ' << c[1] << ' ' << c[2] << ' ' << "0 255 0\n";
+        for (const auto& X : landmarks) stream << X[0] << ' ' << X[1] << ' ' << X[2] << ' ' << "255 255 255\n";
+        stream.flush();
+        const bool logStatus = stream.good();
+        stream.close();
+        return logStatus;
     }
 };
 

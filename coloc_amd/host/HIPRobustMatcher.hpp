@@ -13,6 +13,10 @@
 //        (R, t) candidates of E = U diag(1,1,0) V^T (R = U W V^T or U W^T V^T, t = +-u3), every inlier triangulated
 //        (DLT on the bearing vectors) under each candidate, the candidate with most points in front of both cameras
 //        wins provided the runner-up has < 0.7 of its count.
+//   bool matchMaps(scene1, scene2, commonFeatures, poseDiff, rotDiff)                                  :241-370  (coloc.hpp:326, 443)
+//        as the reference's live code does: every putative map-to-map match is kept, in order (:346, :359-360); the fundamental
+//        matrix predicted from the known displacement, F = Kinv^T rotDiff^T K^T [K rotDiff poseDiff / |poseDiff|]_x (:317-327), is
+//        only used to log f1^T F f2 per match to "guidedmatches2.txt" (:334-349).  Host arithmetic, no GPU work.
 // x1 / x2 are 2 x N UNDISTORTED pixel coordinates (computeRelativePose undistorts with get_ud_pixel, :391-397).
 // Status convention as the reference: EXIT_SUCCESS / EXIT_FAILURE through bool, FALSE MEANS SUCCESS.
 // Only model 'E' (the one coloc_node.cpp:87 selects) is provided; 'F' / 'H' stay with OpenMVG on the host.
@@ -21,6 +25,7 @@
 #include <array>
 #include <cmath>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <map>
 #include <vector>
@@ -301,6 +306,53 @@ public:
         std::vector<openMVG::Pair> pairs;
         for (const auto& kv : putativeMatches) pairs.push_back(kv.first);
         for (const openMVG::Pair& pr : pairs) (void)filterMatchesPair(pr, regions, putativeMatches, geometricMatches, relativePoses);
+    }
+
+    // RobustMatcher::matchMaps (:241-370), called straight after matcher.matchMapFeatures (coloc.hpp:323-326, :439-443): the live
+    // code keeps EVERY putative match (the filterHomography variant above it is commented out in the reference) and writes the
+    // epipolar residual of each under the fundamental matrix the known displacement predicts to guidedmatches2.txt, one line
+    // "res,xL0,xL1,xR0,xR1" per match (:347).  poseDiff / rotDiff are taken by const reference: coloc.hpp:443 hands over the
+    // result of a call.  Returns EXIT_SUCCESS (false).
+    bool matchMaps(std::unique_ptr<openMVG::features::AKAZE_Binary_Regions>& scene1, std::unique_ptr<openMVG::features::AKAZE_Binary_Regions>& scene2,
+                   std::vector<openMVG::matching::IndMatch>& commonFeatures, const openMVG::Vec3& poseDiff, const openMVG::Mat3& rotDiff)
+    {
+        const std::vector<openMVG::matching::IndMatch> putativeMatches = commonFeatures;
+        commonFeatures.clear();
+        const openMVG::features::PointFeatures featI = scene1->GetRegionsPositions();
+        const openMVG::features::PointFeatures featJ = scene2->GetRegionsPositions();
+        openMVG::Mat xL(2, putativeMatches.size()), xR(2, putativeMatches.size());
+        for (size_t k = 0; k < putativeMatches.size(); ++k) {
+            xL(0, k) = featI[putativeMatches[k].i_].x(); xL(1, k) = featI[putativeMatches[k].i_].y();
+            xR(0, k) = featJ[putativeMatches[k].j_].x(); xR(1, k) = featJ[putativeMatches[k].j_].y();
+        }
+        // both cameras from params->K[0] / dist[0], as written at :307-311
+        const auto& K0 = params->K[0];
+        const auto& d0 = params->dist[0];
+        const openMVG::cameras::Pinhole_Intrinsic_Radial_K3 camL(params->imageSize.first, params->imageSize.second, K0(0, 0), K0(0, 2), K0(1, 2), d0[0],
+                                                                 d0[1], d0[2]),
+            camR(params->imageSize.first, params->imageSize.second, K0(0, 0), K0(0, 2), K0(1, 2), d0[0], d0[1], d0[2]);
+        // A = K rotDiff (poseDiff / |poseDiff|), C = [A]_x, F = Kinv^T rotDiff^T K^T C (:315-325)
+        const double nrm = std::sqrt(poseDiff[0] * poseDiff[0] + poseDiff[1] * poseDiff[1] + poseDiff[2] * poseDiff[2]);
+        const openMVG::Mat3 KR = hipgeom::mul(camL.K(), rotDiff);
+        double A[3];
+        for (int i = 0; i < 3; ++i) A[i] = KR(i, 0) * (poseDiff[0] / nrm) + KR(i, 1) * (poseDiff[1] / nrm) + KR(i, 2) * (poseDiff[2] / nrm);
+        openMVG::Mat3 C;
+        C(0, 0) = 0.0;   C(0, 1) = -A[2]; C(0, 2) = A[1];
+        C(1, 0) = A[2];  C(1, 1) = 0.0;   C(1, 2) = -A[0];
+        C(2, 0) = -A[1]; C(2, 1) = A[0];  C(2, 2) = 0.0;
+        const openMVG::Mat3 F = hipgeom::mul(hipgeom::mul(hipgeom::mul(hipgeom::transpose(camR.Kinv()), hipgeom::transpose(rotDiff)),
+                                                          hipgeom::transpose(camL.K())), C);
+        std::ofstream myfile;
+        myfile.open("guidedmatches2.txt");
+        for (size_t k = 0; k < putativeMatches.size(); ++k) {
+            const double f1[3] = { xL(0, k), xL(1, k), 1.0 }, f2[3] = { xR(0, k), xR(1, k), 1.0 };
+            double res = 0.0;
+            for (int i = 0; i < 3; ++i) res += f1[i] * (F(i, 0) * f2[0] + F(i, 1) * f2[1] + F(i, 2) * f2[2]);
+            commonFeatures.push_back(putativeMatches[k]);
+            myfile << res << "," << xL(0, k) << "," << xL(1, k) << "," << xR(0, k) << "," << xR(1, k) << std::endl;
+        }
+        myfile.close();
+        return EXIT_SUCCESS;
     }
 
 private:

@@ -7,7 +7,7 @@
 //   column-major like Eigen: resize(rows, cols), operator()(r, c), rows(), cols()),
 //   openMVG::geometry::Pose3 (rotation(), center(), translation(); Pose3(R, C)),
 //   openMVG::cameras::Pinhole_Intrinsic_Radial_K3 (ctor (w, h, focal, ppx, ppy, k1, k2, k3), have_disto(),
-//   get_ud_pixel() with OpenMVG's bisection on r^2 (1 + k1 r^2 + k2 r^4 + k3 r^6)^2, operator()(2 x N pixels) -> 3 x N bearings, K()),
+//   get_ud_pixel() with OpenMVG's bisection on r^2 (1 + k1 r^2 + k2 r^4 + k3 r^6)^2, operator()(2 x N pixels) -> 3 x N bearings, K(), Kinv()),
 //   openMVG::sfm::Image_Localizer_Match_Data (pt3D, pt2D, vec_inliers, error_max, max_iteration),
 //   openMVG::sfm::Landmark{X} / Landmarks and the slice of SfM_Data ("Scene") Localizer::setupTracks reads,
 //   coloc::Cov6 (6 x 6 pose covariance, [angle-axis | translation] order as PoseRefiner::refinePose fills it,
@@ -89,6 +89,7 @@ public:
     double focal() const { return f_; }
     Vec2 principal_point() const { return Vec2(ppx_, ppy_); }
     Mat3 K() const { Mat3 K; K(0, 0) = f_; K(1, 1) = f_; K(0, 2) = ppx_; K(1, 2) = ppy_; K(2, 2) = 1.0; return K; }
+    Mat3 Kinv() const { Mat3 Ki; Ki(0, 0) = 1.0 / f_; Ki(1, 1) = 1.0 / f_; Ki(0, 2) = -ppx_ / f_; Ki(1, 2) = -ppy_ / f_; Ki(2, 2) = 1.0; return Ki; }
     Vec2 ima2cam(const Vec2& p) const { return Vec2((p[0] - ppx_) / f_, (p[1] - ppy_) / f_); }
     Vec2 cam2ima(const Vec2& p) const { return Vec2(f_ * p[0] + ppx_, f_ * p[1] + ppy_); }
     double imagePlane_toCameraPlaneError(double v) const { return v / f_; }

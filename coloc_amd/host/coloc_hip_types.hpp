@@ -61,6 +61,15 @@ struct SIOPointFeature {
 };
 template <typename T, size_t N>
 using Descriptor = std::array<T, N>;
+// what Regions::GetRegionsPositions() hands out (RobustMatcher.hpp:297-298): positions only
+struct PointFeature {
+    float x_ = 0, y_ = 0;
+    PointFeature() = default;
+    PointFeature(float x, float y) : x_(x), y_(y) {}
+    float x() const { return x_; }
+    float y() const { return y_; }
+};
+using PointFeatures = std::vector<PointFeature>;
 
 // Binary_Regions<SIOPointFeature, 64>
 class AKAZE_Binary_Regions {
@@ -74,6 +83,13 @@ public:
     const void* DescriptorRawData() const { return descs_.data(); }
     size_t RegionCount() const { return feats_.size(); }
     std::array<double, 2> GetRegionPosition(size_t i) const { return { feats_[i].x(), feats_[i].y() }; }
+    PointFeatures GetRegionsPositions() const
+    {
+        PointFeatures p;
+        p.reserve(feats_.size());
+        for (const FeatureT& f : feats_) p.emplace_back(f.x(), f.y());
+        return p;
+    }
 private:
     std::vector<FeatureT> feats_;
     std::vector<DescriptorT> descs_;

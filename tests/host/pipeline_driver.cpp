@@ -3,6 +3,7 @@
 //   initMap            :162-169   matcher.computeMatches(regions, putative); robustMatcher.filterMatches(regions, putative, geometric, poses)
 //   intraPoseEstimator :197-223   matcher.setMapData(...); matcher.matchSceneWithMap(id, data, mapMatches);
 //                                 localizer.localizeImage(id, pose, data, cov, rmse, mapMatches, inliers)
+//   interPoseEstimator :323-326   matcher.matchMapFeatures(map, interMap, common); robustMatcher.matchMaps(map, interMap, common, poseDiff, rotDiff)
 // on frames rendered by tests/test_gpu_pipeline_host.py.  The map (3-D points under camera 0's features) comes from the test,
 // which knows the scene: the driver runs twice -- "features" dumps camera 0's feature positions, "run" does everything.
 // usage: pipeline_driver features|run <dir> <width> <height> <focal> <ppx> <ppy>
@@ -102,6 +103,24 @@ int main(int argc, char** argv)
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out.push_back(pose.rotation()(i, j));
     for (int i = 0; i < 3; ++i) out.push_back(pose.center()[i]);
     out.push_back(rmse);
+    // ---- interPoseEstimator, the map-to-map part (coloc.hpp:323-326): the global map against a second map -- here camera 1's
+    // features -- through matchMapFeatures (thr 60), then matchMaps with the displacement between the two views
+    std::unique_ptr<features::AKAZE_Binary_Regions> interMapRegions(new features::AKAZE_Binary_Regions);
+    for (size_t i = 0; i < data.regions[1]->RegionCount(); ++i) {
+        interMapRegions->Features().push_back(data.regions[1]->Features()[i]);
+        interMapRegions->Descriptors().push_back(data.regions[1]->Descriptors()[i]);
+    }
+    std::vector<IndMatch> commonFeatures;
+    matcher.matchMapFeatures(data.mapRegions, interMapRegions, commonFeatures);
+    const std::vector<IndMatch> before = commonFeatures;
+    Vec3 poseDiff = pose.center();
+    Mat3 rotDiff = pose.rotation();
+    const bool mm = robust.matchMaps(data.mapRegions, interMapRegions, commonFeatures, poseDiff, rotDiff);
+    bool kept = before.size() == commonFeatures.size();
+    for (size_t i = 0; kept && i < before.size(); ++i) kept = before[i] == commonFeatures[i];
+    out.push_back((double)commonFeatures.size());
+    out.push_back(mm ? 1.0 : 0.0);
+    out.push_back(kept ? 1.0 : 0.0);
     dump(dir + "/pipeline_out.bin", out);
     return 0;
 }

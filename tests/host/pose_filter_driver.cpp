@@ -4,6 +4,7 @@
 //   "U drone  rmse cov(36)"                          update -> prints R(9) t(3) gate rejected init P(36)
 //   "E R(9)"                                         prints eulerAnglesZYX(3) and the remapped angles(3)
 //   "L idx source dest R(9) c(3) cov(36) rmse n"     prints the CSV record
+//   "P file nPoses nLandmarks xyz..."                logMaptoPLY(file) of those points, then logPosetoPLY(file + ".track") of every pose
 #include <cstdio>
 #include <iostream>
 #include <memory>
@@ -47,6 +48,16 @@ int main()
             std::fflush(stdout);
             coloc::HIPPoseLog::writePoseCov(std::cout, idx, s, d, R, c, cov, rmse, n);
             std::cout.flush();
+        } else if (cmd == 'P') {
+            char name[512]; int np, nl;
+            if (std::scanf("%511s %d %d", name, &np, &nl) != 3) return 1;
+            std::vector<std::array<double, 3>> poses((size_t)np), pts((size_t)nl);
+            for (auto& p : poses) for (auto& v : p) if (std::scanf("%lf", &v) != 1) return 1;
+            for (auto& p : pts) for (auto& v : p) if (std::scanf("%lf", &v) != 1) return 1;
+            coloc::HIPPoseLog log;
+            bool ok = log.logMaptoPLY(poses, pts, std::string(name));
+            for (const auto& p : poses) ok = log.logPosetoPLY(p, std::string(name) + ".track") && ok;
+            std::printf("%d\n", (int)ok);
         } else return 2;
     }
     return 0;

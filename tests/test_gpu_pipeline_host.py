@@ -35,12 +35,12 @@ def test_cpp_pipeline_on_rendered_frames(tmp_path):
     _pgm(tmp_path / "cam0.pgm", synth.render_plane(tex, PPU, K, Ra, ta, W, H, relief=relief))
     _pgm(tmp_path / "cam1.pgm", synth.render_plane(tex, PPU, K, Rb, tb, W, H, relief=relief))
     args = [str(tmp_path), str(W), str(H), str(K[0, 0]), str(K[0, 2]), str(K[1, 2])]
-    r = subprocess.run([exe, "features"] + args, capture_output=True, text=True)
+    r = subprocess.run([exe, "features"] + args, capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
     feat0 = np.fromfile(tmp_path / "feat0.bin", dtype=np.float64).reshape(-1, 2)
     assert len(feat0) > 500
     synth.backproject_to_plane(feat0, K, Ra, ta, relief=relief).astype(np.float64).tofile(tmp_path / "map_xyz.bin")
-    r = subprocess.run([exe, "run"] + args, capture_output=True, text=True)
+    r = subprocess.run([exe, "run"] + args, capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
     o = np.fromfile(tmp_path / "pipeline_out.bin", dtype=np.float64)
     n0, n1, n_put, n_geo = (int(v) for v in o[:4])
@@ -61,3 +61,17 @@ def test_cpp_pipeline_on_rendered_frames(tmp_path):
     ang2 = np.degrees(np.arccos(np.clip((np.trace(Rabs @ Rb.T) - 1) / 2, -1, 1)))
     print("absolute pose: rotation error %.3f deg, centre error %.4f, %d / %d map matches inliers" % (ang2, np.linalg.norm(Cabs - (-Rb.T @ tb)), n_inl, n_map))
     assert ang2 < 0.5 and np.linalg.norm(Cabs - (-Rb.T @ tb)) < 0.02 * 5.0 and 0.0 < rmse < 3.0
+    # matchMaps (RobustMatcher.hpp:241-370 as called at coloc.hpp:326): every map-to-map match is kept, in order, status false =
+    # success, and guidedmatches2.txt holds "f1^T F f2, xL, yL, xR, yR" per match for F = Kinv^T R^T K^T [K R d / |d|]_x
+    n_common, mm_status, kept = int(o[32]), o[33], o[34]
+    assert n_common > 100 and mm_status == 0.0 and kept == 1.0
+    rows = np.loadtxt(tmp_path / "guidedmatches2.txt", delimiter=",").reshape(-1, 5)
+    assert len(rows) == n_common
+    d = Cabs / np.linalg.norm(Cabs)
+    A = K @ Rabs @ d
+    Cx = np.array([[0, -A[2], A[1]], [A[2], 0, -A[0]], [-A[1], A[0], 0]])
+    F = np.linalg.inv(K).T @ Rabs.T @ K.T @ Cx
+    f1 = np.c_[rows[:, 1:3], np.ones(len(rows))]
+    f2 = np.c_[rows[:, 3:5], np.ones(len(rows))]
+    want = np.einsum("ni,ij,nj->n", f1, F, f2)
+    assert np.allclose(rows[:, 0], want, rtol=2e-3, atol=1e-3 * np.abs(want).max())     # the file carries 6 significant digits

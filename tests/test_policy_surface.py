@@ -49,6 +49,44 @@ def test_every_member_is_the_references_or_documented():
     assert "bearing" not in used                              # the invented member of round 2 stays gone
 
 
+HEADER_OF = {"detector": "HIPDetector.hpp", "matcher": "HIPMatcher.hpp", "localizer": "HIPLocalizer.hpp", "robustMatcher": "HIPRobustMatcher.hpp",
+             "filter": "HIPPoseFilter.hpp", "covIntOptimizer": "HIPCovIntersection.hpp", "logger": "HIPPoseLog.hpp"}
+
+
+def declared_members(header):
+    """names a header declares as member functions or data members (anything followed by `(`, `=`, `;`, `{` or `[` outside comments)"""
+    text = strip_comments(open(os.path.join(ROOT, "coloc_amd", "host", header)).read())
+    return set(re.findall(r"\b([A-Za-z_]\w*)\s*(?=\(|=|;|\{|\[)", text))
+
+
+def test_every_member_the_references_callers_use_is_declared():
+    """The converse of the test above: whatever coloc.hpp / colocInterface.hpp / InterfaceDisk.hpp / InterfaceROS.hpp call on
+    `detector.` / `matcher.` / `localizer.` / `robustMatcher.` / `filter.` / `covIntOptimizer.` / `logger.`
+    (tests/golden/reference_policy_calls.json, tools/gen_reference_policy_calls.py) must be a member of the matching header here, or be
+    listed with its reason in INTEGRATION.md 4c -- round 3 shipped HIPRobustMatcher without matchMaps (coloc.hpp:326, :443)."""
+    calls = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_policy_calls.json")))["calls"]
+    assert set(calls) == set(HEADER_OF) and "matchMaps" in calls["robustMatcher"] and "localizeImage" in calls["localizer"]
+    allowed = documented_exceptions()
+    missing = {}
+    for obj, members in calls.items():
+        have = declared_members(HEADER_OF[obj])
+        lost = [m for m in members if m not in have and m not in allowed]
+        if lost:
+            missing[obj] = lost
+    assert not missing, "members the reference's callers use that the HIP policy headers do not declare: %r" % missing
+
+
+def test_policy_call_list_matches_the_reference_when_it_is_present():
+    ref_root = os.environ.get("COLOC_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref_root, "include", "coloc")):
+        import pytest
+        pytest.skip("reference tree not present (the committed list is used)")
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_reference_policy_calls as g
+    assert g.policy_calls(ref_root) == json.load(open(os.path.join(ROOT, "tests", "golden", "reference_policy_calls.json")))["calls"]
+
+
 def test_reference_call_forms_are_the_ones_used():
     rm = strip_comments(open(os.path.join(ROOT, "coloc_amd", "host", "HIPRobustMatcher.hpp")).read())
     # bearing vectors the way RobustMatcher.hpp:159 asks for them

@@ -166,3 +166,25 @@ def test_pose_csv_record_format(driver):
     assert f[18] == "0.75" and f[19] == "321"
     e = np.array([float(x) for x in _run(driver, "E %s\n" % _fmt(R))[0].split()])[3:]
     assert [float(x) for x in f[15:18]] == pytest.approx(list(e * 180 / np.pi), rel=1e-5, abs=1e-4)
+
+
+def test_ply_dumps(driver, tmp_path):
+    """logMaptoPLY / logPosetoPLY (logUtils.hpp:102-167): ASCII PLY, green vertices for the posed views, white ones for the landmarks,
+    fixed notation with digits10 + 1 = 16 decimals; the track file gets one appended vertex line per call and no header."""
+    rng = np.random.default_rng(3)
+    poses, pts = rng.normal(size=(2, 3)), rng.normal(size=(5, 3)) * 10
+    path = tmp_path / "map.ply"
+    out = _run(driver, "P %s 2 5 %s\n" % (path, " ".join(repr(float(v)) for v in np.r_[poses.ravel(), pts.ravel()])))
+    assert out == ["1"]
+    lines = open(path).read().split("\n")
+    assert lines[:10] == ["ply", "format ascii 1.0", "comment generated by coloc", "element vertex 7", "property double x", "property double y",
+                          "property double z", "property uchar red", "property uchar green", "property uchar blue"]
+    assert lines[10] == "end_header" and len(lines) == 11 + 7 + 1 and lines[-1] == ""
+    body = lines[11:18]
+    for k, row in enumerate(body):
+        f = row.split(" ")
+        want = poses[k] if k < 2 else pts[k - 2]
+        assert f[3:] == (["0", "255", "0"] if k < 2 else ["255", "255", "255"])
+        assert all(len(v.split(".")[1]) == 16 for v in f[:3]) and np.allclose([float(v) for v in f[:3]], want, rtol=0, atol=1e-15)
+    track = open(str(path) + ".track").read().split("\n")
+    assert len(track) == 3 and track[2] == "" and all(t.endswith(" 0 255 0") for t in track[:2])
