@@ -32,6 +32,7 @@
 #include "clc_internal.h"
 #include "clc_sincos.h"
 #include "latch_layout.inc"
+#include "latch_layout_swap.inc"
 
 namespace clc {
 
@@ -47,7 +48,14 @@ struct PatchRow { uint8_t v[6]; };
 static constexpr PatchRow k_pattern[512] = {
 #include "latch_pattern.inc"
 };
+// (round, lane) -> learned triplet.  Round 4: the assignment searched WITH role exchange (tools/latch_anneal.c mode 0, swap 1) -- a slot may
+// read its triplet's a and c patches the other way round, which gives the bank assignment more freedom: conflict degree sum 81 -> 77.
+// Such a slot computes -S; its bit is taken as S' > 0.  -DCLC_CLATCH_NO_SWAP: round 3's assignment (A/B runs).
+#ifdef CLC_CLATCH_NO_SWAP
 static constexpr uint16_t k_slot_triplet[512] = LATCH_SLOT_TRIPLET;
+#else
+static constexpr uint16_t k_slot_triplet[512] = LATCH_SLOT_TRIPLET_EX;
+#endif
 
 // LDS byte address (inside the wave's region) of the dword-aligned start of the patch whose
 // top-left window pixel is (row, col): copy k = (p & 3) holds win[i + k] at byte i.
@@ -66,10 +74,12 @@ static constexpr SlotTable make_slot_table()
 {
     SlotTable t{};
     for (int slot = 0; slot < 512; ++slot) {
-        const int n = k_slot_triplet[slot];
-        t.rec[slot][0] = patch_lds_addr(k_pattern[n].v[0], k_pattern[n].v[1]);
+        const int n = k_slot_triplet[slot] & 511;
+        const bool sw = (k_slot_triplet[slot] >> 10) & 1;
+        const uint16_t a = patch_lds_addr(k_pattern[n].v[0], k_pattern[n].v[1]), c = patch_lds_addr(k_pattern[n].v[4], k_pattern[n].v[5]);
+        t.rec[slot][0] = (uint16_t)((sw ? c : a) | (sw ? 0x8000u : 0u));      // bit 15: roles exchanged (LDS addresses are < 2^15)
         t.rec[slot][1] = patch_lds_addr(k_pattern[n].v[2], k_pattern[n].v[3]);
-        t.rec[slot][2] = patch_lds_addr(k_pattern[n].v[4], k_pattern[n].v[5]);
+        t.rec[slot][2] = sw ? a : c;
         t.rec[n][3] = (uint16_t)(((slot & 63) << 2) | ((slot >> 6) << 8));
     }
     return t;
@@ -173,6 +183,12 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     __builtin_amdgcn_wave_barrier();
 
     // ---- shifted copies 1..3: copy_k[i] = win[i + k]; all thirteen reads first, then the stores
+    // (the 8-byte read of the window's last dword reaches 4 bytes past the window: those bytes lie in the gap in front of copy 1, are
+    // never written, and only feed the three bytes past the end of each copy, which no patch row reaches -- a patch's last row ends
+    // at window byte 4 * kWinDwords - 1 at the latest)
+    static_assert(kCopyBase[1] >= 4 * kWinDwords + 8 && kCopyBase[2] >= kCopyBase[1] + 4 * kWinDwords + 8 &&
+                  kCopyBase[3] >= kCopyBase[2] + 4 * kWinDwords + 8 && kWaveLds >= kCopyBase[3] + 4 * kWinDwords,
+                  "the shifted copies must not overlap the bytes the copy phase reads past the window");
     {
         constexpr int kIters = (kWinDwords + 63) / 64;
         u32x2_a4 d[kIters];
@@ -198,7 +214,7 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     uint32_t bits8 = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const uint32_t pa = rec[j].x & 0xFFFFu, pb = rec[j].x >> 16, pc = rec[j].y & 0xFFFFu;
+        const uint32_t pa = rec[j].x & 0x7FFFu, pb = rec[j].x >> 16, pc = rec[j].y & 0xFFFFu;
         uint32_t aa = 0, cc = 0, ab = 0, cb = 0;
 #pragma unroll
         for (int row = 0; row < 8; ++row) {
@@ -211,7 +227,8 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
             cb = udot4(C.x, B.x, cb); cb = udot4(C.y, B.y, cb);
         }
         const int32_t S = ((int32_t)aa - (int32_t)cc) - 2 * ((int32_t)ab - (int32_t)cb);
-        bits8 |= (S < 0 ? 1u : 0u) << j;
+        const int32_t Se = (rec[j].x & 0x8000u) ? -S : S;                  // a slot that read a and c in exchanged roles holds -S
+        bits8 |= (Se < 0 ? 1u : 0u) << j;
     }
     // ---- back to descriptor order: output round j, lane l <- bit of triplet 64*j + l
     // all eight gathers in flight at once; the sixteen dwords of the descriptor are then dealt to lanes 0..15 with v_writelane
