@@ -48,7 +48,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
@@ -114,6 +114,9 @@ def load_library():
     lib.clc_describe_dev.argtypes = [vp, vp, ci, vp, vp]
     lib.clc_describe_batch_dev.argtypes = [vp, ci, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, vp]
     lib.clc_detect_batch_dev.argtypes = [vp, ci, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, vp]
+    lib.clc_desc_cache_publish.argtypes = [vp, vp, vp, ci]
+    lib.clc_desc_cache_clear.argtypes = []
+    lib.clc_desc_cache_stats.argtypes = [vp, vp]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
     lib.clc_match_2nn_dev.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
@@ -272,6 +275,14 @@ class MultiCam:
             self.h = None
 
 
+def desc_cache_stats():
+    """(hits, misses) of the descriptor cache behind the host-pointer match entry points."""
+    lib = load_library()
+    h, m = C.c_ulonglong(), C.c_ulonglong()
+    lib.clc_desc_cache_stats(C.byref(h), C.byref(m))
+    return int(h.value), int(m.value)
+
+
 def keypoints_to_features(kps):
     lib = load_library()
     kps = np.ascontiguousarray(kps, dtype=KP_DTYPE)
@@ -401,6 +412,12 @@ class Context:
         cnt = (C.c_void_p * n)(*d_counts)
         out = (C.c_void_p * n)(*d_desc) if d_desc is not None else None
         self._chk(self.lib.clc_detect_batch_dev(self.h, n, imgs, width, height, pitch, kps, cnt, out, stream))
+
+    def desc_cache_publish(self, h_desc, d_src=None):
+        """The rows of numpy block h_desc (n x 64) are on this device at d_src (None: the context's own descriptor array, what
+        detect_and_describe filled): later host-pointer match calls given this very block skip its upload."""
+        assert h_desc.dtype == np.uint8 and h_desc.flags["C_CONTIGUOUS"]
+        self._chk(self.lib.clc_desc_cache_publish(self.h, d_src, _p(h_desc), int(h_desc.shape[0])))
 
     # -- describe
     def describe(self, kps):

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -815,13 +816,71 @@ int clc_match_jobs_counted_dev(clc_ctx* ctx, const void* d_desc_base, const clc_
     return run_jobs(ctx, jobs, pick(ctx, stream));
 }
 
-static int match_host(clc_ctx* ctx, const void* h_q, int nq, const uint8_t* d_train, int nt, int threshold,
-                      int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
+// ---- device-side descriptor cache ------------------------------------------------------------------------------------------
+// The reference's host flow hands descriptors from the detector to the matcher through host memory (FeatureMap regions:
+// GPUDetector.hpp:181 -> GPUMatcher.hpp:188-196), and GPUMatcher uploads them again for every call.  Here the detector can PUBLISH
+// the device copy of a block it has just written to a host address (clc_desc_cache_publish); a host-pointer match entry point that
+// is later given that address finds the rows on the device and skips the upload.  An entry is trusted only while the host block
+// still starts and ends with the rows it was published with (first and last 64 bytes compared, not hashed) and has the same count;
+// anything else -- another address, a changed block -- is uploaded as before.  Process-wide, per device, mutex-protected; entries
+// in use by a running call are never evicted.  CLC_DESC_CACHE=0 switches it off.
+struct DescCacheEntry {
+    int device = -1;
+    const void* h = nullptr;
+    int n = 0;
+    uint8_t first[CLC_DESC_BYTES], last[CLC_DESC_BYTES];
+    uint8_t* d = nullptr;
+    size_t cap = 0;          // rows allocated
+    uint64_t stamp = 0;
+    int busy = 0;
+};
+struct DescCache {
+    std::mutex mu;
+    std::vector<DescCacheEntry> e;
+    uint64_t clock = 0;
+    uint64_t hits = 0, misses = 0;      // lookups answered from the cache / uploaded
+    bool enabled = true;
+    DescCache() { const char* v = getenv("CLC_DESC_CACHE"); enabled = !(v && v[0] == '0'); }
+};
+static constexpr size_t kDescCacheEntries = 32;
+static DescCache& desc_cache() { static DescCache c; return c; }
+
+// device rows of host block (h, n) if published and still unchanged at both ends; the entry is pinned until cache_release
+static const uint8_t* cache_acquire(const int device, const void* h, const int n, DescCacheEntry** held)
 {
-    CLC_HIP(ctx, hipMemcpyAsync(ctx->d_q, h_q, (size_t)nq * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    *held = nullptr;
+    DescCache& c = desc_cache();
+    if (!c.enabled || !h || n <= 0) return nullptr;
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (DescCacheEntry& en : c.e) {
+        if (en.device != device || en.h != h || en.n != n || !en.d) continue;
+        const uint8_t* hb = (const uint8_t*)h;
+        if (memcmp(hb, en.first, CLC_DESC_BYTES) != 0 || memcmp(hb + (size_t)(n - 1) * CLC_DESC_BYTES, en.last, CLC_DESC_BYTES) != 0) {
+            if (en.busy == 0) en.h = nullptr;            // the host block has been rewritten: forget the entry
+            break;
+        }
+        en.stamp = ++c.clock;
+        ++en.busy;
+        ++c.hits;
+        *held = &en;
+        return en.d;
+    }
+    ++c.misses;
+    return nullptr;
+}
+static void cache_release(DescCacheEntry* held)
+{
+    if (!held) return;
+    std::lock_guard<std::mutex> lk(desc_cache().mu);
+    --held->busy;
+}
+
+static int match_host_impl(clc_ctx* ctx, const uint8_t* d_query, int nq, const uint8_t* d_train, int nt, int threshold,
+                           int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
+{
     std::vector<K2nnJobDev> jobs(1);
     jobs[0] = K2nnJobDev{};
-    jobs[0].q = (const uint4*)ctx->d_q;
+    jobs[0].q = (const uint4*)d_query;
     jobs[0].t = (const uint4*)d_train;
     jobs[0].out = ctx->d_match;
     jobs[0].best_out = h_best ? ctx->d_best : nullptr;
@@ -838,6 +897,93 @@ static int match_host(clc_ctx* ctx, const void* h_q, int nq, const uint8_t* d_tr
     return CLC_OK;
 }
 
+// query rows from the cache when the detector published them, else uploaded; the cache entry stays pinned for the duration of the call
+static int match_host(clc_ctx* ctx, const void* h_q, int nq, const uint8_t* d_train, int nt, int threshold,
+                      int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
+{
+    DescCacheEntry* held = nullptr;
+    const uint8_t* d_query = cache_acquire(ctx->device, h_q, nq, &held);
+    if (!d_query) {
+        const hipError_t e = hipMemcpyAsync(ctx->d_q, h_q, (size_t)nq * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "match: query upload", e);
+        d_query = ctx->d_q;
+    }
+    const int rc = match_host_impl(ctx, d_query, nq, d_train, nt, threshold, h_match, h_best, h_second);
+    cache_release(held);
+    return rc;
+}
+
+int clc_desc_cache_publish(clc_ctx* ctx, const void* d_src, const void* h_desc, int n)
+{
+    if (!ctx || !h_desc || n < 0) return fail(ctx, CLC_ERR_BAD_ARG, "desc_cache_publish: bad argument");
+    if (!d_src) {
+        if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "desc_cache_publish: context created without detector options and no device source given");
+        d_src = ctx->d_desc;
+    }
+    DescCache& c = desc_cache();
+    if (!c.enabled || n == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    DescCacheEntry* slot = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        for (DescCacheEntry& en : c.e)
+            if (en.device == ctx->device && en.h == h_desc && en.busy == 0) { slot = &en; break; }      // the same host block again
+        if (!slot && c.e.size() < kDescCacheEntries) {
+            c.e.reserve(kDescCacheEntries);                                                             // entries never move (held pointers)
+            c.e.emplace_back();
+            slot = &c.e.back();
+        }
+        if (!slot) {
+            for (DescCacheEntry& en : c.e)
+                if (en.busy == 0 && (!slot || en.stamp < slot->stamp)) slot = &en;                        // least recently used, not in use
+        }
+        if (!slot) return CLC_OK;                                                                        // everything in use: do not cache
+        slot->busy = 1;                                                                                  // reserved while it is being filled
+        slot->h = nullptr;
+    }
+    hipError_t e = hipSuccess;
+    if (slot->cap < (size_t)n || slot->device != ctx->device) {
+        if (slot->d) (void)hipFree(slot->d);
+        slot->d = nullptr; slot->cap = 0;
+        e = hipMalloc((void**)&slot->d, (size_t)n * CLC_DESC_BYTES);
+        if (e == hipSuccess) slot->cap = (size_t)n;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(slot->d, d_src, (size_t)n * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        slot->busy = 0;
+        if (e == hipSuccess) {
+            slot->device = ctx->device; slot->h = h_desc; slot->n = n; slot->stamp = ++c.clock;
+            memcpy(slot->first, h_desc, CLC_DESC_BYTES);
+            memcpy(slot->last, (const uint8_t*)h_desc + (size_t)(n - 1) * CLC_DESC_BYTES, CLC_DESC_BYTES);
+        }
+    }
+    if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "desc_cache_publish", e);
+    return CLC_OK;
+}
+
+int clc_desc_cache_stats(unsigned long long* hits, unsigned long long* misses)
+{
+    DescCache& c = desc_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (hits) *hits = c.hits;
+    if (misses) *misses = c.misses;
+    return CLC_OK;
+}
+
+int clc_desc_cache_clear(void)
+{
+    DescCache& c = desc_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (DescCacheEntry& en : c.e) {
+        if (en.busy) continue;
+        if (en.d) { (void)hipSetDevice(en.device); (void)hipFree(en.d); }
+        en.d = nullptr; en.cap = 0; en.h = nullptr; en.n = 0;
+    }
+    return CLC_OK;
+}
+
 int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt, int threshold,
                   int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
 {
@@ -848,8 +994,18 @@ int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt
         return fail(ctx, CLC_ERR_CAPACITY, "match_2nn: more descriptors than MatcherOptions.maxkp");
     if (nq == 0) return CLC_OK;
     CLC_HIP(ctx, hipSetDevice(ctx->device));
-    if (nt > 0) CLC_HIP(ctx, hipMemcpyAsync(ctx->d_t, h_t, (size_t)nt * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
-    return match_host(ctx, h_q, nq, ctx->d_t, nt, threshold, h_match, h_best, h_second);
+    DescCacheEntry* held = nullptr;
+    const uint8_t* d_train = nt > 0 ? cache_acquire(ctx->device, h_t, nt, &held) : nullptr;
+    if (!d_train) {
+        if (nt > 0) {
+            const hipError_t e = hipMemcpyAsync(ctx->d_t, h_t, (size_t)nt * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "match_2nn: train upload", e);
+        }
+        d_train = ctx->d_t;
+    }
+    const int rc = match_host(ctx, h_q, nq, d_train, nt, threshold, h_match, h_best, h_second);
+    cache_release(held);
+    return rc;
 }
 
 int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, int ncams, const int* pairs,
@@ -880,10 +1036,19 @@ int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, 
         CLC_HIP(ctx, hipMalloc((void**)&ctx->d_pairs, need));
         ctx->pairs_cap = need;
     }
-    for (int c = 0; c < ncams; ++c)
-        if (counts[c] > 0)
+    // a camera whose block the detector published on this device is read where it lies; the others are uploaded
+    std::vector<const uint8_t*> cam_dev((size_t)ncams, nullptr);
+    std::vector<DescCacheEntry*> held((size_t)ncams, nullptr);
+    struct Release { std::vector<DescCacheEntry*>& h; ~Release() { for (DescCacheEntry* e : h) cache_release(e); } } release{ held };
+    for (int c = 0; c < ncams; ++c) {
+        if (counts[c] <= 0) continue;
+        cam_dev[(size_t)c] = cache_acquire(ctx->device, h_desc[c], counts[c], &held[(size_t)c]);
+        if (!cam_dev[(size_t)c]) {
             CLC_HIP(ctx, hipMemcpyAsync(ctx->d_pairs + cam_off[c] * CLC_DESC_BYTES, h_desc[c], (size_t)counts[c] * CLC_DESC_BYTES,
                                         hipMemcpyHostToDevice, ctx->stream));
+            cam_dev[(size_t)c] = ctx->d_pairs + cam_off[c] * CLC_DESC_BYTES;
+        }
+    }
     int32_t* d_out = (int32_t*)(ctx->d_pairs + ((desc_bytes + 255) & ~(size_t)255));
     std::vector<K2nnJobDev> jobs;
     std::vector<size_t> out_off(npairs, 0);
@@ -893,8 +1058,8 @@ int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, 
         out_off[p] = o;
         if (counts[a] == 0) continue;
         K2nnJobDev jb{};
-        jb.q = (const uint4*)(ctx->d_pairs + cam_off[a] * CLC_DESC_BYTES);
-        jb.t = (const uint4*)(ctx->d_pairs + cam_off[b] * CLC_DESC_BYTES);
+        jb.q = (const uint4*)cam_dev[(size_t)a];
+        jb.t = (const uint4*)(counts[b] > 0 ? cam_dev[(size_t)b] : ctx->d_pairs);
         jb.out = d_out + o;
         jb.nq = (uint32_t)counts[a];
         jb.nt = (uint32_t)counts[b];
@@ -1469,12 +1634,15 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
     // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
     const int reserve0 = h_init->reserve;
     int bound = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
+    // Every failure return below drains the stream first (ignoring what the drain reports): launches of the failed solve may still
+    // be in flight and would otherwise write the progress word / result record of the NEXT solve, which reuses the same pinned block.
+    auto drained = [&](const int code) -> int { (void)hipStreamSynchronize(st); return code; };
     rc = enqueue_round(kind == 0 ? h_init->cur_batch : bound);         // (the resection launch takes its first batch as it stands)
-    if (rc != CLC_OK) return rc;
+    if (rc != CLC_OK) return drained(rc);
     uint32_t round = 0;
     for (;;) {
         rc = enqueue_round(bound);                                     // speculative: the round after the one being waited for
-        if (rc != CLC_OK) return rc;
+        if (rc != CLC_OK) return drained(rc);
         // the select kernel publishes one packed word (round number, iterations consumed, iter, n_iter) in pinned memory:
         // poll it (a stream synchronisation costs ~10 us per round); after 2 ms without progress fall back to the
         // synchronisation, which also surfaces errors
@@ -1487,7 +1655,7 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
                 if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(2)) {
                     CLC_HIP(ctx, hipStreamSynchronize(st));
                     w = __atomic_load_n(h_word, __ATOMIC_ACQUIRE);
-                    if ((w >> 49) < (round & 0x7FFFu)) return fail(ctx, CLC_ERR_HIP, "acransac: round did not complete");
+                    if ((w >> 49) < (round & 0x7FFFu)) return drained(fail(ctx, CLC_ERR_HIP, "acransac: round did not complete"));
                 }
             }
         }
@@ -1496,7 +1664,7 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
         const bool switched = ((w >> 48) & 1u) != 0;
         const long left = (long)n_iter_k - iter_k + 4 + (switched ? 0 : reserve0);
         bound = left > kAcrMaxBatch ? kAcrMaxBatch : (int)left;
-        if (round > 0x7000u) return fail(ctx, CLC_ERR_STATE, "acransac: too many rounds");
+        if (round > 0x7000u) return drained(fail(ctx, CLC_ERR_STATE, "acransac: too many rounds"));
     }
     prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);
     // The result record, mask and inlier list were written by the round that completed the run BEFORE its word (system-scope release /
@@ -1508,14 +1676,17 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
         // the host polls that instead of synchronising the stream (~5 us), with the synchronisation as the fallback after 5 ms.
         int32_t* ready = (int32_t*)((uint8_t*)p_ref + pnp_refine_ready_offset());
         __atomic_store_n(ready, 0, __ATOMIC_RELAXED);
-        CLC_HIP(ctx, launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50, d_ref,
-                                       st, &ctx->prof, &d_res->valid, p_ref));
+        {
+            const hipError_t e = launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50, d_ref,
+                                                   st, &ctx->prof, &d_res->valid, p_ref);
+            if (e != hipSuccess) return drained(fail(ctx, CLC_ERR_HIP, "launch_pnp_refine", e));
+        }
         const auto t_start = std::chrono::steady_clock::now();
         unsigned spins = 0;
         while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) {
             if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(5)) {
                 CLC_HIP(ctx, hipStreamSynchronize(st));
-                if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) return fail(ctx, CLC_ERR_HIP, "acransac: refinement did not complete");
+                if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) return drained(fail(ctx, CLC_ERR_HIP, "acransac: refinement did not complete"));
             }
         }
     }

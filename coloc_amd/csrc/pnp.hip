@@ -103,7 +103,9 @@ __global__ __launch_bounds__(64) void p3p_kernel(const double* __restrict__ X, c
     const int gid = blockIdx.x * 64 + threadIdx.x;
     const int sidx = gid >> 2, root = gid & 3;
     if (sidx >= S || (n_dev && sidx >= *n_dev)) return;
-    // slots without a valid pose are NaN (p3p.h: the shared, not-inlined solve of one root)
+    // slots without a valid pose are NaN (p3p.h p3p_sample_root: the solve of one root, force-inlined here and into acr_round_kernel; the two
+    // copies are held to the same bits by tests/test_gpu_acransac.py::test_pose_many_seeds_same_bits_as_p3p_kernel, the gate to re-run
+    // on every compiler bump)
     p3p_sample_root(X, x, K, samples[3 * sidx], samples[3 * sidx + 1], samples[3 * sidx + 2], N, root, Rt + (size_t)48 * sidx + 12 * root);
 }
 

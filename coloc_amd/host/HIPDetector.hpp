@@ -131,6 +131,10 @@ public:
             regions[idx]->Features()[i] = { feat[4 * i], feat[4 * i + 1], feat[4 * i + 2], feat[4 * i + 3] };
             std::memcpy(&(regions[idx]->Descriptors()[i]), &(desc[i * 8]), 8 * sizeof(uint64_t));
         }
+        // the rows just stored in regions[idx] are still in this context's device memory: publish them, so that a HIPMatcher call that
+        // is handed regions[idx]->DescriptorRawData() on the same device reads them there instead of uploading them again (the
+        // reference re-uploads per call, GPUMatcher.hpp:188-196).  A miss costs nothing; a failure to publish is not an error.
+        if (!kps.empty()) (void)clc_desc_cache_publish(ctx_, nullptr, regions[idx]->DescriptorRawData(), static_cast<int>(kps.size()));
         return EXIT_SUCCESS;
     }
 

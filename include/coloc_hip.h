@@ -202,6 +202,17 @@ int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4);
  * (the reference's 100000 / 200000 "none" sentinels read as 65535). */
 int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt, int threshold,
                   int32_t* h_match, uint16_t* h_best, uint16_t* h_second);
+/* Detector -> matcher hand-over without a second upload.  The reference passes descriptors between the two through host memory
+ * (FeatureMap regions, GPUDetector.hpp:181 -> GPUMatcher.hpp:188-196) and uploads them again in every match call.  A host that has
+ * just copied n rows from device memory (d_src; NULL = this context's own descriptor array, i.e. what clc_detect_and_describe filled)
+ * to the host block h_desc can publish that fact: the rows are kept in a process-wide, per-device cache, and clc_match_2nn /
+ * clc_match_map / clc_match_pairs skip the upload of any block they are given whose ADDRESS and COUNT match an entry and whose first
+ * and last 64-byte rows still equal the published ones (compared byte for byte).  Anything else is uploaded as before, so a stale or
+ * rewritten block can only miss.  Up to 32 blocks, least recently used replaced; CLC_DESC_CACHE=0 in the environment disables it. */
+int clc_desc_cache_publish(clc_ctx* ctx, const void* d_src, const void* h_desc, int n);
+int clc_desc_cache_clear(void);
+/* lookups of the host-pointer match entry points answered from the cache / uploaded, since the process started */
+int clc_desc_cache_stats(unsigned long long* hits, unsigned long long* misses);
 /* Device-resident form; d_q / d_t must be 16-byte aligned. */
 int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt,
                       int threshold, int32_t* d_match, void* stream);

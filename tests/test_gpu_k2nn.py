@@ -289,3 +289,47 @@ def test_counted_jobs_read_their_sizes_on_the_device(gpu_ctx, oracle):
         want = oracle.k2nn(A[:na], B[:nb], 40) if na and nb else np.full(na, -1, np.int32)
         assert np.array_equal(got[:na], want), (na, nb)
         assert (got[na:] == -1).all(), (na, nb)
+
+
+def test_descriptor_cache_hits_only_on_the_published_block(oracle):
+    """clc_desc_cache_publish: descriptors the detector left on the device are found by the host-pointer match entry points when
+    they are handed the very host block that was published (same address, same count, same first and last row) -- and only then.
+    Every variant must give the oracle's matches; the hit / miss counters say which path answered."""
+    from coloc_amd import Context
+    from coloc_amd.abi import desc_cache_stats
+    W, H = 320, 240
+    det = Context(device=0, width=W, height=H, maxkp=8000, matcher=False)
+    mat = Context(device=0, width=W, height=H, maxkp=8000, detector=False)
+    img = synth.rect_image(W, H, n_rect=150, seed=31, noise_sigma=2.0)
+    kps, desc, _ = det.detect_and_describe(img)
+    assert len(desc) > 500 and desc.flags["C_CONTIGUOUS"]
+    other = synth.random_descriptors(1500, seed=32)
+    other[:400] = desc[:400]
+    other[:400, 7] ^= 0x21
+    want = oracle.k2nn(desc, other, 40)
+    h0, m0 = desc_cache_stats()
+    assert np.array_equal(mat.match_2nn(desc, other, 40), want)                 # nothing published yet: both blocks uploaded
+    h1, m1 = desc_cache_stats()
+    assert h1 == h0 and m1 == m0 + 2
+    det.desc_cache_publish(desc)                                                # the rows are still in det's device buffer
+    assert np.array_equal(mat.match_2nn(desc, other, 40), want)                 # query block found on the device
+    h2, m2 = desc_cache_stats()
+    assert h2 == h1 + 1 and m2 == m1 + 1
+    assert np.array_equal(mat.match_2nn(other, desc, 40), oracle.k2nn(other, desc, 40))      # ... also as the train block
+    assert desc_cache_stats()[0] == h2 + 1
+    copy = desc.copy()                                                          # same content, another address: uploaded
+    assert np.array_equal(mat.match_2nn(copy, other, 40), want)
+    assert desc_cache_stats()[0] == h2 + 1
+    assert np.array_equal(mat.match_2nn(desc[:-1], other, 40), want[:-1])       # same address, another count: uploaded
+    assert desc_cache_stats()[0] == h2 + 1
+    desc[0, 3] ^= 0xFF                                                          # the host block changes at its first row: the entry is dropped
+    assert np.array_equal(mat.match_2nn(desc, other, 40), oracle.k2nn(desc, other, 40))
+    assert desc_cache_stats()[0] == h2 + 1
+    # map matching and the all-pairs entry take published blocks too
+    det.desc_cache_publish(desc)
+    mat.set_map(other)
+    assert np.array_equal(mat.match_map(desc, 60), oracle.k2nn(desc, other, 60))
+    res = mat.match_pairs([desc, other], [(0, 1), (1, 0)], 40)
+    assert np.array_equal(res[0], oracle.k2nn(desc, other, 40)) and np.array_equal(res[1], oracle.k2nn(other, desc, 40))
+    assert desc_cache_stats()[0] >= h2 + 3
+    det.close(); mat.close()
