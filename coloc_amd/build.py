@@ -17,8 +17,8 @@ HEADERS = ["clc_internal.h", "clc_sincos.h", "clc_acr.h", "p3p.h", "fivept.h", "
 # evaluate in source order without fused multiply-add.
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in plain VGPRs (gfx950's register file is unified), so the K2NN top-2 reads
 # them directly instead of through v_accvgpr_read copies.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-mllvm", "-amdgpu-mfma-vgpr-form", "-ldl"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
 
 
 def hipcc_path():
@@ -40,12 +40,33 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into coloc_amd/lib/libcoloc_hip.so."""
     if not force and not needs_build():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    # CLC_EXTRA_FLAGS: extra compiler flags for experiments (e.g. "-DCLC_K2NN_AHEAD=2"); not set in any shipped build
-    cmd = [hipcc_path()] + FLAGS + os.environ.get("CLC_EXTRA_FLAGS", "").split() + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    # CLC_EXTRA_FLAGS: extra compiler flags for experiments (e.g. "-DCLC_K2NN_AHEAD=2"); not set in any shipped build (their objects
+    # are kept apart from the shipped build's)
+    extra = os.environ.get("CLC_EXTRA_FLAGS", "").split()
+    objdir = os.path.join(LIBDIR, "obj_extra" if extra else "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hipcc = hipcc_path()
+    # one translation unit per process, all of them at once (the sources are independent; a single hipcc call compiles them one after
+    # the other: 25 s against 10 s on the 8 cores of the build container), then one link
+    hdr_time = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS if os.path.exists(os.path.join(CSRC, h)))
+    hdr_time = max(hdr_time, os.path.getmtime(os.path.abspath(__file__)))
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        stale = force or extra or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(os.path.join(CSRC, src)), hdr_time)
+        if stale:
+            jobs.append([hipcc] + CFLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj])
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        for j in jobs:
+            print(" ".join(j))
+    procs = [subprocess.Popen(j, cwd=CSRC) for j in jobs]
+    failed = [j for j, p in zip(jobs, procs) if p.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    link = [hipcc] + LDFLAGS + ["-o", LIB] + [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=CSRC)
     return LIB
 
 
