@@ -15,8 +15,9 @@
 //     j == cols-35 the shift count is 32 = a shift by 0 on x86, so the last 32 columns of THAT ROW
 //     are dropped.  Only widths with cols % 16 == 6 can get there (level 6 of a 640-wide pyramid is
 //     214 px wide).  The tiles of such a level that touch its last 35 columns replay the walk for
-//     their own rows first (pre-test bits of the whole row by ballot, then one lane per row walks
-//     them), so the output is identical to the compiled reference (tests compare against oracle/_ref).
+//     their own rows first (one flag per 16-column group of the row -- all the walk ever asks --, then
+//     one lane per row walks them), so the output is identical to the compiled reference (tests
+//     compare against oracle/_ref).
 //   * orientation = fastAtan2(sum r*I, sum c*I) over the 37-pixel disc, 7th-order odd polynomial,
 //     fp32 in source order, no FMA contraction.
 //
@@ -42,7 +43,7 @@ static constexpr int kTileW = 64, kTileH = 16;
 static constexpr int kImgRows = kTileH + 8, kImgStride = kTileW + 8;        // tile + 3 px ring + 1 px NMS border, each side
 static constexpr int kScRows = kTileH + 2, kScStride = kTileW + 8;          // score tile: column c of the region at byte c + 3
 static constexpr int kRegion = (kTileW + 2) * (kTileH + 2);                 // pixels whose score the tile needs
-static constexpr int kWalkWords = 2 * ((CLC_DETECT_MAX_WIDTH + 63) / 64) + 2; // pre-test bits of a row, as dwords (+ padding)
+static constexpr int kWalkWords = 2 * ((CLC_DETECT_MAX_WIDTH + 255) / 256) + 2; // a row's 16-column group flags, a nibble each (+ padding)
 
 struct DetectArgs {
     PyramidDesc pd;
@@ -118,38 +119,73 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
     if (tid == 0) { s_ncand = 0u; s_nkp = 0u; }
 
     // ---- KFAST.h:245 replay: does the walk of row gy land on cols - 35?  (levels of width 6 mod 16, tiles at the right end)
+#ifdef CLC_DET_ABL_NOWALK
+    const bool walk = false;
+#else
     const bool walk = (cols % 16 == 6) && cols >= 38 && (x0 + kTileW + 1 >= cols - 35);
+#endif
     if (walk) {
-        const int nbits = cols - 7;                         // pre-test bits of columns 3 .. cols - 5
-        const int nchunks = (nbits + 63) >> 6;
-        for (int r = (int)wave; r < kScRows; r += 4) {
-            const int gy = y0 - 1 + r;
-            const bool row_ok = gy >= 3 && gy < rows - 3;
-            const uint8_t* __restrict__ prow = img + (size_t)(row_ok ? gy : 3) * pitch;
-            for (int c = 0; c < nchunks; ++c) {
-                const int x = 3 + 64 * c + (int)lane;
-                bool pre = false;
-                if (row_ok && x <= cols - 5) {
-                    const uint8_t* p = prow + x;
-                    pre = pretest4(p[0], p[-3 * pitch], p[3], p[3 * pitch], p[-3], t);
-                }
-                const uint64_t m = __ballot(pre);
-                if (lane == 0) { s_walk[r][2 * c] = (uint32_t)m; s_walk[r][2 * c + 1] = (uint32_t)(m >> 32); }
+        // The walk only ever asks two things of a 32-column block at j = 3 + 16 g: is any pre-test bit set, and is its low half empty --
+        // i.e. it needs any(g) = "some pixel of columns 3 + 16 g .. 18 + 16 g passes the pre-test" per 16-column group.  A lane takes four
+        // columns 4 l .. 4 l + 3 of a row as dwords (3 of the centre row, 1 each of the rows 3 above and below: five loads instead
+        // of twenty byte loads), a wave instruction covers 256 columns, and all the loads of the wave's rows (w, w + 4, ..: five at most)
+        // are in flight together -- one load latency per 256 columns of width, where one ballot per 64 columns of one row cost
+        // 18 dependent steps (3.6 us per tile at 214 columns).  Lane 4 g' + r: r = 0 -> its columns 0..2 belong to group g' - 1, column 3 to
+        // g'; r != 0 -> all four to g'.  C = ballot(own group) | ballot(previous group) >> 4 then holds any(g) in nibble g.
+        const int nunits = (cols + 255) >> 8;                    // 256-column units per row (<= 16)
+        for (int c = 0; c < nunits; ++c) {
+            const int xl = 256 * c + 4 * (int)lane;              // first of this lane's four columns
+            uint32_t ctr0[5], ctr1[5], ctr2[5], top[5], bot[5];
+#pragma unroll
+            for (int ri = 0; ri < 5; ++ri) {
+                const int r = (int)wave + 4 * ri;
+                const int gy = y0 - 1 + r;
+                const bool ok = r < kScRows && gy >= 3 && gy < rows - 3 && xl < pitch;
+                const uint8_t* p = img + (size_t)(ok ? gy : 3) * pitch + (ok ? xl : 0);
+                ctr0[ri] = (ok && xl >= 4) ? *reinterpret_cast<const uint32_t*>(p - 4) : 0u;
+                ctr1[ri] = ok ? *reinterpret_cast<const uint32_t*>(p) : 0u;
+                ctr2[ri] = (ok && xl + 4 < pitch) ? *reinterpret_cast<const uint32_t*>(p + 4) : 0u;
+                top[ri] = ok ? *reinterpret_cast<const uint32_t*>(p - 3 * pitch) : 0u;
+                bot[ri] = ok ? *reinterpret_cast<const uint32_t*>(p + 3 * pitch) : 0u;
             }
-            if (lane == 0) { s_walk[r][2 * nchunks] = 0u; s_walk[r][2 * nchunks + 1] = 0u; }
+#pragma unroll
+            for (int ri = 0; ri < 5; ++ri) {
+                const int r = (int)wave + 4 * ri;
+                const int gy = y0 - 1 + r;
+                const bool ok = r < kScRows && gy >= 3 && gy < rows - 3;
+                const uint64_t lo64 = (uint64_t)ctr0[ri] | ((uint64_t)ctr1[ri] << 32);     // columns xl - 4 .. xl + 3
+                const uint64_t hi64 = (uint64_t)ctr1[ri] | ((uint64_t)ctr2[ri] << 32);     // columns xl .. xl + 7
+                bool own = false, prev = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = xl + k;
+                    const int cc = (int)((ctr1[ri] >> (8 * k)) & 0xFFu);
+                    const int left = (int)((lo64 >> (8 * (k + 1))) & 0xFFu), right = (int)((hi64 >> (8 * (k + 3))) & 0xFFu);
+                    const int up = (int)((top[ri] >> (8 * k)) & 0xFFu), down = (int)((bot[ri] >> (8 * k)) & 0xFFu);
+                    const bool pre = ok && x >= 3 && x <= cols - 5 && pretest4(cc, up, right, down, left, t);
+                    if ((lane & 3u) == 0u && k < 3) prev |= pre; else own |= pre;
+                }
+                const uint64_t b_own = __ballot(own), b_prev = __ballot(prev);
+                if (lane == 0 && r < kScRows) {
+                    const uint64_t cmask = b_own | (b_prev >> 4);                      // nibble g of unit c: any(16 c + g)
+                    s_walk[r][2 * c] = (uint32_t)cmask; s_walk[r][2 * c + 1] = (uint32_t)(cmask >> 32);
+                    // columns 0..2 of a unit behind the first belong to the LAST group of the unit before (this lane stored it a step ago)
+                    if (c > 0 && (b_prev & 1ull)) s_walk[r][2 * c - 1] |= 0xF0000000u;
+                }
+            }
         }
+        if (tid < (uint32_t)kScRows) { s_walk[tid][2 * nunits] = 0u; s_walk[tid][2 * nunits + 1] = 0u; }
         __syncthreads();
         if (tid < (uint32_t)kScRows) {
             const int gy = y0 - 1 + (int)tid;
             if (gy >= 3 && gy < rows - 3) {
-                int j = 3;
-                while (j < cols - 35) {
-                    const int bit = j - 3;                  // a multiple of 16
-                    const uint32_t lo = s_walk[tid][bit >> 5], hi = s_walk[tid][(bit >> 5) + 1];
-                    const uint32_t m = (bit & 16) ? ((lo >> 16) | (hi << 16)) : lo;
-                    j += (m != 0u && (m & 0xFFFFu) == 0u) ? 16 : 32;
+                int g = 0;                                                              // j = 3 + 16 g
+                while (3 + 16 * g < cols - 35) {
+                    const uint32_t w0 = s_walk[tid][g >> 3], w1 = s_walk[tid][(g + 1) >> 3];
+                    const bool a0 = ((w0 >> (4 * (g & 7))) & 0xFu) != 0u, a1 = ((w1 >> (4 * ((g + 1) & 7))) & 0xFu) != 0u;
+                    g += (!a0 && a1) ? 1 : 2;                                           // KFAST.h:259-265: retreat when only the high half has bits
                 }
-                s_drop[tid] = (j == cols - 35) ? 1u : 0u;
+                s_drop[tid] = (3 + 16 * g == cols - 35) ? 1u : 0u;
             }
         }
     }
@@ -284,6 +320,7 @@ __global__ __launch_bounds__(256) void detect_emit_kernel(const DetectArgs a, co
                                                           const uint32_t* __restrict__ tcount_base)
 {
     __shared__ uint32_t s_part[4];
+    __shared__ uint32_t s_list[256 * 32];           // x | row << 16 of the keypoints of up to 256 mask words
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t cam = blockIdx.y, band = blockIdx.x;
     const int lv = level_of(a.band_begin, a.pd.levels, band);
@@ -321,39 +358,44 @@ __global__ __launch_bounds__(256) void detect_emit_kernel(const DetectArgs a, co
         const uint32_t inc = wave_inclusive_scan(c, lane);
         if (lane == 63u) s_part[wave] = inc;
         __syncthreads();
-        uint32_t before = carry;
+        uint32_t before = 0;
         for (uint32_t w = 0; w < wave; ++w) before += s_part[w];
         const uint32_t total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-        __syncthreads();
-        uint32_t slot = before + inc - c;
-        const int y = (int)(ty * kTileH + r);
+        // the keypoints of these 256 words, in order, into one list: afterwards EVERY thread takes one keypoint (a thread that walked
+        // the bits of its own word paid one load latency per keypoint of that word; strict 3 x 3 suppression leaves at most 32 per word)
+        uint32_t k = before + inc - c;
         while (m != 0ull) {
-            const int b = __builtin_ctzll(m);
+            const uint32_t b = (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
-            if (slot < a.maxkp) {
-                const int x = (int)(tx * kTileW) + b;
-                int xs = 0, ys = 0;
-#pragma unroll
-                for (int rr = -3; rr <= 3; ++rr) {
-                    const int hw = (rr == -3 || rr == 3) ? 1 : ((rr == -2 || rr == 2) ? 2 : 3);
-                    const uint8_t* q = img + (size_t)(y + rr) * L.pitch + x;
-#pragma unroll
-                    for (int cc = -3; cc <= 3; ++cc) {
-                        if (cc < -hw || cc > hw) continue;
-                        const int v = q[cc];
-                        xs += cc * v;
-                        ys += rr * v;
-                    }
-                }
-                clc_keypoint kp;
-                kp.x = x; kp.y = y;
-                kp.score = score[(size_t)y * L.pitch + x];
-                kp.angle = fast_atan2((float)(int16_t)ys, (float)(int16_t)xs);
-                kp.scale = (uint8_t)lv;
-                kps[slot] = kp;
-            }
-            ++slot;
+            s_list[k++] = (tx * kTileW + b) | (r << 16);
         }
+        __syncthreads();
+        for (uint32_t q = tid; q < total; q += 256u) {
+            const uint32_t slot = carry + q;
+            if (slot >= a.maxkp) break;
+            const uint32_t e = s_list[q];
+            const int x = (int)(e & 0xFFFFu), y = (int)(ty * kTileH + (e >> 16));
+            int xs = 0, ys = 0;
+#pragma unroll
+            for (int rr = -3; rr <= 3; ++rr) {
+                const int hw = (rr == -3 || rr == 3) ? 1 : ((rr == -2 || rr == 2) ? 2 : 3);
+                const uint8_t* q8 = img + (size_t)(y + rr) * L.pitch + x;
+#pragma unroll
+                for (int cc = -3; cc <= 3; ++cc) {
+                    if (cc < -hw || cc > hw) continue;
+                    const int v = q8[cc];
+                    xs += cc * v;
+                    ys += rr * v;
+                }
+            }
+            clc_keypoint kp;
+            kp.x = x; kp.y = y;
+            kp.score = score[(size_t)y * L.pitch + x];
+            kp.angle = fast_atan2((float)(int16_t)ys, (float)(int16_t)xs);
+            kp.scale = (uint8_t)lv;
+            kps[slot] = kp;
+        }
+        __syncthreads();
         carry += total;
     }
     // the last band of the camera knows the total
