@@ -44,6 +44,11 @@ def test_default_line_has_contract_fields():
     assert d["pose_solve_p50_ms"] > 0 and "section_errors" not in d
     assert 0 < d["pose_solve_p50_ms_c_abi"] <= d["pose_solve_p50_ms"] * 1.2      # the same solve without the wrapper's allocations
     assert d["settle"]["steps"] == 1000                              # the clock-settling steps are reported, not hidden
+    assert d["warmup_effective"] == 3 + 20 + 1000 + 3 and 0 < d["value_cold"] <= 1.05 * d["value"]     # and so is the cold figure
+    fe = d["front_end"]                                              # the rebuilt detector: two launches, <= 25 us per 640x480 frame
+    assert fe["detect_us"] < 25.0 and fe["batch_of_8_us_per_camera"] < fe["frame_us_no_events"]
+    assert d["stages"]["config2"]["real_front_end"]["Mmatches_per_s"] > 0
+    assert d["host_path"]["match_2nn_10k_x_10k_published_blocks_us"] < d["host_path"]["match_2nn_10k_x_10k_us"]
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["openmvg_ratio_rule"]["value"] > 0
     assert d["value"] > 10 * c["value"]          # north-star target: >= 10x the host-CPU matcher
@@ -58,6 +63,13 @@ def test_two_rank_rehearsal_runs():
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["config"]["pairs"] == 1 and d["value"] > 0 and "REHEARSAL" in d["collective"]
+    # the guarded legs that run the same step through the C multi-camera entry points (clc-rccl / clc-peer at N > 1; rehearsal handles
+    # here: the ranks share the one GPU) went through their whole control flow and reproduced the headline exchange's matches
+    legs = d["exchange_legs"]
+    assert set(legs) == {"clc-rccl", "clc-peer"}
+    for leg in legs.values():
+        assert leg["identical"] is True and leg["us_per_step"] > 0 and "error" not in leg
+    assert d["value_cold"] > 0 and d["warmup_effective"] >= d["warmup"]
 
 
 def test_four_rank_rehearsal_runs():
@@ -71,6 +83,7 @@ def test_four_rank_rehearsal_runs():
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
     assert d["n_gpus"] == 4 and d["config"]["pairs"] == 6 and d["value"] > 0 and "REHEARSAL" in d["collective"]
+    assert all(leg["identical"] is True for leg in d["exchange_legs"].values())
 
 
 def test_streaming_scenario_runs_and_localizes():

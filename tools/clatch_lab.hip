@@ -606,7 +606,7 @@ static float time_variant(const char* name, const PyramidDesc& pd, const uint8_t
                           unsigned dyn_lds = 0, int grid = 0, int v3 = -1)
 {
     if (!selected(name, n)) return 0.f;
-    ClatchArgs a; a.pd = pd; a.slot_stride = 0; a.n_dev = nullptr;
+    ClatchArgs a; a.pd = pd; a.slot_stride = 0; for (int b = 0; b < kMaxBatch; ++b) a.n_dev[b] = nullptr;
     for (int b = 0; b < kMaxBatch; ++b) { a.cam.kps[b] = nullptr; a.cam.desc[b] = nullptr; a.cam.n[b] = 0; }
     a.cam.kps[0] = dk; a.cam.desc[0] = dd; a.cam.n[0] = n;
     auto launch = [&]() {
@@ -652,7 +652,7 @@ static void stamp_report(const PyramidDesc& pd, const uint8_t* darena, const clc
     if (!selected(which == 10 ? "stamps pool" : which ? "stamps v3" : "stamps", n)) return;
     uint64_t* dst; CHECK(hipMalloc((void**)&dst, (size_t)n * 16 * 8)); CHECK(hipMemset(dst, 0, (size_t)n * 16 * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst)));
-    ClatchArgs a; a.pd = pd; a.slot_stride = 0; a.n_dev = nullptr;
+    ClatchArgs a; a.pd = pd; a.slot_stride = 0; for (int b = 0; b < kMaxBatch; ++b) a.n_dev[b] = nullptr;
     for (int b = 0; b < kMaxBatch; ++b) { a.cam.kps[b] = nullptr; a.cam.desc[b] = nullptr; a.cam.n[b] = 0; }
     a.cam.kps[0] = dk; a.cam.desc[0] = dd; a.cam.n[0] = n;
     for (int i = 0; i < 5; ++i) {
