@@ -77,7 +77,7 @@ def cpu_baseline(desc_q, desc_t, xy_q, xy_t):
 
 
 def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_match, n_out, mine, arena, counts,
-                      img_ptrs, kp_ptrs, sptr, mc_headline):
+                      img_ptrs, kp_ptrs, sptr, mc_headline, fallback_line):
     """bench.py --gpus N, after the headline measurement: the same step through clc_mc_gather_enqueue_dev + clc_mc_match_enqueue_dev
     with the RCCL all-gather (clc-rccl) and with IPC peer copies (clc-peer); each leg's matches are compared with the headline
     exchange's, each is timed over 20 steps (max over ranks).  With --backend gloo (ranks sharing a GPU: no communicator possible) the
@@ -97,9 +97,9 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
     def watchdog():
         sys.stderr.write("bench.py: an exchange leg did not return within its limit (rank %d); legs so far: %s\n" % (rank, json.dumps(out)))
         sys.stderr.flush()
-        if rank == 0:
-            print(json.dumps({"metric": "Mmatches/s (512-bit Hamming comparisons) at 10k kp/img, describe+match step", "value": None,
-                              "error": "exchange leg hung", "exchange_legs": out}), flush=True)
+        if rank == 0:          # the headline was measured before the legs: it is not lost with them
+            print(json.dumps(dict(fallback_line, exchange_legs=dict(out, error="an exchange leg did not return within its limit"),
+                                  section_errors=["exchange_legs"])), flush=True)
         os._exit(4)
 
     # the reference result: one more step of the headline exchange
@@ -414,8 +414,16 @@ def main():
     # process (rank 0 prints the line first) if a leg does not come back.
     exchange_legs = None
     if world > 1 and not args.no_exchange_legs:
+        # what rank 0 prints if a leg hangs: the contract's fields of the headline measurement, already complete at this point
+        fallback_line = {"metric": "Mmatches/s (512-bit Hamming comparisons) at 10k kp/img, describe+match step",
+                         "value": total_cmp / (dt / args.steps) / 1e6, "unit": "Mmatches/s", "n_gpus": world, "steps": args.steps,
+                         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                         "dtype": "fp4 (+-1) x fp4 -> f32 accumulate, exact integers (matrix pipe); fp32 sample coords", "data": "synthetic",
+                         "config": {"workload": "config[3]: %d cameras one-per-GPU, 640x480 x 10k kp, all-gather + %d pairs"
+                                                % (world, len(multicam.exhaustive_pairs(world))), "keypoints_per_image": NKP},
+                         "roofline": None, "cpu_baseline": None}
         exchange_legs = run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_match, n_out, mine, arena, counts,
-                                          img_ptrs, kp_ptrs, sptr, mc)
+                                          img_ptrs, kp_ptrs, sptr, mc, fallback_line)
         for k, v in exchange_legs.items():
             if isinstance(v, dict) and (v.get("error") or v.get("identical") is False):
                 errors.append("exchange_legs." + k)
