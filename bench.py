@@ -413,6 +413,7 @@ def main():
     # ranks agree on the outcome through torch.distributed before anyone enters the next collective, and a watchdog ends the
     # process (rank 0 prints the line first) if a leg does not come back.
     exchange_legs = None
+    legs_aborted = False
     if world > 1 and not args.no_exchange_legs:
         # what rank 0 prints if a leg hangs: the contract's fields of the headline measurement, already complete at this point
         fallback_line = {"metric": "Mmatches/s (512-bit Hamming comparisons) at 10k kp/img, describe+match step",
@@ -422,10 +423,14 @@ def main():
                          "config": {"workload": "config[3]: %d cameras one-per-GPU, 640x480 x 10k kp, all-gather + %d pairs"
                                                 % (world, len(multicam.exhaustive_pairs(world))), "keypoints_per_image": NKP},
                          "roofline": None, "cpu_baseline": None}
-        exchange_legs = run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_match, n_out, mine, arena, counts,
-                                          img_ptrs, kp_ptrs, sptr, mc, fallback_line)
+        try:
+            exchange_legs = run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_match, n_out, mine, arena, counts,
+                                              img_ptrs, kp_ptrs, sptr, mc, fallback_line)
+        except Exception as exc:           # outside the legs' own guards: this rank's view of the group can no longer be trusted
+            exchange_legs = {"error": "exchange legs aborted on rank %d: %r" % (rank, exc)}
+            legs_aborted = True
         for k, v in exchange_legs.items():
-            if isinstance(v, dict) and (v.get("error") or v.get("identical") is False):
+            if (isinstance(v, dict) and (v.get("error") or v.get("identical") is False)) or k == "error":
                 errors.append("exchange_legs." + k)
 
     if rank == 0:
@@ -444,7 +449,7 @@ def main():
             # measured HBM traffic of this kernel comes from separate rocprofv3 --pmc passes (profiles/); it is attached
             # only when the recorded plan (formulation, shape) is the one that just ran, and says where it came from
             traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_k2nn_hbm_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r04_k2nn_hbm_traffic.json")
             if os.path.exists(tpath) and world == 1:
                 try:
                     rec = json.load(open(tpath))
@@ -879,6 +884,9 @@ def main():
         if errors:
             out["section_errors"] = errors
         print(json.dumps(out), flush=True)
+    if legs_aborted:                    # no further collective with a group in an unknown state: the line is out, leave
+        sys.stdout.flush()
+        os._exit(3)
     if mc is not None:
         mc.close()
     ctx.close()
