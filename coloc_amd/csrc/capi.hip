@@ -857,7 +857,7 @@ static const uint8_t* cache_acquire(const int device, const void* h, const int n
         const uint8_t* hb = (const uint8_t*)h;
         if (memcmp(hb, en.first, CLC_DESC_BYTES) != 0 || memcmp(hb + (size_t)(n - 1) * CLC_DESC_BYTES, en.last, CLC_DESC_BYTES) != 0) {
             if (en.busy == 0) en.h = nullptr;            // the host block has been rewritten: forget the entry
-            break;
+            continue;                                    // (a newer entry for the same address may follow)
         }
         en.stamp = ++c.clock;
         ++en.busy;
