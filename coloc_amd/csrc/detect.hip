@@ -43,6 +43,7 @@ static constexpr int kTileW = 64, kTileH = 16;
 static constexpr int kImgRows = kTileH + 8, kImgStride = kTileW + 8;        // tile + 3 px ring + 1 px NMS border, each side
 static constexpr int kScRows = kTileH + 2, kScStride = kTileW + 8;          // score tile: column c of the region at byte c + 3
 static constexpr int kRegion = (kTileW + 2) * (kTileH + 2);                 // pixels whose score the tile needs
+static constexpr int kCandPerWave = 64 * ((kRegion + 255) / 256);           // a wave pre-tests every fourth 64-pixel run of the region
 static constexpr int kWalkWords = 2 * ((CLC_DETECT_MAX_WIDTH + 255) / 256) + 2; // a row's 16-column group flags, a nibble each (+ padding)
 
 struct DetectArgs {
@@ -86,11 +87,11 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
     constexpr int k_dy[16] = { 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3 };
     __shared__ __attribute__((aligned(16))) uint8_t s_img[kImgRows * kImgStride];
     __shared__ __attribute__((aligned(16))) uint8_t s_sc[kScRows * kScStride];
-    __shared__ uint16_t s_cand[kRegion];
+    __shared__ uint16_t s_cand[4][kCandPerWave];      // wave-private candidate lists: no atomic, no barrier between pre-test and ring stage
     __shared__ uint32_t s_walk[kScRows][kWalkWords];
     __shared__ uint32_t s_mask[kTileH][2];
     __shared__ uint32_t s_drop[kScRows];
-    __shared__ uint32_t s_ncand, s_nkp;
+    __shared__ uint32_t s_nkp;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t cam = blockIdx.y;
@@ -116,14 +117,10 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
     for (uint32_t i = tid; i < (uint32_t)(kScRows * kScStride / 4); i += 256u) reinterpret_cast<uint32_t*>(s_sc)[i] = 0u;
     if (tid < (uint32_t)kTileH * 2u) s_mask[tid >> 1][tid & 1u] = 0u;
     if (tid < (uint32_t)kScRows) s_drop[tid] = 0u;
-    if (tid == 0) { s_ncand = 0u; s_nkp = 0u; }
+    if (tid == 0) s_nkp = 0u;
 
     // ---- KFAST.h:245 replay: does the walk of row gy land on cols - 35?  (levels of width 6 mod 16, tiles at the right end)
-#ifdef CLC_DET_ABL_NOWALK
-    const bool walk = false;
-#else
     const bool walk = (cols % 16 == 6) && cols >= 38 && (x0 + kTileW + 1 >= cols - 35);
-#endif
     if (walk) {
         // The walk only ever asks two things of a 32-column block at j = 3 + 16 g: is any pre-test bit set, and is its low half empty --
         // i.e. it needs any(g) = "some pixel of columns 3 + 16 g .. 18 + 16 g passes the pre-test" per 16-column group.  A lane takes four
@@ -133,6 +130,7 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
         // 18 dependent steps (3.6 us per tile at 214 columns).  Lane 4 g' + r: r = 0 -> its columns 0..2 belong to group g' - 1, column 3 to
         // g'; r != 0 -> all four to g'.  C = ballot(own group) | ballot(previous group) >> 4 then holds any(g) in nibble g.
         const int nunits = (cols + 255) >> 8;                    // 256-column units per row (<= 16)
+        uint64_t row_flags = 0;                                  // nunits == 1: lane ri of a wave holds the group flags of its row w + 4 ri
         for (int c = 0; c < nunits; ++c) {
             const int xl = 256 * c + 4 * (int)lane;              // first of this lane's four columns
             uint32_t ctr0[5], ctr1[5], ctr2[5], top[5], bot[5];
@@ -166,6 +164,10 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
                     if ((lane & 3u) == 0u && k < 3) prev |= pre; else own |= pre;
                 }
                 const uint64_t b_own = __ballot(own), b_prev = __ballot(prev);
+                if (nunits == 1) {                                                     // the whole row in one word: lane ri keeps it
+                    if ((int)lane == ri) row_flags = b_own | (b_prev >> 4);
+                    continue;
+                }
                 if (lane == 0 && r < kScRows) {
                     const uint64_t cmask = b_own | (b_prev >> 4);                      // nibble g of unit c: any(16 c + g)
                     s_walk[r][2 * c] = (uint32_t)cmask; s_walk[r][2 * c + 1] = (uint32_t)(cmask >> 32);
@@ -174,24 +176,40 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
                 }
             }
         }
-        if (tid < (uint32_t)kScRows) { s_walk[tid][2 * nunits] = 0u; s_walk[tid][2 * nunits + 1] = 0u; }
-        __syncthreads();
-        if (tid < (uint32_t)kScRows) {
-            const int gy = y0 - 1 + (int)tid;
-            if (gy >= 3 && gy < rows - 3) {
-                int g = 0;                                                              // j = 3 + 16 g
+        if (nunits == 1) {
+            // rows of at most 256 columns (every pyramid level of a 640-wide image that can get here): the walk runs in registers on the
+            // lane that holds the row's flags -- no trip through LDS, no extra barrier
+            const int r = (int)wave + 4 * (int)lane;
+            const int gy = y0 - 1 + r;
+            if (lane < 5u && r < kScRows && gy >= 3 && gy < rows - 3) {
+                int g = 0;
                 while (3 + 16 * g < cols - 35) {
-                    const uint32_t w0 = s_walk[tid][g >> 3], w1 = s_walk[tid][(g + 1) >> 3];
-                    const bool a0 = ((w0 >> (4 * (g & 7))) & 0xFu) != 0u, a1 = ((w1 >> (4 * ((g + 1) & 7))) & 0xFu) != 0u;
-                    g += (!a0 && a1) ? 1 : 2;                                           // KFAST.h:259-265: retreat when only the high half has bits
+                    const bool a0 = ((row_flags >> (4 * g)) & 0xFull) != 0ull, a1 = ((row_flags >> (4 * g + 4)) & 0xFull) != 0ull;
+                    g += (!a0 && a1) ? 1 : 2;
                 }
-                s_drop[tid] = (3 + 16 * g == cols - 35) ? 1u : 0u;
+                s_drop[r] = (3 + 16 * g == cols - 35) ? 1u : 0u;
+            }
+        } else {
+            if (tid < (uint32_t)kScRows) { s_walk[tid][2 * nunits] = 0u; s_walk[tid][2 * nunits + 1] = 0u; }
+            __syncthreads();
+            if (tid < (uint32_t)kScRows) {
+                const int gy = y0 - 1 + (int)tid;
+                if (gy >= 3 && gy < rows - 3) {
+                    int g = 0;                                                          // j = 3 + 16 g
+                    while (3 + 16 * g < cols - 35) {
+                        const uint32_t w0 = s_walk[tid][g >> 3], w1 = s_walk[tid][(g + 1) >> 3];
+                        const bool a0 = ((w0 >> (4 * (g & 7))) & 0xFu) != 0u, a1 = ((w1 >> (4 * ((g + 1) & 7))) & 0xFu) != 0u;
+                        g += (!a0 && a1) ? 1 : 2;                                       // KFAST.h:259-265: retreat when only the high half has bits
+                    }
+                    s_drop[tid] = (3 + 16 * g == cols - 35) ? 1u : 0u;
+                }
             }
         }
     }
     __syncthreads();
 
-    // ---- phase 1: dense cardinal pre-test over the tile + 1 px border, survivors compacted into s_cand ----
+    // ---- phase 1: dense cardinal pre-test over the tile + 1 px border; every wave compacts its survivors into a list of its own ----
+    uint32_t ncand = 0;                                        // wave-uniform: candidates of THIS wave
     for (uint32_t i0 = 0; i0 < (uint32_t)kRegion; i0 += 256u) {
         const uint32_t i = i0 + tid;
         const int r = (int)(i / (kTileW + 2)), c = (int)(i - (uint32_t)r * (kTileW + 2));
@@ -202,19 +220,15 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
             pre = pretest4(p[0], p[-3 * kImgStride], p[3], p[3 * kImgStride], p[-3], t);
         }
         const uint64_t m = __ballot(pre);
-        if (m != 0ull) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_ncand, (uint32_t)__popcll(m));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (pre) s_cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((r << 8) | c);
-        }
+        if (pre) s_cand[wave][ncand + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)((r << 8) | c);
+        ncand += (uint32_t)__popcll(m);
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the list is read by the wave that wrote it
+    __builtin_amdgcn_wave_barrier();
 
     // ---- phase 2: 16-ring test + corner score, one candidate per lane ---------------------------
-    const uint32_t ncand = s_ncand;
-    for (uint32_t i = tid; i < ncand; i += 256u) {
-        const uint32_t rc = s_cand[i];
+    for (uint32_t i = lane; i < ncand; i += 64u) {
+        const uint32_t rc = s_cand[wave][i];
         const int r = (int)(rc >> 8), c = (int)(rc & 0xFFu);
         const uint8_t* q = s_img + r * kImgStride + c;         // top-left of the 7 x 7 neighbourhood
         const int ctr = q[3 * kImgStride + 3];
