@@ -116,12 +116,13 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
     }
     for (uint32_t i = tid; i < (uint32_t)(kScRows * kScStride / 4); i += 256u) reinterpret_cast<uint32_t*>(s_sc)[i] = 0u;
     if (tid < (uint32_t)kTileH * 2u) s_mask[tid >> 1][tid & 1u] = 0u;
-    if (tid < (uint32_t)kScRows) s_drop[tid] = 0u;
     if (tid == 0) s_nkp = 0u;
 
     // ---- KFAST.h:245 replay: does the walk of row gy land on cols - 35?  (levels of width 6 mod 16, tiles at the right end)
     const bool walk = (cols % 16 == 6) && cols >= 38 && (x0 + kTileW + 1 >= cols - 35);
-    if (walk) {
+    if (!walk) {
+        if (tid < (uint32_t)kScRows) s_drop[tid] = 0u;           // (with the replay, every entry is written by the lane that walks its row)
+    } else {
         // The walk only ever asks two things of a 32-column block at j = 3 + 16 g: is any pre-test bit set, and is its low half empty --
         // i.e. it needs any(g) = "some pixel of columns 3 + 16 g .. 18 + 16 g passes the pre-test" per 16-column group.  A lane takes four
         // columns 4 l .. 4 l + 3 of a row as dwords (3 of the centre row, 1 each of the rows 3 above and below: five loads instead
@@ -181,19 +182,24 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
             // lane that holds the row's flags -- no trip through LDS, no extra barrier
             const int r = (int)wave + 4 * (int)lane;
             const int gy = y0 - 1 + r;
-            if (lane < 5u && r < kScRows && gy >= 3 && gy < rows - 3) {
-                int g = 0;
-                while (3 + 16 * g < cols - 35) {
-                    const bool a0 = ((row_flags >> (4 * g)) & 0xFull) != 0ull, a1 = ((row_flags >> (4 * g + 4)) & 0xFull) != 0ull;
-                    g += (!a0 && a1) ? 1 : 2;
+            if (lane < 5u && r < kScRows) {
+                uint32_t drop = 0u;
+                if (gy >= 3 && gy < rows - 3) {
+                    int g = 0;
+                    while (3 + 16 * g < cols - 35) {
+                        const bool a0 = ((row_flags >> (4 * g)) & 0xFull) != 0ull, a1 = ((row_flags >> (4 * g + 4)) & 0xFull) != 0ull;
+                        g += (!a0 && a1) ? 1 : 2;
+                    }
+                    drop = (3 + 16 * g == cols - 35) ? 1u : 0u;
                 }
-                s_drop[r] = (3 + 16 * g == cols - 35) ? 1u : 0u;
+                s_drop[r] = drop;
             }
         } else {
             if (tid < (uint32_t)kScRows) { s_walk[tid][2 * nunits] = 0u; s_walk[tid][2 * nunits + 1] = 0u; }
             __syncthreads();
             if (tid < (uint32_t)kScRows) {
                 const int gy = y0 - 1 + (int)tid;
+                uint32_t drop = 0u;
                 if (gy >= 3 && gy < rows - 3) {
                     int g = 0;                                                          // j = 3 + 16 g
                     while (3 + 16 * g < cols - 35) {
@@ -201,8 +207,9 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
                         const bool a0 = ((w0 >> (4 * (g & 7))) & 0xFu) != 0u, a1 = ((w1 >> (4 * ((g + 1) & 7))) & 0xFu) != 0u;
                         g += (!a0 && a1) ? 1 : 2;                                       // KFAST.h:259-265: retreat when only the high half has bits
                     }
-                    s_drop[tid] = (3 + 16 * g == cols - 35) ? 1u : 0u;
+                    drop = (3 + 16 * g == cols - 35) ? 1u : 0u;
                 }
+                s_drop[tid] = drop;
             }
         }
     }
