@@ -881,6 +881,12 @@ def main():
             guarded("pose_solve", sec_pose)
             guarded("two_view", sec_two_view)
             guarded("cpu_baseline", sec_cpu_baseline)
+        if world > 1:
+            # the side sections belong to the one-GPU line (cpu_baseline: rank 0 at N = 1 only, by the bench contract); their keys are
+            # present and null here so that lines of different N can be compared field by field
+            for k in ("cpu_baseline", "gpu_over_cpu", "front_end", "pose_solve", "pose_solve_p50_ms", "two_view", "host_path",
+                      "accepted_matches_per_step"):
+                out.setdefault(k, None)
         if errors:
             out["section_errors"] = errors
         print(json.dumps(out), flush=True)
