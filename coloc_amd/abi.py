@@ -41,6 +41,14 @@ class MatchJob(C.Structure):          # clc_match_job
                 ("out_offset", C.c_uint32), ("threshold", C.c_uint32)]
 
 
+class PoseJob(C.Structure):
+    """clc_pose_job (include/coloc_hip.h)"""
+    _fields_ = [("X", C.c_void_p), ("x", C.c_void_p), ("K", C.c_void_p), ("n", C.c_int), ("max_iteration", C.c_int), ("seed", C.c_uint64),
+                ("precision", C.c_double), ("refine", C.c_int), ("huber_a", C.c_double),
+                ("Rt", C.c_void_p), ("cov", C.c_void_p), ("inlier_mask", C.c_void_p), ("inliers", C.c_void_p),
+                ("n_inliers", C.c_int), ("iterations", C.c_int), ("status", C.c_int), ("error_max", C.c_double), ("rmse", C.c_double)]
+
+
 EXPORTS = [
     "clc_abi_version", "clc_status_string", "clc_ctx_create", "clc_ctx_destroy", "clc_last_error_string",
     "clc_sync", "clc_stream", "clc_pyramid_build", "clc_pyramid_build_dev", "clc_pyramid_level",
@@ -48,7 +56,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
@@ -117,6 +125,7 @@ def load_library():
     lib.clc_desc_cache_publish.argtypes = [vp, vp, vp, ci]
     lib.clc_desc_cache_clear.argtypes = []
     lib.clc_desc_cache_stats.argtypes = [vp, vp]
+    lib.clc_pnp_localize_ac_batch.argtypes = [vp, vp, ci]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
     lib.clc_match_2nn_dev.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp]
@@ -273,6 +282,41 @@ class MultiCam:
         if getattr(self, "h", None):
             self.lib.clc_mc_destroy(self.h)
             self.h = None
+
+
+def pnp_localize_batch(ctxs, problems, max_iteration=256, seeds=None, precision=float("inf"), refine=True, huber_a=16.0):
+    """clc_pnp_localize_ac_batch: problems = [(X, x, K), ...], one context per problem (all on one device); the a-contrario solves run
+    interleaved on the GPU, driven by one host thread.  Returns a list of dicts like Context.pnp_acransac's."""
+    lib = load_library()
+    n = len(problems)
+    assert len(ctxs) == n
+    jobs = (PoseJob * n)()
+    keep = []
+    for i, (X, x, K) in enumerate(problems):
+        X = np.ascontiguousarray(X, dtype=np.float64); x = np.ascontiguousarray(x, dtype=np.float64)
+        K = np.ascontiguousarray(K, dtype=np.float64).reshape(9)
+        N = X.shape[0]
+        Rt, cov = np.zeros(12), np.zeros(36)
+        mask, inl = np.zeros(max(N, 1), dtype=np.uint8), np.zeros(max(N, 1), dtype=np.int32)
+        keep.append((X, x, K, Rt, cov, mask, inl))
+        j = jobs[i]
+        j.X, j.x, j.K, j.n = X.ctypes.data, x.ctypes.data, K.ctypes.data, N
+        j.max_iteration, j.seed, j.precision = int(max_iteration), int(seeds[i] if seeds is not None else 1), float(precision)
+        j.refine, j.huber_a = (1 if refine else 0), float(huber_a)
+        j.Rt, j.cov, j.inlier_mask, j.inliers = Rt.ctypes.data, cov.ctypes.data, mask.ctypes.data, inl.ctypes.data
+    hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+    rc = lib.clc_pnp_localize_ac_batch(hs, jobs, n)
+    if rc != CLC_OK:
+        raise CLCError(rc, "clc_pnp_localize_ac_batch: " + lib.clc_status_string(rc).decode())
+    out = []
+    for i in range(n):
+        X, x, K, Rt, cov, mask, inl = keep[i]
+        j = jobs[i]
+        found = j.n_inliers > 0
+        out.append(dict(Rt=Rt.reshape(3, 4) if found else None, cov=cov.reshape(6, 6) if (found and refine) else None,
+                        mask=mask[:X.shape[0]].astype(bool), inliers=inl[:j.n_inliers].copy(), error_max=j.error_max, rmse=j.rmse,
+                        iterations=j.iterations))
+    return out
 
 
 def desc_cache_stats():

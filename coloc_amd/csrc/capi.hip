@@ -1491,131 +1491,52 @@ size_t dbl(size_t bytes) { return (bytes + 7) / 8; }
 
 // kind 0: a = X (3 N), b = x (2 N), K1 = intrinsics; kind 1: a = x1, b = x2 (2 N each), K1 / K2, image 2 of img_w x img_h.
 // h_model: 12 doubles [R|t] (kind 0) or {E (9), F (9)} (kind 1).
-int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N, const double* h_K1, const double* h_K2, int img_w,
-             int img_h, int max_iteration, uint64_t seed, double precision, double refine_huber, double* h_model, uint8_t* h_mask,
-             int32_t* h_inliers, int* n_inliers, double* error_max, double* min_nfa, int* iterations, int* rounds, double* h_cov,
-             double* rmse)
-{
-    const int m = kind == 0 ? 3 : 5, M = kind == 0 ? 4 : 10, md = kind == 0 ? 12 : 18, ad = kind == 0 ? 3 : 2;
-    if (!ctx || N < 0 || max_iteration < 0 || !h_K1 || (kind == 1 && !h_K2) || (N > 0 && (!h_a || !h_b)))
-        return fail(ctx, CLC_ERR_BAD_ARG, "acransac: bad argument");
-    if (n_inliers) *n_inliers = 0;
-    if (error_max) *error_max = 0.0;
-    if (min_nfa) *min_nfa = INFINITY;
-    if (iterations) *iterations = 0;
-    if (rounds) *rounds = 0;
-    if (h_mask && N > 0) memset(h_mask, 0, (size_t)N);
-    if (N <= m || max_iteration == 0) return CLC_OK;                       // ACRANSAC: nData <= sizeSample -> (0, 0), no model
-    if (N > kAcrMaxN) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 16384 correspondences per solve");
-    if (max_iteration > 500000) return fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 500000 iterations");
-    if (kind == 1 && (img_w <= 0 || img_h <= 0)) return fail(ctx, CLC_ERR_BAD_ARG, "acransac: image size needed for the point-to-line model");
-    CLC_HIP(ctx, hipSetDevice(ctx->device));
-    const bool refine = kind == 0 && refine_huber > 0.0;
-    // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k | initial state | first batch's samples ] uploaded
-    // in one copy, then scratch
-    const size_t samples_d = dbl(sizeof(int32_t) * kAcrMaxBatch * 5);
-    const size_t state_d = 2 * dbl(sizeof(AcrState));                      // [ copy 0 | copy 1 = the state a run starts from ]
-    const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d + samples_d;
-    // the resection round is ONE launch per round that reads what the launch before it wrote: two copies of state, models, slots
-    // and sorted lists, indexed by launch parity (acransac.hip: acr_round_kernel)
-    const int copies = kind == 0 ? 2 : 1;
-    const size_t models_d = (size_t)copies * kAcrMaxBatch * M * md;
-    const size_t hyp_d = dbl(acr_hyp_bytes() * copies * kAcrMaxBatch * M);
-    const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)copies * kAcrMaxBatch * M * N);
-    const size_t idx_d = dbl(sizeof(uint32_t) * (size_t)N);
-    const size_t res_d = dbl(sizeof(AcrResult)), mask_d = dbl((size_t)N);
-    const size_t ref_d = refine ? dbl(pnp_refine_out_bytes()) : 0;
-    int rc = ensure_pnp(ctx, in_d + models_d + hyp_d + sorted_d + 2 * idx_d + res_d + mask_d + ref_d + 16);
-    if (rc != CLC_OK) return rc;
-    // pinned: [ inputs | state mirror | sequence word | result | mask | inlier list | refine record ]
-    const size_t inl_d = dbl(sizeof(int32_t) * (size_t)N);
-    rc = ensure_pinned(ctx, (in_d + state_d + 1 + res_d + mask_d + inl_d + ref_d) * sizeof(double) + 64);   // (+1: the polled word)
-    if (rc != CLC_OK) return rc;
-    double* d = ctx->d_pnp;
-    double* d_a = d;                       d += (size_t)ad * N;
-    double* d_b = d;                       d += (size_t)2 * N;
-    double* d_K1 = d;                      d += 16;
-    double* d_K2 = d;                      d += 16;
-    float* d_cn = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
-    float* d_ck = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
-    AcrState* d_state = (AcrState*)d;      d += state_d;
-    int32_t* d_samples = (int32_t*)d;      d += samples_d;
-    double* d_models = d;                  d += models_d;
-    AcrHyp* d_hyp = (AcrHyp*)d;            d += hyp_d;
-    uint32_t* d_sorted = (uint32_t*)d;     d += sorted_d;
-    uint32_t* d_best = (uint32_t*)d;       d += idx_d;
-    uint32_t* d_index = (uint32_t*)d;      d += idx_d;
-    AcrResult* d_res = (AcrResult*)d;      d += res_d;
-    uint8_t* d_mask = (uint8_t*)d;         d += mask_d;
-    double* d_ref = d;
-    double* hp = (double*)ctx->h_pin;
-    memcpy(hp, h_a, sizeof(double) * ad * N);
-    memcpy(hp + (size_t)ad * N, h_b, sizeof(double) * 2 * N);
-    double* hK = hp + (size_t)(ad + 2) * N;
-    memset(hK, 0, sizeof(double) * 32);
-    memcpy(hK, h_K1, sizeof(double) * 9);
-    if (h_K2) memcpy(hK + 16, h_K2, sizeof(double) * 9);
-    float* h_cn = (float*)(hK + 32);
-    float* h_ck = (float*)(hK + 32 + dbl(sizeof(float) * ((size_t)N + 1)));
-    acr_tables(N, m, h_cn, h_ck, ctx->acr_lg);
-    // the state ACRANSAC starts from and the first batch's samples (drawn from all data) are part of the upload
-    AcrState* h_states = (AcrState*)(hK + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)));
-    int32_t* h_samples = (int32_t*)((double*)h_states + state_d);
-    memset(h_states, 0, 2 * sizeof(AcrState));
-    // resection: launch 0 (parity 0) reads copy 1; the five-point path keeps its single state in copy 0
-    AcrState* h_init = h_states + (kind == 0 ? 1 : 0);
-    h_init->min_nfa = INFINITY; h_init->error_max = INFINITY;
-    h_init->best_iter = -1;
-    h_init->reserve = max_iteration / 10;
-    h_init->n_iter = max_iteration - h_init->reserve;
-    h_init->n_index = N; h_init->index_all = 1;
-    h_init->ac_mode = std::isinf(precision) ? 1 : 0;
-    h_init->grow = 32;
-    h_init->cur_batch = h_init->n_iter < 32 ? h_init->n_iter : 32;
-    if (kind == 1) {                                   // (the resection round draws its own samples on the device)
-        const int nb = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
-        for (int it = 0; it < nb; ++it) {
-            uint32_t pos[8];
-            clc_acr_sample(seed, (uint32_t)it, (uint32_t)N, m, pos);
-            for (int j = 0; j < m; ++j) h_samples[it * m + j] = (int32_t)pos[j];
-        }
-    }
-    unsigned long long* h_word = (unsigned long long*)(hp + in_d + state_d);
-    AcrResult* h_res = (AcrResult*)(hp + in_d + state_d + 1);
-    int32_t* p_inl = (int32_t*)(hp + in_d + state_d + 1 + res_d + mask_d);
-    double* p_ref = hp + in_d + state_d + 1 + res_d + mask_d + inl_d;
-    __atomic_store_n(h_word, 0ull, __ATOMIC_RELAXED);
-
+//
+// One a-contrario solve as a small state machine (round 4): begin() stages the inputs and enqueues the first two rounds, poll() looks at the
+// pinned progress word ONCE -- if the round the host waits for has come out it enqueues the next one (rounds stay enqueued one ahead of
+// what the host knows) or moves on to the refinement, whose record it then polls the same way --, finish() copies the result out.  A
+// single solve spins on poll() exactly as the loop it replaces did; clc_pnp_localize_ac_batch drives SEVERAL solves, each on a context of
+// its own, from one thread: a solve is a chain of short launches with the host in the loop and leaves the GPU idle most of the time, so
+// the chains of independent cameras interleave (BASELINE config[2]: "batched PnP/RANSAC pose").
+struct AcrRun {
+    // arguments
+    clc_ctx* ctx = nullptr;
+    int kind = 0, N = 0, img_w = 0, img_h = 0, max_iteration = 0;
+    const double *h_a = nullptr, *h_b = nullptr, *h_K1 = nullptr, *h_K2 = nullptr;
+    uint64_t seed = 0;
+    double precision = 0.0, refine_huber = -1.0;
+    double* h_model = nullptr; uint8_t* h_mask = nullptr; int32_t* h_inliers = nullptr;
+    int *n_inliers = nullptr, *iterations = nullptr, *rounds = nullptr;
+    double *error_max = nullptr, *min_nfa = nullptr, *h_cov = nullptr, *rmse = nullptr;
+    // state
+    enum Phase { IDLE, ROUNDS, REFINE, DONE } phase = IDLE;
+    int status = CLC_OK;
+    int m = 0, M = 0, md = 0;
+    bool refine = false;
     AcrProblem pb{};
-    pb.kind = kind; pb.n = N; pb.m = m; pb.max_models = M; pb.model_doubles = md;
-    pb.a = d_a; pb.b = d_b; pb.K1 = d_K1; pb.K2 = d_K2; pb.logc_n = d_cn; pb.logc_k = d_ck;
-    pb.loge0 = clc_acr_log10((double)M * (double)(N - m));
-    if (kind == 0) {
-        // ACKernelAdaptorResection_Intrinsics: residuals on the normalised camera plane (x 1 / focal), logalpha0 = log10(pi)
-        pb.logalpha0 = clc_acr_log10(M_PI);
-        pb.mult = 1.0;
-        pb.norm = 1.0 / h_K1[0];
-        for (int e = 0; e < 9; ++e) pb.K1v[e] = h_K1[e];
-    } else {
-        // ACKernelAdaptorEssential: point-to-line, logalpha0 = log10(2 D / A * 0.5) of image 2, error^(1/2)
-        const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
-        pb.logalpha0 = clc_acr_log10(2.0 * D / A * .5);
-        pb.mult = 0.5;
-        pb.norm = 1.0;
-    }
-    pb.max_threshold = std::isinf(precision) ? INFINITY : precision * (pb.norm * pb.norm);
-    pb.seed = seed;
+    hipStream_t st = nullptr;
+    int launches = 0, bound = 0, reserve0 = 0;
+    uint32_t round = 0, spins = 0;
+    std::chrono::steady_clock::time_point wait_start;
+    unsigned long long* h_word = nullptr;
+    AcrResult* h_res = nullptr;
+    int32_t* p_inl = nullptr;
+    double* p_ref = nullptr;
+    int32_t* ready = nullptr;
+    double *d_a = nullptr, *d_b = nullptr, *d_K1 = nullptr, *d_K2 = nullptr, *d_models = nullptr, *d_ref = nullptr;
+    AcrState* d_state = nullptr; int32_t* d_samples = nullptr; AcrHyp* d_hyp = nullptr;
+    uint32_t *d_sorted = nullptr, *d_best = nullptr, *d_index = nullptr;
+    AcrResult* d_res = nullptr; uint8_t* d_mask = nullptr;
 
-    hipStream_t st = ctx->stream;
-    CLC_HIP(ctx, launch_acr_stage(hp, ctx->d_pnp, (in_d + 1) & ~(size_t)1, st));      // (both blocks are sized past in_d + 1)
-    prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
-    // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
-    // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
-    // select straight into the next round's solve while the host is still polling (a 10 us bubble per round otherwise).
-    int launches = 0;
-    auto enqueue_round = [&](const int bound) -> int {
+    // Every failure after the first launch drains the stream first (ignoring what the drain reports): launches of the failed solve may
+    // still be in flight and would otherwise write the progress word / result record of the NEXT solve, which reuses the same pinned block.
+    int drained(const int code) { (void)hipStreamSynchronize(st); phase = DONE; status = code; return code; }
+    int stop(const int code) { phase = DONE; status = code; return code; }
+
+    int enqueue_round(const int bnd)
+    {
         const int32_t* d_cnt = &d_state->cur_batch;
-        const int S = bound < 1 ? 1 : (bound > kAcrMaxBatch ? kAcrMaxBatch : bound);
+        const int S = bnd < 1 ? 1 : (bnd > kAcrMaxBatch ? kAcrMaxBatch : bnd);
         if (kind == 0) {
             // one launch: replay of the previous round, this round's samples, P3P, residuals / sort / NFA; the word of round r comes
             // out of launch r + 1
@@ -1628,92 +1549,263 @@ int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N
         }
         ++launches;
         return CLC_OK;
-    };
-    // Upper bound of the batch a round can ask for, from what the host knows when it enqueues it (one or two rounds behind the
-    // device): while the index set has not switched the batch doubles up to kAcrMaxBatch; afterwards it is what is left of the
-    // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
-    const int reserve0 = h_init->reserve;
-    int bound = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
-    // Every failure return below drains the stream first (ignoring what the drain reports): launches of the failed solve may still
-    // be in flight and would otherwise write the progress word / result record of the NEXT solve, which reuses the same pinned block.
-    auto drained = [&](const int code) -> int { (void)hipStreamSynchronize(st); return code; };
-    rc = enqueue_round(kind == 0 ? h_init->cur_batch : bound);         // (the resection launch takes its first batch as it stands)
-    if (rc != CLC_OK) return drained(rc);
-    uint32_t round = 0;
-    for (;;) {
-        rc = enqueue_round(bound);                                     // speculative: the round after the one being waited for
-        if (rc != CLC_OK) return drained(rc);
-        // the select kernel publishes one packed word (round number, iterations consumed, iter, n_iter) in pinned memory:
-        // poll it (a stream synchronisation costs ~10 us per round); after 2 ms without progress fall back to the
-        // synchronisation, which also surfaces errors
-        ++round;
-        unsigned long long w = 0;
-        {
-            const auto t_start = std::chrono::steady_clock::now();
-            unsigned spins = 0;
-            while (((w = __atomic_load_n(h_word, __ATOMIC_ACQUIRE)) >> 49) < (round & 0x7FFFu)) {
-                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(2)) {
-                    CLC_HIP(ctx, hipStreamSynchronize(st));
+    }
+
+    // validates, stages, enqueues the first two rounds.  Returns a status; phase == DONE afterwards means there is nothing to wait for.
+    int begin()
+    {
+        m = kind == 0 ? 3 : 5; M = kind == 0 ? 4 : 10; md = kind == 0 ? 12 : 18;
+        const int ad = kind == 0 ? 3 : 2;
+        if (!ctx || N < 0 || max_iteration < 0 || !h_K1 || (kind == 1 && !h_K2) || (N > 0 && (!h_a || !h_b)))
+            return stop(fail(ctx, CLC_ERR_BAD_ARG, "acransac: bad argument"));
+        if (n_inliers) *n_inliers = 0;
+        if (error_max) *error_max = 0.0;
+        if (min_nfa) *min_nfa = INFINITY;
+        if (iterations) *iterations = 0;
+        if (rounds) *rounds = 0;
+        if (h_mask && N > 0) memset(h_mask, 0, (size_t)N);
+        if (N <= m || max_iteration == 0) return stop(CLC_OK);                 // ACRANSAC: nData <= sizeSample -> (0, 0), no model
+        if (N > kAcrMaxN) return stop(fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 16384 correspondences per solve"));
+        if (max_iteration > 500000) return stop(fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 500000 iterations"));
+        if (kind == 1 && (img_w <= 0 || img_h <= 0)) return stop(fail(ctx, CLC_ERR_BAD_ARG, "acransac: image size needed for the point-to-line model"));
+        phase = DONE; status = CLC_ERR_HIP;                                     // (what an early CLC_HIP return leaves behind)
+        const int rc0 = begin_body(ad);
+        if (rc0 != CLC_OK) { phase = DONE; status = rc0; }
+        return rc0;
+    }
+
+    int begin_body(const int ad)
+    {
+        CLC_HIP(ctx, hipSetDevice(ctx->device));
+        refine = kind == 0 && refine_huber > 0.0;
+        // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k | initial state | first batch's samples ] uploaded
+        // in one copy, then scratch
+        const size_t samples_d = dbl(sizeof(int32_t) * kAcrMaxBatch * 5);
+        const size_t state_d = 2 * dbl(sizeof(AcrState));                      // [ copy 0 | copy 1 = the state a run starts from ]
+        const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d + samples_d;
+        // the resection round is ONE launch per round that reads what the launch before it wrote: two copies of state, models, slots
+        // and sorted lists, indexed by launch parity (acransac.hip: acr_round_kernel)
+        const int copies = kind == 0 ? 2 : 1;
+        const size_t models_d = (size_t)copies * kAcrMaxBatch * M * md;
+        const size_t hyp_d = dbl(acr_hyp_bytes() * copies * kAcrMaxBatch * M);
+        const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)copies * kAcrMaxBatch * M * N);
+        const size_t idx_d = dbl(sizeof(uint32_t) * (size_t)N);
+        const size_t res_d = dbl(sizeof(AcrResult)), mask_d = dbl((size_t)N);
+        const size_t ref_d = refine ? dbl(pnp_refine_out_bytes()) : 0;
+        int rc = ensure_pnp(ctx, in_d + models_d + hyp_d + sorted_d + 2 * idx_d + res_d + mask_d + ref_d + 16);
+        if (rc != CLC_OK) return rc;
+        // pinned: [ inputs | state mirror | sequence word | result | mask | inlier list | refine record ]
+        const size_t inl_d = dbl(sizeof(int32_t) * (size_t)N);
+        rc = ensure_pinned(ctx, (in_d + state_d + 1 + res_d + mask_d + inl_d + ref_d) * sizeof(double) + 64);   // (+1: the polled word)
+        if (rc != CLC_OK) return rc;
+        double* d = ctx->d_pnp;
+        d_a = d;                               d += (size_t)ad * N;
+        d_b = d;                               d += (size_t)2 * N;
+        d_K1 = d;                              d += 16;
+        d_K2 = d;                              d += 16;
+        float* d_cn = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
+        float* d_ck = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
+        d_state = (AcrState*)d;                d += state_d;
+        d_samples = (int32_t*)d;               d += samples_d;
+        d_models = d;                          d += models_d;
+        d_hyp = (AcrHyp*)d;                    d += hyp_d;
+        d_sorted = (uint32_t*)d;               d += sorted_d;
+        d_best = (uint32_t*)d;                 d += idx_d;
+        d_index = (uint32_t*)d;                d += idx_d;
+        d_res = (AcrResult*)d;                 d += res_d;
+        d_mask = (uint8_t*)d;                  d += mask_d;
+        d_ref = d;
+        double* hp = (double*)ctx->h_pin;
+        memcpy(hp, h_a, sizeof(double) * ad * N);
+        memcpy(hp + (size_t)ad * N, h_b, sizeof(double) * 2 * N);
+        double* hK = hp + (size_t)(ad + 2) * N;
+        memset(hK, 0, sizeof(double) * 32);
+        memcpy(hK, h_K1, sizeof(double) * 9);
+        if (h_K2) memcpy(hK + 16, h_K2, sizeof(double) * 9);
+        float* h_cn = (float*)(hK + 32);
+        float* h_ck = (float*)(hK + 32 + dbl(sizeof(float) * ((size_t)N + 1)));
+        acr_tables(N, m, h_cn, h_ck, ctx->acr_lg);
+        // the state ACRANSAC starts from and the first batch's samples (drawn from all data) are part of the upload
+        AcrState* h_states = (AcrState*)(hK + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)));
+        int32_t* h_samples = (int32_t*)((double*)h_states + state_d);
+        memset(h_states, 0, 2 * sizeof(AcrState));
+        // resection: launch 0 (parity 0) reads copy 1; the five-point path keeps its single state in copy 0
+        AcrState* h_init = h_states + (kind == 0 ? 1 : 0);
+        h_init->min_nfa = INFINITY; h_init->error_max = INFINITY;
+        h_init->best_iter = -1;
+        h_init->reserve = max_iteration / 10;
+        h_init->n_iter = max_iteration - h_init->reserve;
+        h_init->n_index = N; h_init->index_all = 1;
+        h_init->ac_mode = std::isinf(precision) ? 1 : 0;
+        h_init->grow = 32;
+        h_init->cur_batch = h_init->n_iter < 32 ? h_init->n_iter : 32;
+        if (kind == 1) {                                   // (the resection round draws its own samples on the device)
+            const int nb = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
+            for (int it = 0; it < nb; ++it) {
+                uint32_t pos[8];
+                clc_acr_sample(seed, (uint32_t)it, (uint32_t)N, m, pos);
+                for (int j = 0; j < m; ++j) h_samples[it * m + j] = (int32_t)pos[j];
+            }
+        }
+        h_word = (unsigned long long*)(hp + in_d + state_d);
+        h_res = (AcrResult*)(hp + in_d + state_d + 1);
+        p_inl = (int32_t*)(hp + in_d + state_d + 1 + res_d + mask_d);
+        p_ref = hp + in_d + state_d + 1 + res_d + mask_d + inl_d;
+        __atomic_store_n(h_word, 0ull, __ATOMIC_RELAXED);
+
+        pb = AcrProblem{};
+        pb.kind = kind; pb.n = N; pb.m = m; pb.max_models = M; pb.model_doubles = md;
+        pb.a = d_a; pb.b = d_b; pb.K1 = d_K1; pb.K2 = d_K2; pb.logc_n = d_cn; pb.logc_k = d_ck;
+        pb.loge0 = clc_acr_log10((double)M * (double)(N - m));
+        if (kind == 0) {
+            // ACKernelAdaptorResection_Intrinsics: residuals on the normalised camera plane (x 1 / focal), logalpha0 = log10(pi)
+            pb.logalpha0 = clc_acr_log10(M_PI);
+            pb.mult = 1.0;
+            pb.norm = 1.0 / h_K1[0];
+            for (int e = 0; e < 9; ++e) pb.K1v[e] = h_K1[e];
+        } else {
+            // ACKernelAdaptorEssential: point-to-line, logalpha0 = log10(2 D / A * 0.5) of image 2, error^(1/2)
+            const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
+            pb.logalpha0 = clc_acr_log10(2.0 * D / A * .5);
+            pb.mult = 0.5;
+            pb.norm = 1.0;
+        }
+        pb.max_threshold = std::isinf(precision) ? INFINITY : precision * (pb.norm * pb.norm);
+        pb.seed = seed;
+
+        st = ctx->stream;
+        CLC_HIP(ctx, launch_acr_stage(hp, ctx->d_pnp, (in_d + 1) & ~(size_t)1, st));      // (both blocks are sized past in_d + 1)
+        prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
+        // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
+        // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
+        // select straight into the next round's solve while the host is still polling (a 10 us bubble per round otherwise).
+        launches = 0;
+        // Upper bound of the batch a round can ask for, from what the host knows when it enqueues it (one or two rounds behind the
+        // device): while the index set has not switched the batch doubles up to kAcrMaxBatch; afterwards it is what is left of the
+        // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
+        reserve0 = h_init->reserve;
+        bound = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
+        int rc2 = enqueue_round(kind == 0 ? h_init->cur_batch : bound);     // (the resection launch takes its first batch as it stands)
+        if (rc2 != CLC_OK) return drained(rc2);
+        rc2 = enqueue_round(bound);                                     // speculative: the round after the one being waited for
+        if (rc2 != CLC_OK) return drained(rc2);
+        round = 1;
+        spins = 0;
+        wait_start = std::chrono::steady_clock::now();
+        phase = ROUNDS;
+        status = CLC_OK;
+        return CLC_OK;
+    }
+
+    // One look at the progress word / the refinement's ready flag.  Returns the status; phase == DONE when the solve has ended.
+    int poll()
+    {
+        if (phase == ROUNDS) {
+            // the select kernel publishes one packed word (round number, iterations consumed, iter, n_iter) in pinned memory: poll it
+            // (a stream synchronisation costs ~10 us per round); after 2 ms without progress fall back to the synchronisation, which
+            // also surfaces errors
+            unsigned long long w = __atomic_load_n(h_word, __ATOMIC_ACQUIRE);
+            if ((w >> 49) < (round & 0x7FFFu)) {
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - wait_start > std::chrono::milliseconds(2)) {
+                    const hipError_t e = hipStreamSynchronize(st);
+                    if (e != hipSuccess) return drained(fail(ctx, CLC_ERR_HIP, "hipStreamSynchronize(st)", e));
                     w = __atomic_load_n(h_word, __ATOMIC_ACQUIRE);
                     if ((w >> 49) < (round & 0x7FFFu)) return drained(fail(ctx, CLC_ERR_HIP, "acransac: round did not complete"));
-                }
+                } else return CLC_OK;
             }
-        }
-        const int iter_k = (int)(w & 0xFFFFFu), n_iter_k = (int)((w >> 20) & 0xFFFFFu);
-        if (iter_k >= n_iter_k) break;                                 // done: the completing round has left the result in pinned memory
-        const bool switched = ((w >> 48) & 1u) != 0;
-        const long left = (long)n_iter_k - iter_k + 4 + (switched ? 0 : reserve0);
-        bound = left > kAcrMaxBatch ? kAcrMaxBatch : (int)left;
-        if (round > 0x7000u) return drained(fail(ctx, CLC_ERR_STATE, "acransac: too many rounds"));
-    }
-    prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);
-    // The result record, mask and inlier list were written by the round that completed the run BEFORE its word (system-scope release /
-    // acquire): no finish launch, and without refinement no stream synchronisation either -- the round enqueued ahead is still in the
-    // stream, evaluates nothing and touches no host memory; anything enqueued later on this stream is ordered behind it.
-    if (refine) {
-        // Behind the launch that completed the run, on the same stream (nothing is queued behind that launch any more: the word of
-        // the last round comes out of the last launch).  The refinement writes its record into pinned memory and sets `ready` last;
-        // the host polls that instead of synchronising the stream (~5 us), with the synchronisation as the fallback after 5 ms.
-        int32_t* ready = (int32_t*)((uint8_t*)p_ref + pnp_refine_ready_offset());
-        __atomic_store_n(ready, 0, __ATOMIC_RELAXED);
-        {
-            const hipError_t e = launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50, d_ref,
-                                                   st, &ctx->prof, &d_res->valid, p_ref);
+            const int iter_k = (int)(w & 0xFFFFFu), n_iter_k = (int)((w >> 20) & 0xFFFFFu);
+            if (iter_k < n_iter_k) {
+                const bool switched = ((w >> 48) & 1u) != 0;
+                const long left = (long)n_iter_k - iter_k + 4 + (switched ? 0 : reserve0);
+                bound = left > kAcrMaxBatch ? kAcrMaxBatch : (int)left;
+                if (round > 0x7000u) return drained(fail(ctx, CLC_ERR_STATE, "acransac: too many rounds"));
+                const int rc = enqueue_round(bound);                   // speculative: the round after the one being waited for
+                if (rc != CLC_OK) return drained(rc);
+                ++round;
+                spins = 0;
+                wait_start = std::chrono::steady_clock::now();
+                return CLC_OK;
+            }
+            // done: the completing round has left the result in pinned memory
+            prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);
+            // The result record, mask and inlier list were written by the round that completed the run BEFORE its word (system-scope
+            // release / acquire): no finish launch, and without refinement no stream synchronisation either -- the round enqueued ahead is
+            // still in the stream, evaluates nothing and touches no host memory; anything enqueued later on this stream is ordered behind it.
+            if (!refine) { phase = DONE; return CLC_OK; }
+            // Behind the launch that completed the run, on the same stream (nothing is queued behind that launch any more: the word of
+            // the last round comes out of the last launch).  The refinement writes its record into pinned memory and sets `ready` last;
+            // the host polls that instead of synchronising the stream (~5 us), with the synchronisation as the fallback after 5 ms.
+            ready = (int32_t*)((uint8_t*)p_ref + pnp_refine_ready_offset());
+            __atomic_store_n(ready, 0, __ATOMIC_RELAXED);
+            const hipError_t e = launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50,
+                                                   d_ref, st, &ctx->prof, &d_res->valid, p_ref);
             if (e != hipSuccess) return drained(fail(ctx, CLC_ERR_HIP, "launch_pnp_refine", e));
+            spins = 0;
+            wait_start = std::chrono::steady_clock::now();
+            phase = REFINE;
+            return CLC_OK;
         }
-        const auto t_start = std::chrono::steady_clock::now();
-        unsigned spins = 0;
-        while (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) {
-            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t_start > std::chrono::milliseconds(5)) {
-                CLC_HIP(ctx, hipStreamSynchronize(st));
-                if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) return drained(fail(ctx, CLC_ERR_HIP, "acransac: refinement did not complete"));
+        if (phase == REFINE) {
+            if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) {
+                if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - wait_start > std::chrono::milliseconds(5)) {
+                    const hipError_t e = hipStreamSynchronize(st);
+                    if (e != hipSuccess) return drained(fail(ctx, CLC_ERR_HIP, "hipStreamSynchronize(st)", e));
+                    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) return drained(fail(ctx, CLC_ERR_HIP, "acransac: refinement did not complete"));
+                } else return CLC_OK;
+            }
+            phase = DONE;
+        }
+        return status;
+    }
+
+    // after phase == DONE with status CLC_OK and a run that was started: the result into the caller's buffers
+    void finish()
+    {
+        if (status != CLC_OK || !h_res) return;
+        const AcrResult r = *h_res;
+        if (h_model) {
+            if (kind == 0) memcpy(h_model, r.model, sizeof(double) * 12);
+            else { memcpy(h_model, r.model + 9, sizeof(double) * 9); memcpy(h_model + 9, r.model, sizeof(double) * 9); }   // slots hold {F, E}
+        }
+        // the mask is rebuilt from the inlier list here (h_mask was cleared above): the device does not push N bytes + one scattered byte
+        // per inlier over PCIe for it
+        if (h_mask) for (int i = 0; i < r.n_inliers; ++i) h_mask[p_inl[i]] = 1;
+        if (h_inliers && r.n_inliers > 0) memcpy(h_inliers, p_inl, sizeof(int32_t) * (size_t)r.n_inliers);
+        if (n_inliers) *n_inliers = r.n_inliers;
+        if (error_max) *error_max = r.error_max;
+        if (min_nfa) *min_nfa = r.min_nfa;
+        if (iterations) *iterations = r.iterations;
+        if (rounds) *rounds = r.rounds;
+        if (refine) {
+            struct { double Rt[12]; double cov[36]; double cost; double rmse; int32_t iterations; int32_t n_used; } f;
+            memcpy(&f, p_ref, sizeof f);
+            if (r.n_inliers > 0) {
+                if (h_model) memcpy(h_model, f.Rt, sizeof f.Rt);
+                if (h_cov) memcpy(h_cov, f.cov, sizeof f.cov);
+                if (rmse) *rmse = f.rmse;
             }
         }
     }
-    const AcrResult r = *h_res;
-    if (h_model) {
-        if (kind == 0) memcpy(h_model, r.model, sizeof(double) * 12);
-        else { memcpy(h_model, r.model + 9, sizeof(double) * 9); memcpy(h_model + 9, r.model, sizeof(double) * 9); }   // slots hold {F, E}
+};
+
+int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N, const double* h_K1, const double* h_K2, int img_w,
+             int img_h, int max_iteration, uint64_t seed, double precision, double refine_huber, double* h_model, uint8_t* h_mask,
+             int32_t* h_inliers, int* n_inliers, double* error_max, double* min_nfa, int* iterations, int* rounds, double* h_cov,
+             double* rmse)
+{
+    AcrRun run;
+    run.ctx = ctx; run.kind = kind; run.h_a = h_a; run.h_b = h_b; run.N = N; run.h_K1 = h_K1; run.h_K2 = h_K2; run.img_w = img_w; run.img_h = img_h;
+    run.max_iteration = max_iteration; run.seed = seed; run.precision = precision; run.refine_huber = refine_huber;
+    run.h_model = h_model; run.h_mask = h_mask; run.h_inliers = h_inliers; run.n_inliers = n_inliers; run.error_max = error_max;
+    run.min_nfa = min_nfa; run.iterations = iterations; run.rounds = rounds; run.h_cov = h_cov; run.rmse = rmse;
+    int rc = run.begin();
+    if (rc != CLC_OK) return rc;
+    while (run.phase != AcrRun::DONE) {
+        rc = run.poll();
+        if (rc != CLC_OK) return rc;
     }
-    // the mask is rebuilt from the inlier list here (h_mask was cleared above): the device does not push N bytes + one scattered byte
-    // per inlier over PCIe for it
-    if (h_mask) for (int i = 0; i < r.n_inliers; ++i) h_mask[p_inl[i]] = 1;
-    if (h_inliers && r.n_inliers > 0) memcpy(h_inliers, p_inl, sizeof(int32_t) * (size_t)r.n_inliers);
-    if (n_inliers) *n_inliers = r.n_inliers;
-    if (error_max) *error_max = r.error_max;
-    if (min_nfa) *min_nfa = r.min_nfa;
-    if (iterations) *iterations = r.iterations;
-    if (rounds) *rounds = r.rounds;
-    if (refine) {
-        struct { double Rt[12]; double cov[36]; double cost; double rmse; int32_t iterations; int32_t n_used; } f;
-        memcpy(&f, p_ref, sizeof f);
-        if (r.n_inliers > 0) {
-            if (h_model) memcpy(h_model, f.Rt, sizeof f.Rt);
-            if (h_cov) memcpy(h_cov, f.cov, sizeof f.cov);
-            if (rmse) *rmse = f.rmse;
-        }
-    }
-    return CLC_OK;
+    run.finish();
+    return run.status;
 }
 
 } // namespace
@@ -1738,6 +1830,50 @@ int clc_pnp_localize_ac(clc_ctx* ctx, const double* h_X, const double* h_x, int 
     if (rmse) *rmse = 0.0;
     return acr_impl(ctx, 0, h_X, h_x, N, h_K, nullptr, 0, 0, max_iteration, seed, precision, huber_a > 0.0 ? huber_a : 16.0, h_Rt,
                     h_inlier_mask, h_inliers, n_inliers, error_max, nullptr, nullptr, nullptr, h_cov, rmse);
+}
+
+int clc_pnp_localize_ac_batch(clc_ctx* const* ctxs, clc_pose_job* jobs, int n_jobs)
+{
+    if (n_jobs < 0 || (n_jobs > 0 && (!ctxs || !jobs))) return CLC_ERR_BAD_ARG;
+    if (n_jobs == 0) return CLC_OK;
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!ctxs[i]) return CLC_ERR_BAD_ARG;
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(ctxs[i], CLC_ERR_BAD_ARG, "pnp_localize_ac_batch: every job needs a context of its own");
+        if (ctxs[i]->device != ctxs[0]->device) return fail(ctxs[i], CLC_ERR_BAD_ARG, "pnp_localize_ac_batch: the contexts must live on one device");
+    }
+    std::vector<AcrRun> runs((size_t)n_jobs);
+    int worst = CLC_OK, live = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        clc_pose_job& jb = jobs[i];
+        AcrRun& r = runs[(size_t)i];
+        if (jb.Rt) memset(jb.Rt, 0, sizeof(double) * 12);
+        if (jb.cov) memset(jb.cov, 0, sizeof(double) * 36);
+        jb.n_inliers = 0; jb.error_max = 0.0; jb.rmse = 0.0; jb.iterations = 0;
+        r.ctx = ctxs[i]; r.kind = 0; r.h_a = jb.X; r.h_b = jb.x; r.N = jb.n; r.h_K1 = jb.K;
+        r.max_iteration = jb.max_iteration; r.seed = jb.seed; r.precision = jb.precision;
+        r.refine_huber = jb.refine ? (jb.huber_a > 0.0 ? jb.huber_a : 16.0) : -1.0;
+        r.h_model = jb.Rt; r.h_mask = jb.inlier_mask; r.h_inliers = jb.inliers; r.n_inliers = &jb.n_inliers; r.error_max = &jb.error_max;
+        r.iterations = &jb.iterations; r.h_cov = jb.cov; r.rmse = &jb.rmse;
+        jb.status = r.begin();                        // stages this job's inputs and puts its first two rounds into its context's stream
+        if (r.phase != AcrRun::DONE) ++live;
+    }
+    // one thread, all chains: whichever solve's round has come out gets its next one enqueued
+    while (live > 0) {
+        for (int i = 0; i < n_jobs; ++i) {
+            AcrRun& r = runs[(size_t)i];
+            if (r.phase == AcrRun::DONE) continue;
+            (void)r.poll();
+            if (r.phase == AcrRun::DONE) --live;
+        }
+    }
+    for (int i = 0; i < n_jobs; ++i) {
+        AcrRun& r = runs[(size_t)i];
+        r.finish();
+        jobs[i].status = r.status;
+        if (r.status != CLC_OK && worst == CLC_OK) worst = r.status;
+    }
+    return worst;
 }
 
 int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2, int N, const double* h_K1, const double* h_K2,

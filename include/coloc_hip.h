@@ -419,6 +419,36 @@ int clc_pnp_acransac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, 
 int clc_pnp_localize_ac(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, int max_iteration,
                         uint64_t seed, double precision, double huber_a, double* h_Rt, double* h_cov,
                         uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers, double* error_max, double* rmse);
+/* Several independent localisations at once -- BASELINE config[2]'s "batched PnP/RANSAC pose", one per camera: job i is what
+ * clc_pnp_acransac (refine == 0) or clc_pnp_localize_ac (refine != 0) does, on ctxs[i] (every job needs a context of its own; contexts created
+ * without detector and matcher options are enough).  A solve is a chain of short launches with the host in the loop and leaves the GPU idle
+ * most of the time; here ONE host thread drives all the chains, so they interleave on the device.  Every job's result is the one the
+ * single-solve entry gives for the same arguments (same model, inliers, threshold, covariance, bit for bit).  jobs[i].status holds the
+ * job's own status; the return value is the first failure, CLC_OK if none. */
+typedef struct clc_pose_job {
+    /* in */
+    const double* X;          /* n x 3 world points                                      */
+    const double* x;          /* n x 2 pixels                                            */
+    const double* K;          /* 3 x 3 row-major                                         */
+    int           n;
+    int           max_iteration;
+    uint64_t      seed;
+    double        precision;  /* +inf: a-contrario threshold (Localizer.hpp:82-84)       */
+    int           refine;     /* != 0: LM refinement + 6 x 6 covariance behind the solve */
+    double        huber_a;    /* <= 0: 16                                                */
+    /* out (pointers nullable) */
+    double*       Rt;         /* 12                                                      */
+    double*       cov;        /* 36 (refine)                                             */
+    uint8_t*      inlier_mask;/* n                                                       */
+    int32_t*      inliers;    /* n                                                       */
+    int           n_inliers;
+    int           iterations;
+    int           status;
+    double        error_max;
+    double        rmse;       /* refine                                                  */
+} clc_pose_job;
+int clc_pnp_localize_ac_batch(clc_ctx* const* ctxs, clc_pose_job* jobs, int n_jobs);
+
 /* RobustMatcher::filterEssential's ACRANSAC: h_x1 / h_x2 N x 2 undistorted pixels, K1 / K2, img_w x img_h the size of
  * image 2 (point-to-line alpha0 = 2 D / A / 2, residual^(1/2)); residual = symmetric epipolar distance of
  * F = K2^-T E K1^-1 as clc_epipolar_residuals.  *error_max is that squared distance at the a-contrario threshold. */

@@ -249,3 +249,41 @@ def test_essential_on_more_than_8192_matches(gpu_ctx, oracle):
     K = synth.pnp_scene(5, seed=77)["K"]
     got = gpu_ctx.essential_acransac(x1, x2, K, K, (1280, 720), max_iteration=32, seed=5)
     assert got["E"] is not None and len(got["inliers"]) > 0.5 * 9300
+
+
+def test_batched_localisations_equal_the_single_solves(gpu_ctx, oracle):
+    """clc_pnp_localize_ac_batch (BASELINE config[2]: one pose per camera, all at once): eight independent a-contrario solves of different
+    sizes, outlier rates and seeds, each on a context of its own and all driven by one host thread, must each give exactly what the
+    single-solve entry gives -- model, covariance, inlier list in order, threshold -- with and without refinement; an empty and a tiny
+    problem ride along; sharing a context between two jobs is refused."""
+    from coloc_amd import Context
+    from coloc_amd.abi import pnp_localize_batch, CLCError
+    shapes = [(200, 0.3), (1000, 0.3), (5000, 0.4), (300, 0.6), (64, 0.2), (1500, 0.5), (3, 0.0), (800, 0.7)]
+    scenes = [synth.pnp_scene(max(n, 4), seed=8600 + k, outlier_frac=o) for k, (n, o) in enumerate(shapes)]
+    probs = [(sc["X"][:n], sc["x"][:n], sc["K"]) for sc, (n, _) in zip(scenes, shapes)]
+    ctxs = [Context(device=0, detector=False, matcher=False) for _ in shapes]
+    seeds = [31 + k for k in range(len(shapes))]
+    try:
+        for refine in (False, True):
+            got = pnp_localize_batch(ctxs, probs, max_iteration=256, seeds=seeds, refine=refine)
+            for k, (X, x, K) in enumerate(probs):
+                want = gpu_ctx.pnp_acransac(X, x, K, max_iteration=256, seed=seeds[k], refine=refine)
+                g = got[k]
+                assert (g["Rt"] is None) == (want["Rt"] is None), k
+                assert np.array_equal(g["inliers"], want["inliers"]) and np.array_equal(g["mask"], want["mask"]), k
+                assert g["error_max"] == want["error_max"], k
+                if want["Rt"] is not None:
+                    assert np.array_equal(g["Rt"], want["Rt"]), k
+                    if refine:
+                        assert np.array_equal(g["cov"], want["cov"]) and g["rmse"] == want["rmse"], k
+                    else:
+                        assert g["iterations"] == want["iterations"], k
+        assert got[6]["Rt"] is None and len(got[6]["inliers"]) == 0           # n = 3: no model (nData <= sizeSample)
+        # the same again on the same contexts (their state is reused from batch to batch)
+        again = pnp_localize_batch(ctxs, probs, max_iteration=256, seeds=seeds, refine=True)
+        assert all(np.array_equal(a["inliers"], b["inliers"]) for a, b in zip(again, got))
+        with pytest.raises(CLCError):
+            pnp_localize_batch([ctxs[0], ctxs[0]], probs[:2], seeds=seeds[:2])
+    finally:
+        for c in ctxs:
+            c.close()
