@@ -716,6 +716,60 @@ def main():
             out["pose_acransac_only_p50_ms"] = pose["N1000"]["acransac_p50_ms"]
             out["pose_solve_p50_ms_c_abi"] = pose["N1000"]["c_abi_with_refine_p50_ms"]
 
+        def sec_pose_batch():
+            # BASELINE config[2]'s "batched PnP/RANSAC pose": the 4 cameras' localisations (N = 1000 each, 30 % outliers, a-contrario P3P +
+            # refinement + covariance) in ONE clc_pnp_localize_ac_batch call -- every solve on a light context of its own, one host thread
+            # driving all the chains of short launches so that they interleave on the device -- against the same 4 solves one after the
+            # other (clc_pnp_localize_ac).  Caller's buffers allocated once, the C ABI called directly (as a C++ host does); results compared.
+            import ctypes as C
+            from coloc_amd.abi import PoseJob
+            res = {}
+            for ncam in (4, 8):
+                pcs = [Context(device=dev_index, detector=False, matcher=False) for _ in range(ncam)]
+                try:
+                    scs = [synth.pnp_scene(1000, seed=4000 + c) for c in range(ncam)]
+                    keep, jobs = [], (PoseJob * ncam)()
+                    for c, sc in enumerate(scs):
+                        X, x, K = (np.ascontiguousarray(sc[k], dtype=np.float64) for k in ("X", "x", "K"))
+                        K = K.reshape(9)
+                        Rt, cov, mk, inl = np.zeros(12), np.zeros(36), np.zeros(1000, dtype=np.uint8), np.zeros(1000, dtype=np.int32)
+                        keep.append((X, x, K, Rt, cov, mk, inl))
+                        j = jobs[c]
+                        j.X, j.x, j.K, j.n, j.max_iteration, j.precision, j.refine, j.huber_a = X.ctypes.data, x.ctypes.data, K.ctypes.data, 1000, 256, float("inf"), 1, 16.0
+                        j.Rt, j.cov, j.inlier_mask, j.inliers = Rt.ctypes.data, cov.ctypes.data, mk.ctypes.data, inl.ctypes.data
+                    hs = (C.c_void_p * ncam)(*[c_.h for c_ in pcs])
+                    tb, ts = [], []
+                    ni_, em_, rm_ = C.c_int(), C.c_double(), C.c_double()
+                    same = True
+                    for it in range(105):
+                        for c in range(ncam):
+                            jobs[c].seed = it + 1 + c
+                        t1 = time.perf_counter()
+                        rc = ctx.lib.clc_pnp_localize_ac_batch(hs, jobs, ncam)
+                        tb.append((time.perf_counter() - t1) * 1e3)
+                        assert rc == 0
+                        got = [(keep[c][3].copy(), int(jobs[c].n_inliers)) for c in range(ncam)]
+                        t1 = time.perf_counter()
+                        for c in range(ncam):
+                            X, x, K, Rt, cov, mk, inl = keep[c]
+                            rc = ctx.lib.clc_pnp_localize_ac(ctx.h, X.ctypes.data, x.ctypes.data, 1000, K.ctypes.data, 256, it + 1 + c, float("inf"), 16.0,
+                                                             Rt.ctypes.data, cov.ctypes.data, mk.ctypes.data, inl.ctypes.data, C.byref(ni_), C.byref(em_), C.byref(rm_))
+                            assert rc == 0
+                            same = same and ni_.value == got[c][1] and np.array_equal(Rt, got[c][0])
+                        ts.append((time.perf_counter() - t1) * 1e3)
+                    tb, ts = np.sort(tb[5:]), np.sort(ts[5:])
+                    res["cameras_%d" % ncam] = {"batch_p50_ms": float(tb[len(tb) // 2]), "batch_p95_ms": float(tb[int(len(tb) * 0.95)]),
+                                                "per_pose_p50_ms": float(tb[len(tb) // 2]) / ncam,
+                                                "one_after_the_other_p50_ms": float(ts[len(ts) // 2]), "one_after_the_other_per_pose_p50_ms": float(ts[len(ts) // 2]) / ncam,
+                                                "batches": int(len(tb)), "identical_results": bool(same)}
+                finally:
+                    for c_ in pcs:
+                        c_.close()
+            out["pose_batch"] = {"what": "config[2] 'batched PnP/RANSAC pose': clc_pnp_localize_ac_batch, one a-contrario P3P solve + LM refinement + covariance per "
+                                         "camera (N = 1000, 30 % outliers, 256 iterations max), all cameras' chains of launches interleaved from one host "
+                                         "thread; C ABI, caller's buffers allocated once; beside it the same solves one after the other", **res}
+            out["pose_batch_per_pose_p50_ms"] = res["cameras_4"]["per_pose_p50_ms"]
+
         def sec_two_view():
             # two-view filter: a-contrario five-point RANSAC over 1000 correspondences, 30 % outliers
             rng2 = np.random.default_rng(11)
@@ -879,12 +933,13 @@ def main():
             guarded("shares", sec_shares)
             guarded("front_end", sec_front_end)
             guarded("pose_solve", sec_pose)
+            guarded("pose_batch", sec_pose_batch)
             guarded("two_view", sec_two_view)
             guarded("cpu_baseline", sec_cpu_baseline)
         if world > 1:
             # the side sections belong to the one-GPU line (cpu_baseline: rank 0 at N = 1 only, by the bench contract); their keys are
             # present and null here so that lines of different N can be compared field by field
-            for k in ("cpu_baseline", "gpu_over_cpu", "front_end", "pose_solve", "pose_solve_p50_ms", "two_view", "host_path",
+            for k in ("cpu_baseline", "gpu_over_cpu", "front_end", "pose_solve", "pose_solve_p50_ms", "pose_batch", "pose_batch_per_pose_p50_ms", "two_view", "host_path",
                       "accepted_matches_per_step"):
                 out.setdefault(k, None)
         if errors:

@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--scene", choices=["plane", "synthetic"], default="plane")
     ap.add_argument("--pipelined", action="store_true", help="plane scene, one rank: the two-lane loop also below 4 cameras")
     ap.add_argument("--sequential", action="store_true", help="plane scene: the camera-by-camera loop only")
+    ap.add_argument("--no-overlap", action="store_true", help="plane scene, frame-batched loop: no pipelining -- a frame's front end is enqueued and waited for inside its own timed region")
     ap.add_argument("--unique-frames", type=int, default=6, help="plane scene: rendered frames per camera (the trajectory loops over them)")
     args = ap.parse_args()
 
@@ -271,9 +272,14 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
     # a gentle relief under the cameras: a flat scene leaves the essential matrix with its planar two-fold ambiguity
     relief = synth.smooth_relief(centres=((4.2, 4.4, 0.55, 0.9), (6.0, 5.6, 0.45, 0.7), (5.1, 6.3, 0.40, 0.6), (5.9, 4.0, 0.50, 0.8), (3.6, 6.0, 0.45, 0.7)))
 
+    POW12 = np.power(np.float32(1.2), np.arange(256, dtype=np.float32))        # pow(1.2f, scale), GPUDetector.hpp:173-179
+
     def feature_xy(kps):
-        s = np.power(np.float32(1.2), kps["scale"].astype(np.float32))
-        return np.stack([s * kps["x"], s * kps["y"]], axis=1).astype(np.float64)
+        s = POW12[kps["scale"]]
+        out = np.empty((len(kps), 2), dtype=np.float64)
+        out[:, 0] = s * kps["x"]
+        out[:, 1] = s * kps["y"]
+        return out
 
     # the map: one reference view a little higher up, its CLATCH descriptors + the 3-D points under its keypoints
     Rm, tm = synth.look_at_plane_pose(centre, HEIGHT * 1.06)
@@ -282,12 +288,17 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
     ctx.set_map(desc_m)
     M = len(desc_m)
 
+    pose_cache = {}
+
     def pose_of(cam, f):
-        a = 2 * math.pi * (f % args.unique_frames) / args.unique_frames
-        off = np.array([0.35 * math.cos(a) + 0.12 * (cam - (n_cams - 1) / 2), 0.25 * math.sin(a)])
-        R, t = synth.look_at_plane_pose(centre + off, HEIGHT, yaw=0.08 * (cam - (n_cams - 1) / 2) + 0.05 * math.sin(a),
-                                        tilt=(0.03 * math.cos(a), 0.03 * math.sin(a) - 0.01 * cam))
-        return R, t, -R.T @ t
+        key = (cam, f % args.unique_frames)
+        if key not in pose_cache:
+            a = 2 * math.pi * key[1] / args.unique_frames
+            off = np.array([0.35 * math.cos(a) + 0.12 * (cam - (n_cams - 1) / 2), 0.25 * math.sin(a)])
+            R, t = synth.look_at_plane_pose(centre + off, HEIGHT, yaw=0.08 * (cam - (n_cams - 1) / 2) + 0.05 * math.sin(a),
+                                            tilt=(0.03 * math.cos(a), 0.03 * math.sin(a) - 0.01 * cam))
+            pose_cache[key] = (R, t, -R.T @ t)
+        return pose_cache[key]
 
     frames = {(cam, u): torch.from_numpy(synth.render_plane(tex, PPU, K, *pose_of(cam, u)[:2], W, H, relief=relief)).to(dev)
               for cam in my_cams for u in range(args.unique_frames)}
@@ -569,16 +580,132 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
         lanes[1]["ctx"].close()
         return st
 
+    # ---------------------------------------------------------------------------------------------------------------------
+    # frame-batched (world == 1, 2 .. 8 cameras): every stage handles ALL cameras of a frame in one call -- one front-end call
+    # (clc_detect_batch_dev: one pyramid, two detector and one CLATCH launch for the frame's cameras), one counted map-match launch with
+    # a job per camera, one copy-out, ONE batched a-contrario solve (clc_pnp_localize_ac_batch: the cameras' solves, each on a light
+    # context of its own, interleave on the device under one host thread) -- and the device work of frame f + 1 is enqueued on a second
+    # stream before frame f's poses are solved.  (Round 4's first attempt at frame-granular batching still solved the poses one after the
+    # other beside the batched front end; the batched solve is what makes it pay.)
+    # ---------------------------------------------------------------------------------------------------------------------
+    def run_batched(overlap=True):
+        from coloc_amd.abi import pnp_localize_batch
+        st = new_stats()
+        lat = st["lat"]
+        nc = len(my_cams)
+        EAGER = 12288
+        arena = torch.zeros((1 + 2 * nc, CAP, 64), dtype=torch.uint8, device=dev)
+        arena[0, :M] = torch.from_numpy(desc_m).to(dev)
+        map_n = torch.tensor([M], dtype=torch.int32, device=dev)
+        fe_stream = torch.cuda.Stream(device=dev)
+        fe_ctx = Context(device=local_rank, width=W, height=H, maxkp=CAP, match_thresh=60)      # the front end's context (its own workspaces)
+        pose_ctxs = [Context(device=local_rank, detector=False, matcher=False) for _ in range(nc)]
+        sets = [dict(kps=torch.zeros((nc, CAP, 20), dtype=torch.uint8, device=dev), cnt=torch.zeros((nc, 2), dtype=torch.int32, device=dev),
+                     match=torch.empty((nc, CAP), dtype=torch.int32, device=dev),
+                     h_cnt=torch.zeros((nc, 2), dtype=torch.int32).pin_memory(), h_kps=torch.zeros((nc, EAGER, 20), dtype=torch.uint8).pin_memory(),
+                     h_match=torch.zeros((nc, EAGER), dtype=torch.int32).pin_memory(), done=torch.cuda.Event()) for _ in range(2)]
+        d_pair = torch.empty(CAP, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+
+        def block_of(f, b):
+            return 1 + (f & 1) * nc + b
+
+        def enqueue(f):
+            S = sets[f & 1]
+            sp = fe_stream.cuda_stream
+            fe_ctx.detect_batch_dev([frames[(cam, f % args.unique_frames)].data_ptr() for cam in my_cams], W, H, W,
+                                    [S["kps"][b].data_ptr() for b in range(nc)], [S["cnt"][b].data_ptr() for b in range(nc)],
+                                    [arena[block_of(f, b)].data_ptr() for b in range(nc)], sp)
+            # map tracking of every camera (GPUMatcher.hpp:174-178, thr 60) in one sweep launch, the counts read on the device
+            fe_ctx.match_jobs_counted_dev(arena.data_ptr(), [(block_of(f, b) * CAP, CAP, 0, M, b * CAP, 60) for b in range(nc)],
+                                          [S["cnt"][b].data_ptr() for b in range(nc)], [map_n.data_ptr()] * nc, [0] * nc, S["match"].data_ptr(), sp)
+            with torch.cuda.stream(fe_stream):
+                S["h_cnt"].copy_(S["cnt"], non_blocking=True)
+                S["h_kps"].copy_(S["kps"][:, :EAGER], non_blocking=True)
+                S["h_match"].copy_(S["match"][:, :EAGER], non_blocking=True)
+                S["done"].record(fe_stream)
+
+        def solve_frame(f, stats, enqueue_next):
+            S = sets[f & 1]
+            t0 = time.perf_counter()
+            if not overlap:
+                enqueue(f)                                   # (--no-overlap: the frame's own front end inside its timed region, nothing hidden)
+            S["done"].synchronize()
+            per_cam = []
+            for b in range(nc):
+                n = min(int(S["h_cnt"][b, 0]), CAP)
+                if n > EAGER:                                # rare: fetch the rows beyond the eager copy
+                    with torch.cuda.stream(fe_stream):
+                        m = S["match"][b, :n].cpu().numpy()
+                        kps = S["kps"][b, :n].cpu().numpy().reshape(-1).view(KP_DTYPE)
+                else:
+                    # views of the pinned rows: this set is next written for frame f + 2, behind frame f's inter-camera step
+                    m = S["h_match"][b, :n].numpy()
+                    kps = S["h_kps"][b, :n].numpy().reshape(-1).view(KP_DTYPE)
+                per_cam.append((n, m, kps))
+            if overlap and enqueue_next:
+                enqueue(f + 1)                               # the GPU runs the next frame's front end beside this frame's pose rounds
+            t1 = time.perf_counter()
+            jobs, who = [], []
+            for b, (n, m, kps) in enumerate(per_cam):
+                sel = np.nonzero(m >= 0)[0]
+                if len(sel) >= 8:
+                    jobs.append((Xmap[m[sel]], feature_xy(kps[sel]), K)); who.append((b, sel))
+            res = pnp_localize_batch(pose_ctxs[:len(jobs)], jobs, max_iteration=256, seeds=[f + 1] * len(jobs), refine=True) if jobs else []
+            est = {}
+            for (b, sel), r in zip(who, res):
+                if r["Rt"] is None:
+                    continue
+                cam = my_cams[b]
+                n, m, kps = per_cam[b]
+                Rt, cov = r["Rt"], r["cov"]
+                Ce = -Rt[:, :3].T @ Rt[:, 3]
+                Cc = Rt[:, :3].T @ cov[3:, 3:] @ Rt[:, :3]
+                gt = pose_of(cam, f)[2]
+                stats["pos_err"].append(np.linalg.norm(Ce - gt)); stats["n_inl"].append(len(r["inliers"])); stats["n_match"].append(len(sel)); stats["n_kp"].append(n)
+                stats["poses"][(cam, f)] = Rt
+                est[cam] = dict(C=Ce, cov=Cc, gt=gt, Rt=Rt, n=n, kps=kps, m=m)
+            t2 = time.perf_counter()
+            return est, t1 - t0, t2 - t1
+
+        # untimed: the first frame twice (the contexts allocate their workspaces on their first calls)
+        for _ in range(2):
+            if overlap:
+                enqueue(0)
+            solve_frame(0, new_stats(), False)
+        torch.cuda.synchronize()
+        t_start = time.perf_counter()
+        if overlap:
+            enqueue(0)
+        for f in range(args.frames):
+            t0 = time.perf_counter()
+            est, tw, tp = solve_frame(f, st, f + 1 < args.frames)
+            t1 = time.perf_counter()
+            for cam in est:
+                lat["front_end"].append(tw / nc); lat["pose"].append(tp / nc); lat["frame"].append((t1 - t0) / nc)
+            inter_and_fuse(ctx, sptr, f, est, {cm: arena[block_of(f, bb)].data_ptr() for bb, cm in enumerate(my_cams)}, d_pair, st)
+        st["wall"] = time.perf_counter() - t_start
+        torch.cuda.synchronize()
+        fe_ctx.close()
+        for c in pose_ctxs:
+            c.close()
+        return st
+
     # two lanes pay off once each has a chain of camera frames per frame to overlap: measured 0.42 -> 0.27-0.29 ms per camera frame at
     # 8 cameras, no gain at 2 or 3 (the per-frame hand-over between the host threads costs what the overlap buys)
     pipelined = world == 1 and (len(my_cams) >= 4 or args.pipelined) and not args.sequential
-    seq = run_sequential(with_inter=not pipelined)
+    batched = world == 1 and 2 <= len(my_cams) <= 8 and not args.sequential and not args.pipelined
+    seq = run_sequential(with_inter=not (pipelined or batched))
     st = seq
     same = True
+    lanes_st = None
     if pipelined:
-        st = run_pipelined()
+        st = lanes_st = run_pipelined()
         # the two call patterns must have found the same poses
         same = all(np.array_equal(seq["poses"][k], st["poses"].get(k)) for k in seq["poses"]) and len(seq["poses"]) == len(st["poses"])
+    if batched:
+        st = run_batched(overlap=not args.no_overlap)
+        same = same and all(np.array_equal(seq["poses"][k], st["poses"].get(k)) for k in seq["poses"]) and len(seq["poses"]) == len(st["poses"])
     if rank == 0:
         p50 = lambda v: float(np.median(v) * 1e3) if len(v) else None
         med = lambda v: float(np.median(v)) if len(v) else None
@@ -586,9 +713,12 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
         pos_err, pos_err_fused, pos_err_inter = st["pos_err"], st["pos_err_fused"], st["pos_err_inter"]
         out = {"scenario": "config[4]-shaped streaming loop on RENDERED frames (textured plane, %d x %d), %d camera(s) on this rank, %d ranks"
                            % (W, H, len(my_cams), world),
-               "mode": "pipelined: two lanes (host thread + context + stream), each enqueues the front end + counted map match of its next "
-                       "camera frame (no host synchronisation) before it solves its current frame's pose; frame = a frame's wall time over "
-                       "both lanes / cameras" if pipelined else "sequential: camera by camera, a synchronisation between the stages",
+               "mode": ("frame-batched: one front-end call, one counted map-match launch and ONE batched a-contrario solve (clc_pnp_localize_ac_batch) for "
+                        "all cameras of a frame, the next frame's device work enqueued on a second stream before the poses are solved; frame = a "
+                        "frame's wall time / cameras") if batched else
+                       ("pipelined: two lanes (host thread + context + stream), each enqueues the front end + counted map match of its next "
+                        "camera frame (no host synchronisation) before it solves its current frame's pose; frame = a frame's wall time over "
+                        "both lanes / cameras" if pipelined else "sequential: camera by camera, a synchronisation between the stages"),
                "frames_per_camera": args.frames, "localized_frames": len(pos_err), "map_points": int(len(desc_m)),
                "camera_frames_per_s_per_gpu": (1000.0 / p50(lat["frame"])) if lat["frame"] else None,
                "cameras_at_30fps_per_gpu": (1000.0 / p50(lat["frame"]) / 30.0) if lat["frame"] else None,
@@ -606,14 +736,22 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
                "camera_height": HEIGHT,
                "pose_rule": "a-contrario P3P, 256 iterations, error_max = inf (Localizer.hpp:82-93) + LM refinement",
                "note": "frames are rendered on the host before the loop; everything from the uploaded frame to the fused position is timed"}
-        if pipelined:
+        if pipelined or batched:
             sl = seq["lat"]
             out["sequential"] = {"what": "the same frames camera by camera with a synchronisation between the stages (round 3's call pattern), "
                                          "intra-camera stages only", "p50_ms": {k: p50(v) for k, v in sl.items() if v},
                                  "cameras_at_30fps_per_gpu": (1000.0 / p50(sl["frame"]) / 30.0) if sl["frame"] else None,
                                  "localized_frames": len(seq["pos_err"]), "wall_s": seq["wall"]}
             out["same_poses_both_modes"] = bool(same)
-            out["frame_p50_ms"] = {"sequential": p50(sl["frame"]), "pipelined": p50(lat["frame"])}
+            out["frame_p50_ms"] = {"sequential": p50(sl["frame"])}
+            if lanes_st is not None:
+                ll = lanes_st["lat"]
+                out["frame_p50_ms"]["pipelined"] = p50(ll["frame"])
+                out["two_lanes"] = {"what": "two lanes (host thread + context + stream), poses solved one after the other inside a lane",
+                                    "p50_ms": {k: p50(v) for k, v in ll.items() if v},
+                                    "cameras_at_30fps_per_gpu": (1000.0 / p50(ll["frame"]) / 30.0) if ll["frame"] else None}
+            if batched:
+                out["frame_p50_ms"]["batched"] = p50(lat["frame"])
         print(json.dumps(out))
         if not same:
             sys.exit(3)

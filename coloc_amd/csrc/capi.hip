@@ -199,8 +199,10 @@ int ensure_pnp(clc_ctx* ctx, size_t doubles)
     if (ctx->d_pnp) CLC_HIP(ctx, hipFree(ctx->d_pnp));
     ctx->d_pnp = nullptr;
     ctx->pnp_cap = 0;
-    CLC_HIP(ctx, hipMalloc((void**)&ctx->d_pnp, doubles * sizeof(double)));
-    ctx->pnp_cap = doubles;
+    // half as much again: a stream of solves whose sizes creep upwards (map matches per frame) must not reallocate at every new maximum
+    const size_t cap = doubles + doubles / 2;
+    CLC_HIP(ctx, hipMalloc((void**)&ctx->d_pnp, cap * sizeof(double)));
+    ctx->pnp_cap = cap;
     return CLC_OK;
 }
 
@@ -1229,8 +1231,9 @@ static int ensure_pinned(clc_ctx* ctx, size_t bytes)
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->h_pin) CLC_HIP(ctx, hipHostFree(ctx->h_pin));
     ctx->h_pin = nullptr; ctx->pin_cap = 0;
-    CLC_HIP(ctx, hipHostMalloc(&ctx->h_pin, bytes, hipHostMallocDefault));
-    ctx->pin_cap = bytes;
+    const size_t cap = bytes + bytes / 2;           // (see ensure_pnp: a pinned allocation costs a millisecond)
+    CLC_HIP(ctx, hipHostMalloc(&ctx->h_pin, cap, hipHostMallocDefault));
+    ctx->pin_cap = cap;
     return CLC_OK;
 }
 

@@ -50,7 +50,11 @@ public:
     }
     HIPLocalizer(const HIPLocalizer&) = delete;
     HIPLocalizer& operator=(const HIPLocalizer&) = delete;
-    ~HIPLocalizer() { if (ctx_) clc_ctx_destroy(ctx_); }
+    ~HIPLocalizer()
+    {
+        for (clc_ctx* c : batch_ctxs_) clc_ctx_destroy(c);
+        if (ctx_) clc_ctx_destroy(ctx_);
+    }
 
     bool setupTracks(openMVG::cameras::Pinhole_Intrinsic_Radial_K3* cam, colocData& data,
                      const openMVG::features::AKAZE_Binary_Regions& queryRegions, openMVG::matching::IndMatches& trackedFeatures,
@@ -89,6 +93,83 @@ public:
         inliers = matching_data.vec_inliers;
         if (!this->refine(idx, pose, matching_data, covariance, rmse)) std::cerr << "Refining pose for image failed." << std::endl;
         return EXIT_SUCCESS;
+    }
+
+    // localizeImage for SEVERAL cameras at once (not in the reference, whose loop calls localizeImage camera by camera, coloc.hpp:129-137;
+    // BASELINE config[2]: "batched PnP/RANSAC pose").  The cameras' a-contrario solves -- chains of short launches with the host in the
+    // loop -- run through clc_pnp_localize_ac_batch, each on a light context of its own, and interleave on the device; the refinement
+    // follows per camera.  Poses, inliers, covariances and the sampler seeds are exactly those of calling localizeImage for idxs[0],
+    // idxs[1], ... in this order.  Returns one status per camera in the members' convention (false = success).
+    std::vector<bool> localizeImages(const std::vector<int>& idxs, std::vector<openMVG::geometry::Pose3>& poses, colocData& data,
+                                     std::vector<Cov6>& covariances, std::vector<float>& rmses,
+                                     std::vector<openMVG::matching::IndMatches>& trackedFeatures, std::vector<std::vector<uint32_t>>& inliers)
+    {
+        const size_t nc = idxs.size();
+        std::vector<bool> status(nc, static_cast<bool>(EXIT_FAILURE));
+        if (poses.size() < nc) poses.resize(nc);
+        if (covariances.size() < nc) covariances.resize(nc);
+        if (rmses.size() < nc) rmses.resize(nc, 0.0f);
+        if (inliers.size() < nc) inliers.resize(nc);
+        if (!ctx_ || trackedFeatures.size() < nc) return status;
+        while (batch_ctxs_.size() < nc) {
+            clc_ctx* c = nullptr;
+            if (clc_ctx_create(0, nullptr, nullptr, &c) != CLC_OK) return status;
+            batch_ctxs_.push_back(c);
+        }
+        std::vector<openMVG::sfm::Image_Localizer_Match_Data> md(nc);
+        std::vector<std::vector<double>> X(nc), x(nc);
+        std::vector<std::vector<int32_t>> inl(nc);
+        std::vector<double> Kd(9 * nc), Rt(12 * nc);
+        std::vector<clc_pose_job> jobs;
+        std::vector<size_t> who;
+        for (size_t k = 0; k < nc; ++k) {
+            int idx = idxs[k];
+            openMVG::cameras::Pinhole_Intrinsic_Radial_K3 cam = camera(idx);
+            md[k].error_max = std::numeric_limits<double>::infinity();
+            md[k].max_iteration = 256;
+            if (setupTracks(&cam, data, *data.regions.at(idx).get(), trackedFeatures[k], &md[k]) == EXIT_FAILURE) {
+                std::cout << "Failure while setting up 2D-3D correspondences" << std::endl;
+                continue;
+            }
+            const uint64_t seed_value = seed++;                        // (localize() takes its seed before it looks at the data)
+            const int n = static_cast<int>(md[k].pt3D.cols());
+            md[k].vec_inliers.clear();
+            if (n == 0) { std::cout << "Localization unsuccessful" << std::endl; continue; }
+            X[k].resize(3 * static_cast<size_t>(n)); x[k].resize(2 * static_cast<size_t>(n)); inl[k].resize(static_cast<size_t>(n));
+            for (int i = 0; i < n; ++i) {
+                for (int r = 0; r < 3; ++r) X[k][3 * i + r] = md[k].pt3D(r, i);
+                x[k][2 * i] = md[k].pt2D(0, i);
+                x[k][2 * i + 1] = md[k].pt2D(1, i);
+            }
+            intrinsics(cam, &Kd[9 * k]);
+            clc_pose_job jb{};
+            jb.X = X[k].data(); jb.x = x[k].data(); jb.K = &Kd[9 * k]; jb.n = n;
+            jb.max_iteration = static_cast<int>(md[k].max_iteration); jb.seed = seed_value;
+            jb.precision = md[k].error_max;                            // +inf: the a-contrario threshold
+            jb.refine = 0;
+            jb.Rt = &Rt[12 * k]; jb.inliers = inl[k].data();
+            jobs.push_back(jb);
+            who.push_back(k);
+        }
+        if (!jobs.empty()) {
+            const int rc = clc_pnp_localize_ac_batch(batch_ctxs_.data(), jobs.data(), static_cast<int>(jobs.size()));
+            if (rc != CLC_OK) std::cerr << "HIPLocalizer: clc_pnp_localize_ac_batch: " << clc_status_string(rc) << std::endl;
+        }
+        for (size_t j = 0; j < jobs.size(); ++j) {
+            const size_t k = who[j];
+            const clc_pose_job& jb = jobs[j];
+            if (jb.status != CLC_OK) { std::cout << "Localization unsuccessful" << std::endl; continue; }
+            md[k].vec_inliers.assign(inl[k].begin(), inl[k].begin() + jb.n_inliers);
+            if (jb.n_inliers > 0) md[k].error_max = jb.error_max;
+            if (!(jb.n_inliers > 2.5 * 3)) { std::cout << "Localization unsuccessful" << std::endl; continue; }
+            poses[k] = pose_from_Rt(&Rt[12 * k]);
+            std::cout << "Localization successful" << std::endl;
+            inliers[k] = md[k].vec_inliers;
+            int idx = idxs[k];
+            if (!this->refine(idx, poses[k], md[k], covariances[k], rmses[k])) std::cerr << "Refining pose for image failed." << std::endl;
+            status[k] = static_cast<bool>(EXIT_SUCCESS);
+        }
+        return status;
     }
 
     // SfM_Localizer::Localize(P3P_KE_CVPR17, ...): true = a pose supported by more than 2.5 x 3 points was found;
@@ -191,6 +272,7 @@ private:
     }
 
     clc_ctx* ctx_ = nullptr;
+    std::vector<clc_ctx*> batch_ctxs_;          // localizeImages: one light context per camera of a batch, created on first use
     std::pair<int, int>* imageSize;
     std::vector<openMVG::Mat3>* K;
     std::vector<openMVG::Vec3>* dist;

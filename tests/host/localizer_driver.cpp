@@ -81,6 +81,32 @@ int main(int argc, char** argv)
             const bool none = coloc::HIP_SfM_Localizer::Localize(coloc::resection::SolverType::P3P_KE_CVPR17, { (size_t)w, (size_t)h }, nullptr, rd, pose2, 1);
             out.push_back(none ? 1.0 : 0.0);
         }
+        // localizeImages (config[2]'s batched pose): two cameras' worth of the same data in one call on a FRESH localizer must give exactly
+        // what two localizeImage calls in a row give on another fresh one (same sampler seeds in the same order)
+        {
+            coloc::HIPLocalizer seq(params), bat(params);
+            geometry::Pose3 p1, p2;
+            coloc::Cov6 c1, c2;
+            float r1 = -1.0f, r2 = -1.0f;
+            std::vector<uint32_t> i1, i2;
+            int id = 0;
+            const bool s1 = seq.localizeImage(id, p1, data, c1, r1, tracked, i1);
+            const bool s2 = seq.localizeImage(id, p2, data, c2, r2, tracked, i2);
+            std::vector<geometry::Pose3> bp;
+            std::vector<coloc::Cov6> bc;
+            std::vector<float> br;
+            std::vector<matching::IndMatches> bt = { tracked, tracked };
+            std::vector<std::vector<uint32_t>> bi;
+            const std::vector<bool> bs = bat.localizeImages({ 0, 0 }, bp, data, bc, br, bt, bi);
+            bool same = bs.size() == 2 && bs[0] == s1 && bs[1] == s2 && bi[0] == i1 && bi[1] == i2 && br[0] == r1 && br[1] == r2;
+            for (int i = 0; same && i < 3; ++i) {
+                same = same && bp[0].center()[i] == p1.center()[i] && bp[1].center()[i] == p2.center()[i];
+                for (int j = 0; j < 3; ++j) same = same && bp[0].rotation()(i, j) == p1.rotation()(i, j) && bp[1].rotation()(i, j) == p2.rotation()(i, j);
+            }
+            for (int i = 0; same && i < 6; ++i) for (int j = 0; j < 6; ++j) same = same && bc[0](i, j) == c1(i, j) && bc[1](i, j) == c2(i, j);
+            out.push_back(same ? 1.0 : 0.0);
+            out.push_back((s1 || s2) ? 1.0 : 0.0);
+        }
         dump(dir + "/loc_out.bin", out);
     }
     // ---- twoview.bin: [w, h, f, ppx, ppy, n, x1 (2 n), x2 (2 n)]  (undistorted pixels)

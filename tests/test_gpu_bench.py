@@ -43,6 +43,10 @@ def test_default_line_has_contract_fields():
     assert "acransac" in d["pose_solve"]["rule"].lower() or "a-contrario" in d["pose_solve"]["rule"]
     assert d["pose_solve_p50_ms"] > 0 and "section_errors" not in d
     assert 0 < d["pose_solve_p50_ms_c_abi"] <= d["pose_solve_p50_ms"] * 1.2      # the same solve without the wrapper's allocations
+    # config[2]'s batched pose: the cameras' solves in one call give the single solves' results and cost less per pose than one after the other
+    for k in ("cameras_4", "cameras_8"):
+        pb = d["pose_batch"][k]
+        assert pb["identical_results"] is True and 0 < pb["batch_p50_ms"] < pb["one_after_the_other_p50_ms"]
     assert d["settle"]["steps"] == 1000                              # the clock-settling steps are reported, not hidden
     assert d["warmup_effective"] == 3 + 20 + 1000 + 3 and 0 < d["value_cold"] <= 1.05 * d["value"]     # and so is the cold figure
     fe = d["front_end"]                                              # the rebuilt detector: two launches, <= 25 us per 640x480 frame
@@ -125,7 +129,10 @@ def test_streaming_scenario_two_lanes_same_poses():
                          capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = _last_json(out.stdout)
-    assert d["mode"].startswith("pipelined") and d["same_poses_both_modes"] is True
+    # round 4: the headline loop is the frame-batched one (one front-end call, one counted match launch, ONE batched a-contrario solve per
+    # frame); the two-lane loop still runs beside it and all three call patterns must find bit for bit the same poses
+    assert d["mode"].startswith("frame-batched") and d["same_poses_both_modes"] is True
+    assert "pipelined" in d["frame_p50_ms"] and "batched" in d["frame_p50_ms"] and d["two_lanes"]["cameras_at_30fps_per_gpu"] > 8
     assert d["localized_frames"] == 24 and d["sequential"]["localized_frames"] == 24
     assert d["inter_steps"] == 24 and d["inter_failures"] == 0
     assert d["position_error_p50"] < 0.005 * d["camera_height"] and d["position_error_fused_p50"] < 0.005 * d["camera_height"]

@@ -68,6 +68,8 @@ def test_localizer_and_two_view_drivers(tmp_path, gpu_ctx):
     tail = o[51 + n_inl:]
     assert tail[0] == 1.0 and int(tail[1]) == n_inl and np.linalg.norm(tail[2:5] - Ctrue) < 0.05
     assert tail[5] == 0.0                                          # without intrinsics: the uncalibrated kernel is not provided
+    # HIPLocalizer::localizeImages (config[2]'s batched pose): two cameras in one call == two localizeImage calls in a row, bit for bit
+    assert tail[6] == 1.0 and tail[7] == 0.0
 
     t = np.fromfile(tmp_path / "twoview_out.bin", dtype=np.float64)
     assert t[0] == 0.0
