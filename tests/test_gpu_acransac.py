@@ -287,3 +287,38 @@ def test_batched_localisations_equal_the_single_solves(gpu_ctx, oracle):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_batched_localisations_one_bad_job_does_not_take_the_others_down(gpu_ctx):
+    """clc_pnp_localize_ac_batch with a job the entry refuses (more than 16 384 correspondences) between two good ones: the call reports
+    the failure (first failing status), the good jobs are solved all the same and equal the single solves, and the contexts stay usable."""
+    import ctypes as C
+    from coloc_amd import Context
+    from coloc_amd.abi import PoseJob, load_library, CLC_OK
+    lib = load_library()
+    scs = [synth.pnp_scene(600, seed=9100), synth.pnp_scene(17000, seed=9101), synth.pnp_scene(900, seed=9102)]
+    ctxs = [Context(device=0, detector=False, matcher=False) for _ in scs]
+    try:
+        jobs, keep = (PoseJob * 3)(), []
+        for k, sc in enumerate(scs):
+            X, x, K = (np.ascontiguousarray(sc[n], dtype=np.float64) for n in ("X", "x", "K"))
+            N = X.shape[0]
+            Rt, cov, mk, inl = np.zeros(12), np.zeros(36), np.zeros(N, dtype=np.uint8), np.zeros(N, dtype=np.int32)
+            keep.append((X, x, K, Rt, cov, mk, inl))
+            j = jobs[k]
+            j.X, j.x, j.K, j.n, j.max_iteration, j.seed, j.precision, j.refine, j.huber_a = X.ctypes.data, x.ctypes.data, K.ctypes.data, N, 256, 5 + k, float("inf"), 1, 16.0
+            j.Rt, j.cov, j.inlier_mask, j.inliers = Rt.ctypes.data, cov.ctypes.data, mk.ctypes.data, inl.ctypes.data
+        hs = (C.c_void_p * 3)(*[c.h for c in ctxs])
+        rc = lib.clc_pnp_localize_ac_batch(hs, jobs, 3)
+        assert rc != CLC_OK and jobs[1].status == rc and jobs[1].n_inliers == 0
+        for k in (0, 2):
+            assert jobs[k].status == CLC_OK and jobs[k].n_inliers > 0
+            want = gpu_ctx.pnp_acransac(scs[k]["X"], scs[k]["x"], scs[k]["K"], max_iteration=256, seed=5 + k, refine=True)
+            assert np.array_equal(keep[k][3].reshape(3, 4), want["Rt"]) and np.array_equal(keep[k][6][:jobs[k].n_inliers], want["inliers"])
+        # the refused job's context is still good for a solve of its own
+        again = ctxs[1].pnp_acransac(scs[0]["X"], scs[0]["x"], scs[0]["K"], max_iteration=256, seed=5, refine=True)
+        assert np.array_equal(again["Rt"], keep[0][3].reshape(3, 4))
+        assert lib.clc_pnp_localize_ac_batch(hs, jobs, 0) == CLC_OK and lib.clc_pnp_localize_ac_batch(None, None, 2) != CLC_OK
+    finally:
+        for c in ctxs:
+            c.close()
