@@ -58,7 +58,7 @@ EXPORTS = [
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
-    "clc_k2nn_queries_per_block", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
+    "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
     "clc_mc_gather_enqueue_dev", "clc_mc_match_enqueue_dev", "clc_mc_counts", "clc_match_jobs_counted_dev",
 ]
@@ -176,6 +176,7 @@ def load_library():
     lib.clc_k2nn_clock_check.argtypes = [vp, vp, ci, vp, ci, vp, vp, dp, dp, dp, ip]
     lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
     lib.clc_k2nn_queries_per_block.argtypes = [vp]
+    lib.clc_k2nn_plan_query.argtypes = [vp, ci, ci, vp]
     _lib = lib
     return lib
 
@@ -490,6 +491,13 @@ class Context:
     @property
     def k2nn_queries_per_block(self):
         return int(self.lib.clc_k2nn_queries_per_block(self.h))
+
+    def k2nn_plan_query(self, nq, nt):
+        """clc_k2nn_plan_query: how one nq x nt pair would be cut into sweep workgroups (dict)."""
+        info = (C.c_int32 * 8)()
+        self._chk(self.lib.clc_k2nn_plan_query(self.h, int(nq), int(nt), info))
+        return dict(zip(("qblocks", "splits", "t_per_split", "atomic_merge", "bias_a_tiles", "bias_b_tiles", "queries_per_block", "target_blocks"),
+                        [int(v) for v in info]))
 
     def k2nn_clock_check(self, d_q, nq, d_t, nt, d_match, stream=None):
         """In-kernel shader clock of one (diagnostic, stamped) sweep: (median GHz, min, max, workgroups)."""

@@ -117,6 +117,8 @@ struct clc_ctx {
     bool partial_dirty = false;      // armed (all-ones) state of the atomic top-2 rows was lost
     int formulation = K2NN_MATRIX;   // K2NN sweep formulation (k2nn.hip): FP4 matrix pipe, or round 1's popcount kernel for A/B runs
     int target_blocks = 0;           // K2NN sweep workgroups aimed at per launch; 0 = the formulation's default
+    int bias_a = 295, bias_b = 264;  // matrix sweep, one-round single-job plans: train share of a workgroup on wave slot 0 / 1 in 1/256 of the
+                                     // equal share (k2nn.hip; measured optimum 19 : 17 : 13-14 tiles at 10k x 10k); CLC_K2NN_BIAS=a,b, 0,0 = equal shares
     bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
@@ -212,7 +214,7 @@ int default_target_blocks(int formulation) { return formulation == K2NN_POPCOUNT
 int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
 {
     const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
-    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), target, ctx->xcd_map, ctx->formulation);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b);
     const int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;
     if (!plan.atomic_merge) ctx->partial_dirty = true;           // slab mode scribbles over the armed rows
@@ -277,6 +279,10 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         if (v > 0) ctx->target_blocks = v;
     }
     if (const char* e = getenv("CLC_K2NN_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
+    if (const char* e = getenv("CLC_K2NN_BIAS")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a < 1024 && b < 1024) { ctx->bias_a = a; ctx->bias_b = b; }
+    }
     if (const char* e = getenv("CLC_K2NN_FORMULATION"))
         ctx->formulation = (e[0] == 'p' || e[0] == '1') ? K2NN_POPCOUNT : ((e[0] == '2' || strstr(e, "plain")) ? K2NN_MATRIX_PLAIN : K2NN_MATRIX);
     if (dopts) {
@@ -690,6 +696,18 @@ int clc_k2nn_queries_per_block(const clc_ctx* ctx)
     return k2nn_queries_per_block(ctx ? ctx->formulation : K2NN_MATRIX);
 }
 
+int clc_k2nn_plan_query(const clc_ctx* ctx, int nq, int nt, int32_t* info)
+{
+    if (!ctx || nq < 0 || nt < 0 || !info) return CLC_ERR_BAD_ARG;
+    K2nnJobDev jb{};
+    jb.nq = (uint32_t)nq; jb.nt = (uint32_t)nt;
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
+    const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b);
+    info[0] = (int32_t)jb.qblocks; info[1] = (int32_t)jb.splits; info[2] = (int32_t)jb.t_per_split; info[3] = plan.atomic_merge ? 1 : 0;
+    info[4] = (int32_t)jb.bias_a; info[5] = (int32_t)jb.bias_b; info[6] = k2nn_queries_per_block(ctx->formulation); info[7] = target;
+    return CLC_OK;
+}
+
 int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int32_t* d_match, void* stream,
                          double* ghz_median, double* ghz_min, double* ghz_max, int* workgroups)
 {
@@ -703,7 +721,7 @@ int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t,
     jobs[0].q = (const uint4*)d_q; jobs[0].t = (const uint4*)d_t; jobs[0].out = d_match;
     jobs[0].nq = (uint32_t)nq; jobs[0].nt = (uint32_t)nt; jobs[0].thr = 40u;
     const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
-    const K2nnPlan plan = k2nn_plan(jobs.data(), 1, target, ctx->xcd_map, ctx->formulation);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b);
     if (!plan.atomic_merge) return fail(ctx, CLC_ERR_CAPACITY, "k2nn_clock_check: train set too large");
     int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;

@@ -90,6 +90,12 @@ struct K2nnJobDev {
     uint32_t     q_row0;
     uint32_t     xcd_rot;     // matrix sweep: the XCD (workgroup id & 7) that takes this job's query block 0 -- the jobs of a launch
                               // continue round the XCDs where the job before them stopped (k2nn_plan)
+    // matrix sweep, ONE job that fills the chip once (round 4): unequal train shares by the wave slot a workgroup lands on.  The first
+    // 256 workgroup ids take slot 0 of every SIMD, the next 256 slot 1, the rest slot 2 (measured: slot == id / 256 for 760 of 760), and the
+    // matrix pipe serves a lower slot first: with equal shares the slot-0 workgroup of a CU ends its loop at 17.3 us, slot 1 at 19.0, slot 2
+    // at 22.5, the last part of it alone on the CU at a quarter of the CU's rate.  bias_a / bias_b = train tiles of a slot-0 / slot-1 split
+    // (0 = equal shares); the slot-2 splits of a query block take what is left.
+    uint32_t     bias_a, bias_b;
 };
 // the sizes a sweep workgroup works with (scalar loads when the counts live in device memory)
 __device__ __forceinline__ uint32_t k2nn_job_nq(const K2nnJobDev& job)
@@ -116,7 +122,8 @@ struct K2nnPlan {
 // The two formulations of the sweep (k2nn.hip): FP4 matrix pipe (default) and round 1's xor + popcount VALU kernel.
 enum { K2NN_MATRIX = 0, K2NN_POPCOUNT = 1, K2NN_MATRIX_PLAIN = 2 };   // PLAIN: round 2's tile loop (no MFMA / top-2 interleave)
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true, int formulation = K2NN_MATRIX);
+// bias_a / bias_b: train share of a workgroup on wave slot 0 / 1 in 1/256 of the equal share (0: equal shares); used by single-job one-round plans only
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true, int formulation = K2NN_MATRIX, int bias_a = 0, int bias_b = 0);
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
 // In atomic mode d_partial must hold 0xFF bytes in every entry the jobs use (top-2 rows and arrival counters);
 // the workgroup that completes a query block leaves it that way again (self re-arming workspace).

@@ -45,6 +45,7 @@
 //     writes the int32 results and re-arms rows and counter -- no second launch, no spinning.
 //     Train sets beyond 2^22 vectors fall back to per-split slabs + an ordered merge kernel.
 #include "clc_internal.h"
+#include <algorithm>
 
 namespace clc {
 
@@ -364,8 +365,13 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     // XCD, so an XCD's L2 pulls an eighth of the queries plus the train set instead of all of both (PMC, 10k x 10k:
     // 10.1 MB fetched with the plain order = 8 x (Q + T)).  The grid is padded to a multiple of 8 query blocks.
     const uint32_t within = blockIdx.x >> 3;
-    const uint32_t qblock = ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within / job.splits);
-    const uint32_t split = within % job.splits;
+    const bool biased = job.bias_a != 0u;
+    // biased shares: the query blocks of an XCD are INTERLEAVED over its workgroups (query block = within % nqx), so that every query
+    // block has splits on all three wave slots (blocked, as below, the 19 splits of a query block sit on one slot)
+    const uint32_t nqx = job.qblocks >> 3;                          // query blocks per XCD (biased plans: a multiple of 8 in all)
+    const uint32_t qblock = biased ? ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within % nqx)
+                                   : ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within / job.splits);
+    const uint32_t split = biased ? within / nqx : within % job.splits;
     if (qblock >= job.qblocks) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -412,8 +418,25 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     for (int qt = 0; qt < QT; ++qt) { best[qt] = __uint_as_float(kMxInf); second[qt] = __uint_as_float(kMxInf); }
 
     // this workgroup's train rows [s0, s1): t_per_split is a multiple of 32, so only the train set's last tile can be partial
-    const uint32_t s0 = min(split * job.t_per_split, job_nt);
-    const uint32_t s1 = min(s0 + job.t_per_split, job_nt);
+    uint32_t s0 = min(split * job.t_per_split, job_nt);
+    uint32_t s1 = min(s0 + job.t_per_split, job_nt);
+    if (biased) {
+        // split k of this query block sits on wave slot (k nqx + q) / 32, q = the query block's place on its XCD: n0 splits of bias_a
+        // tiles, n1 of bias_b, the remaining n2 share what is left (the last one takes the remainder)
+        const uint32_t ql = within % nqx;
+        const uint32_t n0 = min((32u - ql + nqx - 1u) / nqx, job.splits);
+        const uint32_t n1 = min((64u - ql + nqx - 1u) / nqx, job.splits) - n0;
+        const uint32_t n2 = job.splits - n0 - n1;
+        const uint32_t nt_tiles = (job_nt + 31u) >> 5;
+        const uint32_t used = n0 * job.bias_a + n1 * job.bias_b;
+        const uint32_t rest = nt_tiles > used ? nt_tiles - used : 0u;
+        const uint32_t c = n2 ? rest / n2 : 0u, extra = n2 ? rest - c * n2 : 0u;      // the first `extra` slot-2 splits take one tile more
+        const uint32_t k0 = min(split, n0), k1 = min(split - k0, n1), k2 = split - k0 - k1;
+        const uint32_t begin = k0 * job.bias_a + k1 * job.bias_b + k2 * c + min(k2, extra);
+        const uint32_t size = split < n0 ? job.bias_a : (split < n0 + n1 ? job.bias_b : c + (k2 < extra ? 1u : 0u));
+        s0 = min(begin * 32u, job_nt);
+        s1 = split + 1u == job.splits ? job_nt : min(s0 + size * 32u, job_nt);
+    }
     const uint32_t ntiles = (s1 - s0 + 31u) >> 5;
     const int scale_a = 0x8B8B8B8B, scale_b = 0x7F7F7F7F;            // E8M0 block scales: 2^12 (trains), 1 (queries)
     // train tile = 32 rows x 64 B = 2 KB contiguous: thread tid owns its 8 bytes number tid = row tid >> 3, words
@@ -577,7 +600,9 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
         uint64_t* o = stamps + 8u * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
         o[5] = __builtin_amdgcn_s_memrealtime();
         o[6] = ((uint64_t)qblock << 32) | split;
-        o[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));      // XCC_ID[3:0]
+        // XCC_ID[3:0] | HW_ID << 8 (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13]: where on the chip this workgroup's wave 0 sits)
+        o[7] = (uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11)) |
+               ((uint64_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)) << 8);
     }
     if (s_arrival != job.splits - 1u) return;
     if (tid == 0) atomicExch(cnt, kEmpty);
@@ -670,7 +695,7 @@ __global__ __launch_bounds__(kMergeQ * kMergeGroups) void k2nn_merge_kernel(cons
     if (job.second_out) job.second_out[qi] = (uint16_t)min(a.second_v, 65535);
 }
 
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map, int formulation)
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map, int formulation, int bias_a, int bias_b)
 {
     const bool mx = formulation != K2NN_POPCOUNT;
     const uint32_t qpb = mx ? kMxQPerBlock : kQPerBlock;
@@ -720,6 +745,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         splits = jb.nt ? (jb.nt + per - 1) / per : 1u;
         jb.splits = splits;
         jb.t_per_split = per;
+        jb.bias_a = jb.bias_b = 0u;
         jb.nq_pad = (jb.nq + 63u) & ~63u;
         jb.partial_off = (uint32_t)off;
         jb.atomic_merge = plan.atomic_merge ? 1u : 0u;
@@ -727,6 +753,33 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         if (plan.atomic_merge) {                                          // arrival counters: one uint32 per query block
             jb.cnt_off = (uint32_t)(2u * off);
             off += (jb.qblocks + 1u) / 2u;
+        }
+    }
+    if (mx && njobs == 1 && plan.atomic_merge && bias_a > 0 && bias_b > 0) {
+        // unequal shares by wave slot (K2nnJobDev.bias_a): one job whose grid is one round of three workgroups per CU -- every XCD holds
+        // more than 64 and at most 96 of them -- with whole eights of query blocks (nothing padded) and counts known on the host
+        K2nnJobDev& jb = jobs[0];
+        const uint32_t per_xcd = (jb.qblocks >> 3) * jb.splits;
+        const uint32_t nt_tiles = (jb.nt + 31u) >> 5;
+        const uint32_t mean = jb.splits ? nt_tiles / jb.splits : 0u;
+        // (with one or two query blocks per XCD the biased plan measured 0.3-0.8 us SLOWER -- 2048 x 60000, 4096 x 30000 --, from three on 1-2 us faster)
+        if ((jb.qblocks & 7u) == 0u && jb.qblocks >= 24u && per_xcd > 64u && per_xcd <= 96u && !jb.cnt_q && !jb.cnt_t && jb.splits >= 6u && mean >= 8u) {
+            // bias_a / bias_b arrive in 1/256 of the equal share (values below 64: tiles, for experiments)
+            const uint32_t den = jb.splits * 256u;
+            const uint32_t a = bias_a < 64 ? (uint32_t)bias_a : (nt_tiles * (uint32_t)bias_a + den / 2u) / den;
+            const uint32_t b = bias_b < 64 ? (uint32_t)bias_b : (nt_tiles * (uint32_t)bias_b + den / 2u) / den;
+            // every query block's split sizes as the kernel derives them: all within the 13-bit index field (256 tiles), the slot-0 and
+            // slot-1 splits inside the train set
+            const uint32_t nqx = jb.qblocks >> 3;
+            bool ok = a >= 1u && b >= 1u && a <= 255u && b <= 255u;
+            for (uint32_t ql = 0; ok && ql < nqx; ++ql) {
+                const uint32_t n0 = std::min((32u - ql + nqx - 1u) / nqx, jb.splits);
+                const uint32_t n1 = std::min((64u - ql + nqx - 1u) / nqx, jb.splits) - n0;
+                const uint32_t n2 = jb.splits - n0 - n1;
+                const uint32_t used = n0 * a + n1 * b;
+                ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u;
+            }
+            if (ok) { jb.bias_a = a; jb.bias_b = b; }
         }
     }
     plan.partial_elems = off;

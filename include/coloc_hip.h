@@ -239,6 +239,12 @@ int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation);
 /* Queries per sweep workgroup of the context's formulation: the grain on which a caller that deals query slices out
  * to several GPUs (clc_match_job.q_offset / nq) should cut them, so that no workgroup is split between two jobs. */
 int clc_k2nn_queries_per_block(const clc_ctx* ctx);
+/* How the context would cut ONE nq x nt pair into sweep workgroups (planning only, nothing is launched): info[0] query blocks, [1] train
+ * splits per query block, [2] train rows per equal split, [3] 1 = splits folded in-launch (atomic top-2 rows), 0 = slabs + merge kernel,
+ * [4], [5] train TILES (32 rows) of a split on wave slot 0 / 1 when the pair runs as one round with unequal shares by wave slot
+ * (0 = equal shares; round 4, k2nn.hip), [6] queries per workgroup, [7] workgroups aimed at per launch.  The reference has no such
+ * entry (its grid is ((num_q - 1) >> 8) + 1 blocks, CUDAK2NN.cu:79); tests and bench.py report the plan with it. */
+int clc_k2nn_plan_query(const clc_ctx* ctx, int nq, int nt, int32_t* info);
 
 /* Measurement aid (replaces nothing in the reference): runs ONE sweep of d_q x d_t with the diagnostic build of the
  * matrix-formulation kernel, whose workgroups bracket their tile loop with the shader-clock and the constant 100 MHz

@@ -333,3 +333,44 @@ def test_descriptor_cache_hits_only_on_the_published_block(oracle):
     assert np.array_equal(res[0], oracle.k2nn(desc, other, 40)) and np.array_equal(res[1], oracle.k2nn(other, desc, 40))
     assert desc_cache_stats()[0] >= h2 + 3
     det.close(); mat.close()
+
+
+@pytest.mark.parametrize("nq,nt", [(10000, 10000), (10000, 9985), (10240, 12000), (9985, 7211), (8192, 20000), (6144, 16001), (8192, 8192), (14336, 5000)])
+def test_one_round_plans_with_unequal_shares_by_wave_slot(oracle, k2nn_formulation, nq, nt):
+    """Round 4: a single pair whose sweep is ONE round of three workgroups per CU gives the workgroups on wave slot 0 / 1 / 2 of their SIMDs
+    unequal train shares (k2nn.hip: the matrix pipe serves a lower slot first) and interleaves the query blocks of an XCD over its
+    workgroups.  Shapes that take that plan (whole eights of query blocks, 65..96 workgroups per XCD) with ragged train counts, ties across
+    the unequal split boundaries included: same indices and distances as the oracle, and as a context with equal shares."""
+    import os
+    from coloc_amd import Context
+    Q, T = synth.planted_descriptors(nq, nt, seed=1234 + nq + nt)
+    step = max(nt // 97, 1)
+    T[step::step] = T[0]                                # the same row at ~97 places over the whole train set: ties for the minimum across splits
+    Q[0] = T[0]
+    Q[1] = T[0]; Q[1, 3] ^= 1                           # distance 1 to every copy: lowest index must win, second == best -> rejected
+    mo, bo, so = oracle.k2nn(Q, T, 40, want_dist=True)
+    res = []
+    for bias in ("295,264", "0,0", "22,9", "9,22"):      # default, equal shares, and two lopsided settings in tiles
+        old = os.environ.get("CLC_K2NN_BIAS")
+        os.environ["CLC_K2NN_BIAS"] = bias
+        try:
+            ctx = Context(device=0, width=640, height=480, maxkp=max(nq, nt), detector=False)
+        finally:
+            if old is None:
+                del os.environ["CLC_K2NN_BIAS"]
+            else:
+                os.environ["CLC_K2NN_BIAS"] = old
+        try:
+            ctx.set_k2nn_formulation(k2nn_formulation)
+            plan = ctx.k2nn_plan_query(nq, nt)
+            # the matrix formulations take the unequal-share plan for these shapes (unless switched off), the popcount sweep never does
+            assert (plan["bias_a_tiles"] > 0) == (k2nn_formulation != "popcount" and bias != "0,0"), plan
+            if bias == "22,9" and plan["bias_a_tiles"]:
+                assert (plan["bias_a_tiles"], plan["bias_b_tiles"]) == (22, 9)
+            for _ in range(2):                          # twice: the rows and counters re-arm
+                m, b, s = ctx.match_2nn(Q, T, 40, want_dist=True)
+            res.append((m, b, s))
+        finally:
+            ctx.close()
+    for m, b, s in res:
+        assert np.array_equal(m, mo) and np.array_equal(b, bo) and np.array_equal(s, so)

@@ -45,3 +45,13 @@ wg = ids                        # rows are in blockIdx.x order (one job)
 for lo in range(0, len(h), 128):
     m = (wg >= lo) & (wg < lo + 128)
     print("  workgroups %3d-%3d: loop length p50 %.2f us, loop end p50 %.2f us" % (lo, min(lo + 127, len(h) - 1), np.median((le - ls)[m]), np.median(le[m])))
+
+# where each workgroup sat (HW_ID of its wave 0): does the wave slot -- the order in which a CU's workgroups arrived -- decide who is served?
+hw = (h[:, 7] >> 8).astype(np.int64)
+slot, simd, cu, sh, se = hw & 0xF, (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+print("wave slot of wave 0:", {int(v): int((slot == v).sum()) for v in np.unique(slot)})
+for v in np.unique(slot):
+    m = slot == v
+    print("  slot %d: %3d workgroups, loop length p50 %.2f us (p10 %.2f, p90 %.2f), loop end p50 %.2f, p90 %.2f" % (v, m.sum(), np.median((le - ls)[m]), np.percentile((le - ls)[m], 10), np.percentile((le - ls)[m], 90), np.median(le[m]), np.percentile(le[m], 90)))
+for name, f in (("id // 256", lambda v: v // 256),):
+    print("  slot == %-14s for %4d of %d workgroups" % (name, int((f(ids) == slot).sum()), len(ids)))

@@ -9,7 +9,9 @@ dev = torch.device("cuda", 0)
 ctx = Context(device=0, width=640, height=480, maxkp=20000)
 st = torch.cuda.Stream(device=dev); torch.cuda.set_stream(st)
 print(os.path.basename(os.environ.get("COLOC_HIP_LIB", "in tree")))
-for nq, nt in [(10000, 10000), (8508, 9390), (9000, 9000), (7000, 10000), (5000, 10000), (3000, 10000), (1500, 10000), (12000, 12000), (6000, 6000)]:
+SIZES = [(10000, 10000), (8508, 9390), (9000, 9000), (7000, 10000), (5000, 10000), (3000, 10000), (1500, 10000), (12000, 12000), (6000, 6000)]
+if os.environ.get("SIZES"): SIZES = [tuple(int(v) for v in p.split("x")) for p in os.environ["SIZES"].split(",")]
+for nq, nt in SIZES:
     Qh, Th = synth.planted_descriptors(nq, nt, seed=5)
     Q, T = torch.from_numpy(Qh).to(dev), torch.from_numpy(Th).to(dev)
     m = torch.empty(nq, dtype=torch.int32, device=dev); ref = torch.empty(nq, dtype=torch.int32, device=dev)
