@@ -341,11 +341,8 @@ __device__ __forceinline__ uint32_t mx_decode_rel(const uint32_t bits, const uin
 // t covers the top-2 of chain 0 of tile t, chain 0 of tile t + 1 covers the top-2 of chain 1 of tile t -- so the kernel keeps its
 // three waves per SIMD; the price is that every A operand is read from LDS twice.  PIPE = false is round 2's loop (k-step outer,
 // both chains per A read, then all 64 v_med3): kept selectable as CLC_K2NN_MATRIX_PLAIN for A/B runs.
-#ifndef CLC_K2NN_MIN_WAVES
-#define CLC_K2NN_MIN_WAVES 1
-#endif
-template <bool STAMP, int MODE>
-__global__ __launch_bounds__(64 * kMxWaves, CLC_K2NN_MIN_WAVES) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial,
+template <bool STAMP, bool PIPE>
+__global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial,
                                                                       uint64_t* __restrict__ stamps)
 {
     constexpr int QT = kMxQT;
@@ -460,86 +457,6 @@ __global__ __launch_bounds__(64 * kMxWaves, CLC_K2NN_MIN_WAVES) void k2nn_sweep_
     for (int i = 0; i < 16; ++i) { acc0[i] = __uint_as_float(kMxInf); acc1[i] = __uint_as_float(kMxInf); }
     uint64_t st_clk = 0, st_real = 0;
     if (STAMP) { st_clk = __builtin_amdgcn_s_memtime(); st_real = __builtin_amdgcn_s_memrealtime(); }
-    constexpr bool PIPE = MODE == 1;
-    if (MODE == 2) {
-        // Round 4: both chains of a tile advance TOGETHER -- every A operand is read from LDS once and feeds two MFMAs (chain 0, chain 1),
-        // which also alternates two independent accumulator chains inside the wave (a chain of eight dependent MFMAs waits for its own
-        // result every time; three waves per SIMD covered that only partly) -- while the 32 keys of the tile BEFORE are folded into the
-        // running top-2 in the MFMAs' shadow.  That takes two accumulator sets per chain, alternating between "being computed" and
-        // "being folded" from tile to tile (the loop is unrolled by two so that the roles are register names, not copies).
-        mx_v16f xa0 = acc0, xa1 = acc0, xb0 = acc0, xb1 = acc0;            // all "none"
-        auto stage = [&](const uint32_t t) __attribute__((always_inline)) {
-            const uint32_t buf = t & 1u;
-            s_a[buf][dst] = mx_expand_not(r0.x);
-            s_a[buf][dst + 32] = mx_expand_not(r0.y);
-            r0 = r1;
-            __syncthreads();          // one barrier per tile: buffer `buf` was last read two iterations ago, before the previous barrier
-            if (t + 2u < ntiles) r1 = load_bits(t + 2u);                // bits of the tile after next: in flight for a whole tile
-            if (t + 1u == ntiles && ((s1 - s0) & 31u)) {
-                // partial last tile: rows past the end get a penalty that puts their distance field above 512
-                const uint32_t valid = (s1 - s0) & 31u;
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if ((uint32_t)(8 * (i >> 2) + 4 * (int)(lane >> 5) + (i & 3)) >= valid) cinit[i] += 4194304.0f + 8192.0f;
-            }
-        };
-        auto fold2 = [&](const int q, const float k0, const float k1) __attribute__((always_inline)) {
-            second[q] = mx_med3(best[q], second[q], k0);
-            best[q] = mx_med3(best[q], k0, 0.0f);             // = min: every key is > 0
-            second[q] = mx_med3(best[q], second[q], k1);
-            best[q] = mx_med3(best[q], k1, 0.0f);
-        };
-        auto body = [&](const uint32_t buf, mx_v16f& cur0, mx_v16f& cur1, const mx_v16f& prev0, const mx_v16f& prev1) __attribute__((always_inline)) {
-#ifndef CLC_K2NN_AHEAD2
-#define CLC_K2NN_AHEAD2 2
-#endif
-            constexpr int kAhead = CLC_K2NN_AHEAD2;                      // an A operand now lasts two MFMAs
-            u32x4 ring[kAhead];
-#pragma unroll
-            for (int k = 0; k < kAhead; ++k) ring[k] = s_a[buf][k * kStride + lane];
-            mx_v16f ci;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) ci[i] = cinit[i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const u32x4 av = ring[j % kAhead];
-                const mx_v8i a8 = { (int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0 };
-                if (j + kAhead < 8) ring[j % kAhead] = s_a[buf][(j + kAhead) * kStride + lane];
-                const mx_v8i b80 = { b[0][j].x, b[0][j].y, b[0][j].z, b[0][j].w, 0, 0, 0, 0 };
-                const mx_v8i b81 = { b[1][j].x, b[1][j].y, b[1][j].z, b[1][j].w, 0, 0, 0, 0 };
-                cur0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b80, j == 0 ? ci : cur0, 4, 4, 0, scale_a, 0, scale_b);
-                fold2(0, prev0[2 * j], prev0[2 * j + 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                cur1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b81, j == 0 ? ci : cur1, 4, 4, 0, scale_a, 0, scale_b);
-                fold2(1, prev1[2 * j], prev1[2 * j + 1]);
-                if (j == 7) {                                            // the step back of the tile just folded in (see the plain loop)
-#pragma unroll
-                    for (int q = 0; q < QT; ++q) { best[q] -= 32.0f; second[q] -= 32.0f; }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        auto fold_last = [&](const mx_v16f& l0, const mx_v16f& l1) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) { fold2(0, l0[i], l0[i + 1]); fold2(1, l1[i], l1[i + 1]); }
-#pragma unroll
-            for (int q = 0; q < QT; ++q) { best[q] -= 32.0f; second[q] -= 32.0f; }
-        };
-        uint32_t t = 0;
-        for (; t + 1u < ntiles; t += 2u) {
-            stage(t);
-            body(0u, xa0, xa1, xb0, xb1);
-            stage(t + 1u);
-            body(1u, xb0, xb1, xa0, xa1);
-        }
-        if (t < ntiles) {
-            stage(t);
-            body(0u, xa0, xa1, xb0, xb1);
-            fold_last(xa0, xa1);
-        } else {
-            fold_last(xb0, xb1);          // (no tile at all: "none" all round)
-        }
-    } else
     for (uint32_t t = 0; t < ntiles; ++t) {
         const uint32_t buf = t & 1u;
         s_a[buf][dst] = mx_expand_not(r0.x);
@@ -891,18 +808,16 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, true, stream);
             if (formulation == K2NN_POPCOUNT)
                 hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
-            else {
-                const dim3 grid(grid_x, cnt), block(64 * kMxWaves);
-                uint64_t* const no_stamps = nullptr;
-                switch ((formulation == K2NN_MATRIX_PLAIN ? 0 : (formulation == K2NN_MATRIX_R3 ? 1 : 2)) + (d_stamps ? 3 : 0)) {
-                case 0: hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, 0>), grid, block, 0, stream, list, d_partial, no_stamps); break;
-                case 1: hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, 1>), grid, block, 0, stream, list, d_partial, no_stamps); break;
-                case 2: hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, 2>), grid, block, 0, stream, list, d_partial, no_stamps); break;
-                case 3: hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, 0>), grid, block, 0, stream, list, d_partial, d_stamps); break;
-                case 4: hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, 1>), grid, block, 0, stream, list, d_partial, d_stamps); break;
-                default: hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, 2>), grid, block, 0, stream, list, d_partial, d_stamps); break;
-                }
-            }
+            else if (d_stamps && formulation == K2NN_MATRIX_PLAIN)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, false>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
+            else if (d_stamps)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
+            else if (formulation == K2NN_MATRIX_PLAIN)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, false>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                                   (uint64_t*)nullptr);
+            else
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                                   (uint64_t*)nullptr);
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, false, stream);
         }
         if (list.j[0].atomic_merge) {
