@@ -117,8 +117,8 @@ struct clc_ctx {
     bool partial_dirty = false;      // armed (all-ones) state of the atomic top-2 rows was lost
     int formulation = K2NN_MATRIX;   // K2NN sweep formulation (k2nn.hip): FP4 matrix pipe, or round 1's popcount kernel for A/B runs
     int target_blocks = 0;           // K2NN sweep workgroups aimed at per launch; 0 = the formulation's default
-    int bias_a = 295, bias_b = 264;  // matrix sweep, one-round single-job plans: train share of a workgroup on wave slot 0 / 1 in 1/256 of the
-                                     // equal share (k2nn.hip; measured optimum 19 : 17 : 13-14 tiles at 10k x 10k); CLC_K2NN_BIAS=a,b, 0,0 = equal shares
+    int bias_a = 326, bias_b = 249;  // matrix sweep, one-round single-job plans: train share of a workgroup on wave slot 0 / 1 in 1/256 of the
+                                     // equal share (k2nn.hip; measured optimum 21 : 16 : 12-13 tiles at 10k x 10k); CLC_K2NN_BIAS=a,b, 0,0 = equal shares
     bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results

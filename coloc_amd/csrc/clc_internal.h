@@ -114,6 +114,9 @@ static constexpr int kK2nnJobsPerLaunch = 16;
 // Passed BY VALUE as the kernel argument (1.2 KB of kernarg): no job upload, no staging hazard.
 struct K2nnJobList {
     K2nnJobDev j[kK2nnJobsPerLaunch];
+    // job 0 with unequal shares by wave slot (bias_a != 0): what workgroup w = id >> 3 of an XCD takes -- query block of the XCD (bits 0..7),
+    // first train tile (8..19), train tiles (20..31); filled by launch_k2nn (no integer division in the kernel: ~30 vector instructions each)
+    uint32_t bias_tab[96];
 };
 struct K2nnPlan {
     size_t   partial_elems;// uint2 entries needed

@@ -368,11 +368,11 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     const bool biased = job.bias_a != 0u;
     // biased shares: the query blocks of an XCD are INTERLEAVED over its workgroups (query block = within % nqx), so that every query
     // block has splits on all three wave slots (blocked, as below, the 19 splits of a query block sit on one slot)
-    const uint32_t nqx = job.qblocks >> 3;                          // query blocks per XCD (biased plans: a multiple of 8 in all)
-    const uint32_t qblock = biased ? ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within % nqx)
+    const uint32_t bias_e = biased ? jobs.bias_tab[within < 96u ? within : 95u] : 0u;       // (a biased plan has at most 96 workgroups per XCD)
+    const uint32_t qblock = biased ? ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (bias_e & 0xFFu)
                                    : ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within / job.splits);
-    const uint32_t split = biased ? within / nqx : within % job.splits;
-    if (qblock >= job.qblocks) return;
+    const uint32_t split = biased ? (STAMP ? within / (job.qblocks >> 3) : 0u) : within % job.splits;   // (biased plans fold in-launch: no slab row)
+    if (qblock >= job.qblocks || (biased && within >= (job.qblocks >> 3) * job.splits)) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -421,21 +421,8 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     uint32_t s0 = min(split * job.t_per_split, job_nt);
     uint32_t s1 = min(s0 + job.t_per_split, job_nt);
     if (biased) {
-        // split k of this query block sits on wave slot (k nqx + q) / 32, q = the query block's place on its XCD: n0 splits of bias_a
-        // tiles, n1 of bias_b, the remaining n2 share what is left (the last one takes the remainder)
-        const uint32_t ql = within % nqx;
-        const uint32_t n0 = min((32u - ql + nqx - 1u) / nqx, job.splits);
-        const uint32_t n1 = min((64u - ql + nqx - 1u) / nqx, job.splits) - n0;
-        const uint32_t n2 = job.splits - n0 - n1;
-        const uint32_t nt_tiles = (job_nt + 31u) >> 5;
-        const uint32_t used = n0 * job.bias_a + n1 * job.bias_b;
-        const uint32_t rest = nt_tiles > used ? nt_tiles - used : 0u;
-        const uint32_t c = n2 ? rest / n2 : 0u, extra = n2 ? rest - c * n2 : 0u;      // the first `extra` slot-2 splits take one tile more
-        const uint32_t k0 = min(split, n0), k1 = min(split - k0, n1), k2 = split - k0 - k1;
-        const uint32_t begin = k0 * job.bias_a + k1 * job.bias_b + k2 * c + min(k2, extra);
-        const uint32_t size = split < n0 ? job.bias_a : (split < n0 + n1 ? job.bias_b : c + (k2 < extra ? 1u : 0u));
-        s0 = min(begin * 32u, job_nt);
-        s1 = split + 1u == job.splits ? job_nt : min(s0 + size * 32u, job_nt);
+        s0 = min(((bias_e >> 8) & 0xFFFu) * 32u, job_nt);
+        s1 = min(s0 + (bias_e >> 20) * 32u, job_nt);
     }
     const uint32_t ntiles = (s1 - s0 + 31u) >> 5;
     const int scale_a = 0x8B8B8B8B, scale_b = 0x7F7F7F7F;            // E8M0 block scales: 2^12 (trains), 1 (queries)
@@ -803,6 +790,28 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             if (list.j[j].nt == 0u && list.j[j].nq > max_nq_empty) max_nq_empty = list.j[j].nq;
         }
         for (int j = cnt; j < kK2nnJobsPerLaunch; ++j) list.j[j] = K2nnJobDev{};
+        for (uint32_t& e : list.bias_tab) e = 0u;
+        if (cnt == 1 && list.j[0].bias_a != 0u && formulation != K2NN_POPCOUNT) {
+            // workgroup w of an XCD: query block w % nqx (the query blocks of an XCD interleaved, so that each has splits on all three wave
+            // slots), its split k = w / nqx sits on slot w / 32: n0 splits of bias_a tiles, n1 of bias_b, the n2 slot-2 splits share the
+            // rest (the first `extra` of them one tile more)
+            const K2nnJobDev& jb = list.j[0];
+            const uint32_t nqx = jb.qblocks >> 3, nt_tiles = (jb.nt + 31u) >> 5;
+            for (uint32_t w = 0; w < nqx * jb.splits && w < 96u; ++w) {
+                const uint32_t ql = w % nqx, k = w / nqx;
+                const uint32_t n0 = std::min((32u - ql + nqx - 1u) / nqx, jb.splits);
+                const uint32_t n1 = std::min((64u - ql + nqx - 1u) / nqx, jb.splits) - n0;
+                const uint32_t n2 = jb.splits - n0 - n1;
+                const uint32_t used = n0 * jb.bias_a + n1 * jb.bias_b;
+                const uint32_t rest = nt_tiles > used ? nt_tiles - used : 0u;
+                const uint32_t c = n2 ? rest / n2 : 0u, extra = n2 ? rest - c * n2 : 0u;
+                const uint32_t k0 = std::min(k, n0), k1 = std::min(k - k0, n1), k2 = k - k0 - k1;
+                const uint32_t begin = k0 * jb.bias_a + k1 * jb.bias_b + k2 * c + std::min(k2, extra);
+                uint32_t size = k < n0 ? jb.bias_a : (k < n0 + n1 ? jb.bias_b : c + (k2 < extra ? 1u : 0u));
+                if (k + 1u == jb.splits) size = nt_tiles > begin ? nt_tiles - begin : 0u;      // the last split takes what is left
+                list.bias_tab[w] = ql | (std::min(begin, 4095u) << 8) | (std::min(size, 4095u) << 20);
+            }
+        }
         if (max_nq == 0) continue;
         if (grid_x > 0) {
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, true, stream);

@@ -350,7 +350,7 @@ def test_one_round_plans_with_unequal_shares_by_wave_slot(oracle, k2nn_formulati
     Q[1] = T[0]; Q[1, 3] ^= 1                           # distance 1 to every copy: lowest index must win, second == best -> rejected
     mo, bo, so = oracle.k2nn(Q, T, 40, want_dist=True)
     res = []
-    for bias in ("295,264", "0,0", "22,9", "9,22"):      # default, equal shares, and two lopsided settings in tiles
+    for bias in ("326,249", "0,0", "22,9", "9,22"):      # default, equal shares, and two lopsided settings in tiles
         old = os.environ.get("CLC_K2NN_BIAS")
         os.environ["CLC_K2NN_BIAS"] = bias
         try:
