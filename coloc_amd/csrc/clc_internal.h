@@ -96,6 +96,7 @@ struct K2nnJobDev {
     // at 22.5, the last part of it alone on the CU at a quarter of the CU's rate.  bias_a / bias_b = train tiles of a slot-0 / slot-1 split
     // (0 = equal shares); the slot-2 splits of a query block take what is left.
     uint32_t     bias_a, bias_b;
+    uint32_t     bias_magic;  // ceil(2^32 / qblocks): workgroup id / qblocks as a multiply-high (exact for ids below 2^16)
 };
 // the sizes a sweep workgroup works with (scalar loads when the counts live in device memory)
 __device__ __forceinline__ uint32_t k2nn_job_nq(const K2nnJobDev& job)
@@ -114,9 +115,10 @@ static constexpr int kK2nnJobsPerLaunch = 16;
 // Passed BY VALUE as the kernel argument (1.2 KB of kernarg): no job upload, no staging hazard.
 struct K2nnJobList {
     K2nnJobDev j[kK2nnJobsPerLaunch];
-    // job 0 with unequal shares by wave slot (bias_a != 0): what workgroup w = id >> 3 of an XCD takes -- query block of the XCD (bits 0..7),
-    // first train tile (8..19), train tiles (20..31); filled by launch_k2nn (no integer division in the kernel: ~30 vector instructions each)
-    uint32_t bias_tab[96];
+    // job 0 with unequal shares by wave slot (bias_a != 0), filled by launch_k2nn (no integer division in the kernel: ~30 vector
+    // instructions each).  bias_magic == 0: what workgroup w = id >> 3 of an XCD takes -- query block of the XCD (bits 0..7), first train
+    // tile (8..19), train tiles (20..31); bias_magic != 0: per query block, see launch_k2nn
+    uint32_t bias_tab[128];
 };
 struct K2nnPlan {
     size_t   partial_elems;// uint2 entries needed

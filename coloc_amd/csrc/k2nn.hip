@@ -341,7 +341,7 @@ __device__ __forceinline__ uint32_t mx_decode_rel(const uint32_t bits, const uin
 // t covers the top-2 of chain 0 of tile t, chain 0 of tile t + 1 covers the top-2 of chain 1 of tile t -- so the kernel keeps its
 // three waves per SIMD; the price is that every A operand is read from LDS twice.  PIPE = false is round 2's loop (k-step outer,
 // both chains per A read, then all 64 v_med3): kept selectable as CLC_K2NN_MATRIX_PLAIN for A/B runs.
-template <bool STAMP, bool PIPE>
+template <bool STAMP, bool PIPE, bool GLOBAL = false>
 __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial,
                                                                       uint64_t* __restrict__ stamps)
 {
@@ -368,11 +368,21 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     const bool biased = job.bias_a != 0u;
     // biased shares: the query blocks of an XCD are INTERLEAVED over its workgroups (query block = within % nqx), so that every query
     // block has splits on all three wave slots (blocked, as below, the 19 splits of a query block sit on one slot)
-    const uint32_t bias_e = biased ? jobs.bias_tab[within < 96u ? within : 95u] : 0u;       // (a biased plan has at most 96 workgroups per XCD)
-    const uint32_t qblock = biased ? ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (bias_e & 0xFFu)
-                                   : ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within / job.splits);
-    const uint32_t split = biased ? (STAMP ? within / (job.qblocks >> 3) : 0u) : within % job.splits;   // (biased plans fold in-launch: no slab row)
-    if (qblock >= job.qblocks || (biased && within >= (job.qblocks >> 3) * job.splits)) return;
+    // ... when the query blocks come in whole eights.  Otherwise (bias_magic != 0) they are interleaved over ALL workgroup ids -- query block =
+    // id % qblocks, split = id / qblocks, nothing padded, a query block's splits spread over the XCDs: measured 0.8-1.5 us faster than the
+    // padded per-XCD order for 36 / 34 / 28 / 47 query blocks, 0.8-1.4 us slower than the per-XCD interleave for 40 / 32 / 24 (each L2 then
+    // pulls both sets whole)
+    // (a template parameter, not a run-time flag: with both orders in one instantiation the register allocator copied the sixteen C registers
+    // in front of every chain -- 32 v_mov per tile, +0.7 us on the 10k x 10k sweep)
+    constexpr bool global_order = GLOBAL;
+    const uint32_t bias_k = global_order ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__umulhi(blockIdx.x, job.bias_magic)) : 0u;   // (wave-uniform: keep it scalar)
+    const uint32_t bias_q = blockIdx.x - bias_k * job.qblocks;
+    const uint32_t bias_e = biased ? jobs.bias_tab[global_order ? (bias_q & 127u) : (within < 96u ? within : 95u)] : 0u;
+    const uint32_t qblock = global_order ? bias_q
+                          : (biased ? ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (bias_e & 0xFFu)
+                                    : ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within / job.splits));
+    const uint32_t split = global_order ? bias_k : (biased ? (STAMP ? within / (job.qblocks >> 3) : 0u) : within % job.splits);
+    if (qblock >= job.qblocks || (global_order && split >= job.splits) || (biased && !global_order && within >= (job.qblocks >> 3) * job.splits)) return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -420,9 +430,23 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     // this workgroup's train rows [s0, s1): t_per_split is a multiple of 32, so only the train set's last tile can be partial
     uint32_t s0 = min(split * job.t_per_split, job_nt);
     uint32_t s1 = min(s0 + job.t_per_split, job_nt);
-    if (biased) {
+    if (biased && !global_order) {
         s0 = min(((bias_e >> 8) & 0xFFFu) * 32u, job_nt);
         s1 = min(s0 + (bias_e >> 20) * 32u, job_nt);
+    }
+    if (global_order) {
+        // the query block's splits in id order: n0 on slot 0 with bias_a tiles each, n1 on slot 1 with bias_b, the rest on slot 2 with c
+        // (the first `extra` of them c + 1) tiles; the last split ends with the train set
+        const uint32_t n0 = bias_e & 0xFFu, n1 = (bias_e >> 8) & 0xFFu, c = (bias_e >> 16) & 0xFFu, extra = bias_e >> 24;
+        const uint32_t k0 = min(split, n0), k1 = min(split - k0, n1), k2 = split - k0 - k1;
+        const uint32_t begin = k0 * job.bias_a + k1 * job.bias_b + k2 * c + min(k2, extra);
+        const uint32_t size = split < n0 ? job.bias_a : (split < n0 + n1 ? job.bias_b : c + (k2 < extra ? 1u : 0u));
+        s0 = min(begin * 32u, job_nt);
+        s1 = split + 1u == job.splits ? job_nt : min(s0 + size * 32u, job_nt);
+    }
+    if (global_order) {
+        s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
+        s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s1);
     }
     const uint32_t ntiles = (s1 - s0 + 31u) >> 5;
     const int scale_a = 0x8B8B8B8B, scale_b = 0x7F7F7F7F;            // E8M0 block scales: 2^12 (trains), 1 (queries)
@@ -732,7 +756,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         splits = jb.nt ? (jb.nt + per - 1) / per : 1u;
         jb.splits = splits;
         jb.t_per_split = per;
-        jb.bias_a = jb.bias_b = 0u;
+        jb.bias_a = jb.bias_b = jb.bias_magic = 0u;
         jb.nq_pad = (jb.nq + 63u) & ~63u;
         jb.partial_off = (uint32_t)off;
         jb.atomic_merge = plan.atomic_merge ? 1u : 0u;
@@ -766,7 +790,32 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
                 const uint32_t used = n0 * a + n1 * b;
                 ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u;
             }
-            if (ok) { jb.bias_a = a; jb.bias_b = b; }
+            if (ok) { jb.bias_a = a; jb.bias_b = b; jb.bias_magic = 0u; }
+        }
+        // the same for query-block counts that are NOT whole eights: interleaved over all workgroup ids (K2nnJobDev.bias_magic), the split
+        // count taken anew (no per-XCD fit, nothing padded)
+        const uint32_t QB = jb.qblocks;
+        uint32_t sp = QB ? (uint32_t)target_blocks / QB : 0u;
+        if (sp > nt_tiles / 8u) sp = nt_tiles / 8u;                            // >= 8 tiles per split on average
+        if (jb.bias_a == 0u && (QB & 7u) != 0u && QB >= 24u && QB <= 128u && sp >= 6u && QB * sp > 512u && QB * sp <= 768u && !jb.cnt_q && !jb.cnt_t &&
+            target_blocks == 768) {
+            const uint32_t den = sp * 256u;
+            const uint32_t a = bias_a < 64 ? (uint32_t)bias_a : (nt_tiles * (uint32_t)bias_a + den / 2u) / den;
+            const uint32_t b = bias_b < 64 ? (uint32_t)bias_b : (nt_tiles * (uint32_t)bias_b + den / 2u) / den;
+            bool ok = a >= 1u && b >= 1u && a <= 255u && b <= 255u;
+            for (uint32_t q = 0; ok && q < QB; ++q) {
+                const uint32_t n0 = std::min((256u - q + QB - 1u) / QB, sp);
+                const uint32_t n1 = std::min((512u - q + QB - 1u) / QB, sp) - n0;
+                const uint32_t n2 = sp - n0 - n1;
+                const uint32_t used = n0 * a + n1 * b;
+                ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u;
+            }
+            if (ok) {
+                jb.bias_a = a; jb.bias_b = b;
+                jb.bias_magic = (uint32_t)((0x100000000ull + QB - 1u) / QB);
+                jb.splits = sp;
+                jb.t_per_split = ((nt_tiles + sp - 1u) / sp) * 32u;             // (the equal share: reporting only)
+            }
         }
     }
     plan.partial_elems = off;
@@ -791,6 +840,22 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
         }
         for (int j = cnt; j < kK2nnJobsPerLaunch; ++j) list.j[j] = K2nnJobDev{};
         for (uint32_t& e : list.bias_tab) e = 0u;
+        if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u && formulation != K2NN_POPCOUNT) {
+            // interleaved over all ids: per query block q its split k is workgroup k QB + q, on wave slot (k QB + q) / 256 -- n0 splits on slot 0
+            // (bits 0..7), n1 on slot 1 (8..15), tiles of a slot-2 split (16..23), how many of them take one more (24..31)
+            const K2nnJobDev& jb = list.j[0];
+            const uint32_t QB = jb.qblocks, nt_tiles = (jb.nt + 31u) >> 5;
+            for (uint32_t q = 0; q < QB && q < 128u; ++q) {
+                const uint32_t n0 = std::min((256u - q + QB - 1u) / QB, jb.splits);
+                const uint32_t n1 = std::min((512u - q + QB - 1u) / QB, jb.splits) - n0;
+                const uint32_t n2 = jb.splits - n0 - n1;
+                const uint32_t used = n0 * jb.bias_a + n1 * jb.bias_b;
+                const uint32_t rest = nt_tiles > used ? nt_tiles - used : 0u;
+                const uint32_t c = n2 ? rest / n2 : 0u, extra = n2 ? rest - c * n2 : 0u;
+                list.bias_tab[q] = n0 | (n1 << 8) | (std::min(c, 255u) << 16) | (std::min(extra, 255u) << 24);
+            }
+            grid_x = QB * jb.splits;                                          // nothing padded
+        } else
         if (cnt == 1 && list.j[0].bias_a != 0u && formulation != K2NN_POPCOUNT) {
             // workgroup w of an XCD: query block w % nqx (the query blocks of an XCD interleaved, so that each has splits on all three wave
             // slots), its split k = w / nqx sits on slot w / 32: n0 splits of bias_a tiles, n1 of bias_b, the n2 slot-2 splits share the
@@ -817,6 +882,16 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, true, stream);
             if (formulation == K2NN_POPCOUNT)
                 hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
+            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u && d_stamps && formulation == K2NN_MATRIX_PLAIN)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
+            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u && d_stamps)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
+            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u && formulation == K2NN_MATRIX_PLAIN)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                                   (uint64_t*)nullptr);
+            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                                   (uint64_t*)nullptr);
             else if (d_stamps && formulation == K2NN_MATRIX_PLAIN)
                 hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, false>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
             else if (d_stamps)

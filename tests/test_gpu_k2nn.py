@@ -335,12 +335,14 @@ def test_descriptor_cache_hits_only_on_the_published_block(oracle):
     det.close(); mat.close()
 
 
-@pytest.mark.parametrize("nq,nt", [(10000, 10000), (10000, 9985), (10240, 12000), (9985, 7211), (8192, 20000), (6144, 16001), (8192, 8192), (14336, 5000)])
+@pytest.mark.parametrize("nq,nt", [(10000, 10000), (10000, 9985), (10240, 12000), (9985, 7211), (8192, 20000), (6144, 16001), (8192, 8192), (14336, 5000),
+                                   (9000, 9000), (8508, 9390), (7000, 10017), (12000, 12000), (6400, 9000)])
 def test_one_round_plans_with_unequal_shares_by_wave_slot(oracle, k2nn_formulation, nq, nt):
     """Round 4: a single pair whose sweep is ONE round of three workgroups per CU gives the workgroups on wave slot 0 / 1 / 2 of their SIMDs
     unequal train shares (k2nn.hip: the matrix pipe serves a lower slot first) and interleaves the query blocks of an XCD over its
-    workgroups.  Shapes that take that plan (whole eights of query blocks, 65..96 workgroups per XCD) with ragged train counts, ties across
-    the unequal split boundaries included: same indices and distances as the oracle, and as a context with equal shares."""
+    workgroups.  Shapes that take that plan -- whole eights of query blocks with 65..96 workgroups per XCD, and other query-block counts,
+    which are interleaved over all workgroup ids instead -- with ragged train counts, ties across the unequal split boundaries included:
+    same indices and distances as the oracle, and as a context with equal shares."""
     import os
     from coloc_amd import Context
     Q, T = synth.planted_descriptors(nq, nt, seed=1234 + nq + nt)
@@ -364,7 +366,8 @@ def test_one_round_plans_with_unequal_shares_by_wave_slot(oracle, k2nn_formulati
             ctx.set_k2nn_formulation(k2nn_formulation)
             plan = ctx.k2nn_plan_query(nq, nt)
             # the matrix formulations take the unequal-share plan for these shapes (unless switched off), the popcount sweep never does
-            assert (plan["bias_a_tiles"] > 0) == (k2nn_formulation != "popcount" and bias != "0,0"), plan
+            if bias in ("326,249", "0,0"):                # (a lopsided setting may not fit a shape: then the plan falls back to equal shares)
+                assert (plan["bias_a_tiles"] > 0) == (k2nn_formulation != "popcount" and bias != "0,0"), plan
             if bias == "22,9" and plan["bias_a_tiles"]:
                 assert (plan["bias_a_tiles"], plan["bias_b_tiles"]) == (22, 9)
             for _ in range(2):                          # twice: the rows and counters re-arm
