@@ -6,15 +6,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, synth
 from coloc_amd import Context
-ctx = Context(device=0, width=640, height=480, maxkp=10000, detector=False)
-Q, T = synth.planted_descriptors(10000, 10000, seed=3000)
+ctx = Context(device=0, width=640, height=480, maxkp=70000, detector=False)
+NQ, NT = (int(v) for v in os.environ.get("SIZE", "10000x10000").split("x"))
+Q, T = synth.planted_descriptors(NQ, NT, seed=3000)
 dq, dt = torch.from_numpy(Q).cuda(), torch.from_numpy(T).cuda()
-dm = torch.empty(10000, dtype=torch.int32, device="cuda")
+dm = torch.empty(NQ, dtype=torch.int32, device="cuda")
 for _ in range(200):
-    ctx.match_2nn_dev(dq.data_ptr(), 10000, dt.data_ptr(), 10000, 40, dm.data_ptr())
+    ctx.match_2nn_dev(dq.data_ptr(), NQ, dt.data_ptr(), NT, 40, dm.data_ptr())
 path = "/tmp/k2nn_stamps.bin"
 os.environ["CLC_K2NN_STAMP_DUMP"] = path
-clk = ctx.k2nn_clock_check(dq.data_ptr(), 10000, dt.data_ptr(), 10000, dm.data_ptr())
+clk = ctx.k2nn_clock_check(dq.data_ptr(), NQ, dt.data_ptr(), NT, dm.data_ptr())
+print("plan", ctx.k2nn_plan_query(NQ, NT))
 h = np.fromfile(path, dtype=np.uint64).reshape(-1, 8)
 keep = h[:, 4] > 0
 ids = np.nonzero(keep)[0]
