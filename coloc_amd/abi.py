@@ -49,6 +49,9 @@ class PoseJob(C.Structure):
                 ("n_inliers", C.c_int), ("iterations", C.c_int), ("status", C.c_int), ("error_max", C.c_double), ("rmse", C.c_double)]
 
 
+ABI_VERSION = 2          # CLC_ABI_VERSION of include/coloc_hip.h
+DESC_CACHE_OFF, DESC_CACHE_VERIFY, DESC_CACHE_TRUST = 0, 1, 2
+
 EXPORTS = [
     "clc_abi_version", "clc_status_string", "clc_ctx_create", "clc_ctx_destroy", "clc_last_error_string",
     "clc_sync", "clc_stream", "clc_pyramid_build", "clc_pyramid_build_dev", "clc_pyramid_level",
@@ -56,7 +59,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
@@ -105,6 +108,11 @@ def load_library():
                            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
     _share_torch_hip_runtime()
     lib = C.CDLL(path)
+    # the version BEFORE any symbol an older library does not export is resolved (include/coloc_hip.h CLC_ABI_VERSION)
+    got = lib.clc_abi_version() if hasattr(lib, "clc_abi_version") else 0
+    if got != ABI_VERSION:
+        raise CLCError(-1, "%s reports ABI version %d, this binding needs %d: rebuild it (python -c 'import __graft_entry__ as g; g.build()')"
+                       % (path, got, ABI_VERSION))
     lib.clc_status_string.restype = C.c_char_p
     lib.clc_last_error_string.restype = C.c_char_p
     lib.clc_last_error_string.argtypes = [C.c_void_p]
@@ -125,6 +133,7 @@ def load_library():
     lib.clc_desc_cache_publish.argtypes = [vp, vp, vp, ci]
     lib.clc_desc_cache_clear.argtypes = []
     lib.clc_desc_cache_stats.argtypes = [vp, vp]
+    lib.clc_desc_cache_mode.argtypes = [vp, ci]
     lib.clc_pnp_localize_ac_batch.argtypes = [vp, vp, ci]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
@@ -457,6 +466,10 @@ class Context:
         cnt = (C.c_void_p * n)(*d_counts)
         out = (C.c_void_p * n)(*d_desc) if d_desc is not None else None
         self._chk(self.lib.clc_detect_batch_dev(self.h, n, imgs, width, height, pitch, kps, cnt, out, stream))
+
+    def desc_cache_mode(self, mode):
+        """clc_desc_cache_mode: "off" | "verify" (whole-block fold, default) | "trust" (address + count + 18 sampled rows)."""
+        self._chk(self.lib.clc_desc_cache_mode(self.h, {"off": DESC_CACHE_OFF, "verify": DESC_CACHE_VERIFY, "trust": DESC_CACHE_TRUST}[mode]))
 
     def desc_cache_publish(self, h_desc, d_src=None):
         """The rows of numpy block h_desc (n x 64) are on this device at d_src (None: the context's own descriptor array, what

@@ -120,6 +120,7 @@ struct clc_ctx {
     int bias_a = 326, bias_b = 249;  // matrix sweep, one-round single-job plans: train share of a workgroup on wave slot 0 / 1 in 1/256 of the
                                      // equal share (k2nn.hip; measured optimum 21 : 16 : 12-13 tiles at 10k x 10k); CLC_K2NN_BIAS=a,b, 0,0 = equal shares
     bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
+    int cache_mode = CLC_DESC_CACHE_VERIFY;   // how this context's host-pointer match entry points treat published blocks (clc_desc_cache_mode)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
     size_t pairs_cap = 0;
@@ -208,6 +209,15 @@ int ensure_pnp(clc_ctx* ctx, size_t doubles)
     return CLC_OK;
 }
 
+int cache_mode_default()
+{
+    const char* v = getenv("CLC_DESC_CACHE");
+    if (!v || !v[0]) return CLC_DESC_CACHE_VERIFY;
+    if (v[0] == '0' || v[0] == 'o' || v[0] == 'O') return CLC_DESC_CACHE_OFF;
+    if (v[0] == 't' || v[0] == 'T' || v[0] == '2') return CLC_DESC_CACHE_TRUST;
+    return CLC_DESC_CACHE_VERIFY;
+}
+
 // matrix: 3 workgroups of 4 waves per CU (152 VGPRs); popcount: 10 rounds of 8-wave workgroups (measured optima)
 int default_target_blocks(int formulation) { return formulation == K2NN_POPCOUNT ? 2560 : 768; }
 
@@ -279,6 +289,7 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
         if (v > 0) ctx->target_blocks = v;
     }
     if (const char* e = getenv("CLC_K2NN_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
+    ctx->cache_mode = cache_mode_default();
     if (const char* e = getenv("CLC_K2NN_BIAS")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a < 1024 && b < 1024) { ctx->bias_a = a; ctx->bias_b = b; }
@@ -840,15 +851,26 @@ int clc_match_jobs_counted_dev(clc_ctx* ctx, const void* d_desc_base, const clc_
 // The reference's host flow hands descriptors from the detector to the matcher through host memory (FeatureMap regions:
 // GPUDetector.hpp:181 -> GPUMatcher.hpp:188-196), and GPUMatcher uploads them again for every call.  Here the detector can PUBLISH
 // the device copy of a block it has just written to a host address (clc_desc_cache_publish); a host-pointer match entry point that
-// is later given that address finds the rows on the device and skips the upload.  An entry is trusted only while the host block
-// still starts and ends with the rows it was published with (first and last 64 bytes compared, not hashed) and has the same count;
-// anything else -- another address, a changed block -- is uploaded as before.  Process-wide, per device, mutex-protected; entries
-// in use by a running call are never evicted.  CLC_DESC_CACHE=0 switches it off.
+// is later given that address finds the rows on the device and skips the upload.  How far a lookup trusts an entry is a property of
+// the context that looks it up (clc_desc_cache_mode):
+//   VERIFY (default): address and count match AND a 64-bit position-keyed fold of ALL rows of the host block equals the one taken at
+//           publish time -- a block rewritten anywhere, or an allocation reused for other rows, can only miss (round 4 compared the
+//           first and last row only: a block edited in the middle was answered with the stale device rows);
+//   TRUST:  address, count and 18 sampled rows (first, last, 16 spread over the block) -- for a host that OWNS its blocks and states
+//           that it does not rewrite a published block in place (HIPDetector / HIPMatcher over FeatureMap regions, which only the
+//           detector writes); no pass over the block, the lookup costs a microsecond;
+//   OFF:    every block is uploaded, as the reference does.
+// Process-wide, per device, mutex-protected; entries in use by a running call are never evicted.  CLC_DESC_CACHE=0|verify|trust in the
+// environment sets the mode new contexts start with.
+enum { kCacheSamples = 16 };
 struct DescCacheEntry {
     int device = -1;
     const void* h = nullptr;
     int n = 0;
     uint8_t first[CLC_DESC_BYTES], last[CLC_DESC_BYTES];
+    uint8_t sample[kCacheSamples][CLC_DESC_BYTES];      // rows (i + 1) * n / (kCacheSamples + 1)
+    uint64_t fold = 0;       // desc_block_fold of the n published rows
+    bool has_fold = false;   // (blocks published by a TRUST context carry none: only TRUST lookups can hit them)
     uint8_t* d = nullptr;
     size_t cap = 0;          // rows allocated
     uint64_t stamp = 0;
@@ -859,23 +881,65 @@ struct DescCache {
     std::vector<DescCacheEntry> e;
     uint64_t clock = 0;
     uint64_t hits = 0, misses = 0;      // lookups answered from the cache / uploaded
-    bool enabled = true;
-    DescCache() { const char* v = getenv("CLC_DESC_CACHE"); enabled = !(v && v[0] == '0'); }
 };
 static constexpr size_t kDescCacheEntries = 32;
 static DescCache& desc_cache() { static DescCache c; return c; }
 
-// device rows of host block (h, n) if published and still unchanged at both ends; the entry is pinned until cache_release
-static const uint8_t* cache_acquire(const int device, const void* h, const int n, DescCacheEntry** held)
+// 64-bit fold of n descriptor rows: every 16 bytes are keyed with their position (the key steps per row, the four pairs of a row take
+// different constants), multiplied 64 x 64 -> 128 and folded; the row terms are summed.  One multiply per 16 bytes: a 640 KB block
+// takes what reading it takes.  Change detection, not cryptography.
+static inline uint64_t fold_mul(const uint64_t a, const uint64_t b)
+{
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    return (uint64_t)p ^ (uint64_t)(p >> 64);
+}
+static uint64_t desc_block_fold(const void* h, const size_t n)
+{
+    const uint8_t* p = (const uint8_t*)h;
+    uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, k = 0x9E3779B97F4A7C15ull;
+    for (size_t r = 0; r < n; ++r, p += CLC_DESC_BYTES, k += 0xD1B54A32D192ED03ull) {
+        uint64_t w[8];
+        memcpy(w, p, sizeof w);                          // (host blocks carry no alignment promise)
+        h0 += fold_mul(w[0] ^ k, w[1] ^ 0x8BB84B93962EACC9ull);
+        h1 += fold_mul(w[2] ^ (k + 0x2D358DCCAA6C78A5ull), w[3] ^ 0x4B33A62ED433D4A3ull);
+        h2 += fold_mul(w[4] ^ (k + 0x4D5A2DA51DE1AA47ull), w[5] ^ 0xA0761D6478BD642Full);
+        h3 += fold_mul(w[6] ^ (k + 0xE7037ED1A0B428DBull), w[7] ^ 0x589965CC75374CC3ull);
+    }
+    return (h0 ^ (h1 << 1 | h1 >> 63)) + (h2 ^ (h3 << 7 | h3 >> 57)) + (uint64_t)n;
+}
+static inline const uint8_t* cache_sample_row(const void* h, const int n, const int i)
+{
+    return (const uint8_t*)h + (size_t)((uint64_t)(i + 1) * (uint64_t)n / (kCacheSamples + 1)) * CLC_DESC_BYTES;
+}
+
+// device rows of host block (h, n) if published and, by the rule of `mode`, still the published rows; the entry is pinned until cache_release
+static const uint8_t* cache_acquire(const int mode, const int device, const void* h, const int n, DescCacheEntry** held)
 {
     *held = nullptr;
     DescCache& c = desc_cache();
-    if (!c.enabled || !h || n <= 0) return nullptr;
-    std::lock_guard<std::mutex> lk(c.mu);
+    if (mode == CLC_DESC_CACHE_OFF || !h || n <= 0) return nullptr;
+    uint64_t fold = 0;
+    bool folded = false;
+    std::unique_lock<std::mutex> lk(c.mu);
     for (DescCacheEntry& en : c.e) {
         if (en.device != device || en.h != h || en.n != n || !en.d) continue;
         const uint8_t* hb = (const uint8_t*)h;
-        if (memcmp(hb, en.first, CLC_DESC_BYTES) != 0 || memcmp(hb + (size_t)(n - 1) * CLC_DESC_BYTES, en.last, CLC_DESC_BYTES) != 0) {
+        bool same = memcmp(hb, en.first, CLC_DESC_BYTES) == 0 && memcmp(hb + (size_t)(n - 1) * CLC_DESC_BYTES, en.last, CLC_DESC_BYTES) == 0;
+        for (int i = 0; same && i < kCacheSamples; ++i) same = memcmp(cache_sample_row(h, n, i), en.sample[i], CLC_DESC_BYTES) == 0;
+        if (same && mode == CLC_DESC_CACHE_VERIFY) {
+            if (!en.has_fold) continue;                  // published without a fold: not for a verifying context
+            if (!folded) {                               // the pass over the block, outside the lock (an entry cannot move; its fields
+                ++en.busy;                               // are re-read under the lock below)
+                lk.unlock();
+                fold = desc_block_fold(h, (size_t)n);
+                folded = true;
+                lk.lock();
+                --en.busy;
+                if (en.device != device || en.h != h || en.n != n || !en.d || !en.has_fold) continue;
+            }
+            same = fold == en.fold;
+        }
+        if (!same) {
             if (en.busy == 0) en.h = nullptr;            // the host block has been rewritten: forget the entry
             continue;                                    // (a newer entry for the same address may follow)
         }
@@ -922,7 +986,7 @@ static int match_host(clc_ctx* ctx, const void* h_q, int nq, const uint8_t* d_tr
                       int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
 {
     DescCacheEntry* held = nullptr;
-    const uint8_t* d_query = cache_acquire(ctx->device, h_q, nq, &held);
+    const uint8_t* d_query = cache_acquire(ctx->cache_mode, ctx->device, h_q, nq, &held);
     if (!d_query) {
         const hipError_t e = hipMemcpyAsync(ctx->d_q, h_q, (size_t)nq * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "match: query upload", e);
@@ -941,8 +1005,12 @@ int clc_desc_cache_publish(clc_ctx* ctx, const void* d_src, const void* h_desc, 
         d_src = ctx->d_desc;
     }
     DescCache& c = desc_cache();
-    if (!c.enabled || n == 0) return CLC_OK;
+    if (ctx->cache_mode == CLC_DESC_CACHE_OFF || n == 0) return CLC_OK;
     CLC_HIP(ctx, hipSetDevice(ctx->device));
+    // a verifying context folds the block it publishes (the host has just written it: the pass runs out of its caches); a trusting
+    // one does not, and its entries can then only be hit by trusting lookups
+    const bool with_fold = ctx->cache_mode == CLC_DESC_CACHE_VERIFY;
+    const uint64_t fold = with_fold ? desc_block_fold(h_desc, (size_t)n) : 0u;
     DescCacheEntry* slot = nullptr;
     {
         std::lock_guard<std::mutex> lk(c.mu);
@@ -977,9 +1045,19 @@ int clc_desc_cache_publish(clc_ctx* ctx, const void* d_src, const void* h_desc, 
             slot->device = ctx->device; slot->h = h_desc; slot->n = n; slot->stamp = ++c.clock;
             memcpy(slot->first, h_desc, CLC_DESC_BYTES);
             memcpy(slot->last, (const uint8_t*)h_desc + (size_t)(n - 1) * CLC_DESC_BYTES, CLC_DESC_BYTES);
+            for (int i = 0; i < kCacheSamples; ++i) memcpy(slot->sample[i], cache_sample_row(h_desc, n, i), CLC_DESC_BYTES);
+            slot->fold = fold; slot->has_fold = with_fold;
         }
     }
     if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "desc_cache_publish", e);
+    return CLC_OK;
+}
+
+int clc_desc_cache_mode(clc_ctx* ctx, int mode)
+{
+    if (!ctx || (mode != CLC_DESC_CACHE_OFF && mode != CLC_DESC_CACHE_VERIFY && mode != CLC_DESC_CACHE_TRUST))
+        return fail(ctx, CLC_ERR_BAD_ARG, "desc_cache_mode: unknown mode");
+    ctx->cache_mode = mode;
     return CLC_OK;
 }
 
@@ -1015,7 +1093,7 @@ int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt
     if (nq == 0) return CLC_OK;
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     DescCacheEntry* held = nullptr;
-    const uint8_t* d_train = nt > 0 ? cache_acquire(ctx->device, h_t, nt, &held) : nullptr;
+    const uint8_t* d_train = nt > 0 ? cache_acquire(ctx->cache_mode, ctx->device, h_t, nt, &held) : nullptr;
     if (!d_train) {
         if (nt > 0) {
             const hipError_t e = hipMemcpyAsync(ctx->d_t, h_t, (size_t)nt * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream);
@@ -1062,7 +1140,7 @@ int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, 
     struct Release { std::vector<DescCacheEntry*>& h; ~Release() { for (DescCacheEntry* e : h) cache_release(e); } } release{ held };
     for (int c = 0; c < ncams; ++c) {
         if (counts[c] <= 0) continue;
-        cam_dev[(size_t)c] = cache_acquire(ctx->device, h_desc[c], counts[c], &held[(size_t)c]);
+        cam_dev[(size_t)c] = cache_acquire(ctx->cache_mode, ctx->device, h_desc[c], counts[c], &held[(size_t)c]);
         if (!cam_dev[(size_t)c]) {
             CLC_HIP(ctx, hipMemcpyAsync(ctx->d_pairs + cam_off[c] * CLC_DESC_BYTES, h_desc[c], (size_t)counts[c] * CLC_DESC_BYTES,
                                         hipMemcpyHostToDevice, ctx->stream));

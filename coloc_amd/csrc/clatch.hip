@@ -40,6 +40,7 @@ static constexpr int kRow0 = LATCH_ROW0, kCol0 = LATCH_COL0;   // first window r
 static constexpr int kStride = LATCH_STRIDE;                   // bytes per stored window row
 static constexpr int kWinDwords = LATCH_NROWS * LATCH_STRIDE / 4;
 static constexpr int kWaveLds = LATCH_WAVE_BYTES;
+static_assert(kWaveLds <= 0x8000, "bit 15 of a slot record's first LDS address carries the role-exchange flag (make_slot_table)");
 static constexpr int kCopyBase[4] = LATCH_COPY_BASES;
 static constexpr int kTile0 = 5;                               // learned patches cover rows/cols 5..60
 static constexpr int kTiles = 7;

@@ -116,8 +116,8 @@ static constexpr int kK2nnJobsPerLaunch = 16;
 struct K2nnJobList {
     K2nnJobDev j[kK2nnJobsPerLaunch];
     // job 0 with unequal shares by wave slot (bias_a != 0), filled by launch_k2nn (no integer division in the kernel: ~30 vector
-    // instructions each).  bias_magic == 0: what workgroup w = id >> 3 of an XCD takes -- query block of the XCD (bits 0..7), first train
-    // tile (8..19), train tiles (20..31); bias_magic != 0: per query block, see launch_k2nn
+    // instructions each).  bias_magic == 0: what workgroup w = id >> 3 of an XCD takes -- query block of the XCD (bits 0..4), first train
+    // tile (5..22), train tiles (23..31: k2nn.hip kBias*); bias_magic != 0: per query block, see launch_k2nn
     uint32_t bias_tab[128];
 };
 struct K2nnPlan {

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(256) void detect_emit_kernel(const DetectArgs a, co
                                                           const uint32_t* __restrict__ tcount_base)
 {
     __shared__ uint32_t s_part[4];
-    __shared__ uint32_t s_list[256 * 32];           // x | row << 16 of the keypoints of up to 256 mask words
+    constexpr uint32_t kListCap = 256u * 32u;
+    __shared__ uint32_t s_list[kListCap];           // x | row << 16 of the keypoints of up to 256 mask words
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t cam = blockIdx.y, band = blockIdx.x;
     const int lv = level_of(a.band_begin, a.pd.levels, band);
@@ -381,21 +382,26 @@ __global__ __launch_bounds__(256) void detect_emit_kernel(const DetectArgs a, co
         __syncthreads();
         uint32_t before = 0;
         for (uint32_t w = 0; w < wave; ++w) before += s_part[w];
-        const uint32_t total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+        // (strict 3 x 3 suppression leaves at most 32 keypoints per 64-bit word, so a mask written by detect_tile_kernel fills at most the
+        // list; the bounds below only keep masks that did NOT come from it -- a timing ablation in round 4 -- from writing past the list
+        // or reading outside the level: this kernel trusts nothing about its producer that it can check for free)
+        const uint32_t total = min(s_part[0] + s_part[1] + s_part[2] + s_part[3], kListCap);
         // the keypoints of these 256 words, in order, into one list: afterwards EVERY thread takes one keypoint (a thread that walked
         // the bits of its own word paid one load latency per keypoint of that word; strict 3 x 3 suppression leaves at most 32 per word)
         uint32_t k = before + inc - c;
         while (m != 0ull) {
             const uint32_t b = (uint32_t)__builtin_ctzll(m);
             m &= m - 1ull;
-            s_list[k++] = (tx * kTileW + b) | (r << 16);
+            if (k < kListCap) s_list[k] = (tx * kTileW + b) | (r << 16);
+            ++k;
         }
         __syncthreads();
         for (uint32_t q = tid; q < total; q += 256u) {
             const uint32_t slot = carry + q;
             if (slot >= a.maxkp) break;
             const uint32_t e = s_list[q];
-            const int x = (int)(e & 0xFFFFu), y = (int)(ty * kTileH + (e >> 16));
+            // keypoints lie in [3, w - 4] x [3, h - 4] (KFAST.h:431,455): the clamp is the identity on them
+            const int x = min(max((int)(e & 0xFFFFu), 3), (int)L.w - 4), y = min(max((int)(ty * kTileH + (e >> 16)), 3), (int)L.h - 4);
             int xs = 0, ys = 0;
 #pragma unroll
             for (int rr = -3; rr <= 3; ++rr) {

@@ -74,6 +74,14 @@ static constexpr uint32_t kMxIdxBits = 13;               // train index inside a
 static constexpr uint32_t kMxMaxSplit = 1u << kMxIdxBits;
 static constexpr uint32_t kMxMagic = 0x4B000000u;        // float bits of 2^23
 static constexpr uint32_t kMxInf = 0x7F800000u;          // "no key yet": above every accumulator value
+// per-XCD unequal-share table entry (K2nnJobList.bias_tab, bias_magic == 0): query block of the XCD in bits 0..4 (at most 32 per XCD),
+// first train tile in bits 5..22 (2^18 tiles = 2^23 rows: above the 2^22 rows of the atomic fold), train tiles in bits 23..31 (a
+// split holds at most 256 tiles, the 13-bit index inside a split).  k2nn_plan refuses the plan when a field would not hold its value.
+static constexpr uint32_t kBiasQlBits = 5, kBiasQlMask = (1u << kBiasQlBits) - 1u;
+static constexpr uint32_t kBiasBeginShift = kBiasQlBits, kBiasBeginBits = 18, kBiasBeginMask = (1u << kBiasBeginBits) - 1u;
+static constexpr uint32_t kBiasSizeShift = kBiasBeginShift + kBiasBeginBits, kBiasSizeMax = (1u << (32u - kBiasSizeShift)) - 1u;
+static_assert(kBiasSizeMax >= kMxMaxSplit / 32u, "a split of 256 tiles must fit the size field");
+static_assert(((kIdxMask + 1u) >> 5) <= kBiasBeginMask + 1u, "every tile of an atomically folded train set must fit the begin field");
 
 int k2nn_queries_per_block(int formulation) { return formulation == K2NN_POPCOUNT ? kQPerBlock : kMxQPerBlock; }
 
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     const uint32_t bias_q = blockIdx.x - bias_k * job.qblocks;
     const uint32_t bias_e = biased ? jobs.bias_tab[global_order ? (bias_q & 127u) : (within < 96u ? within : 95u)] : 0u;
     const uint32_t qblock = global_order ? bias_q
-                          : (biased ? ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (bias_e & 0xFFu)
+                          : (biased ? ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (bias_e & kBiasQlMask)
                                     : ((blockIdx.x + 8u - job.xcd_rot) & 7u) + 8u * (within / job.splits));
     const uint32_t split = global_order ? bias_k : (biased ? (STAMP ? within / (job.qblocks >> 3) : 0u) : within % job.splits);
     if (qblock >= job.qblocks || (global_order && split >= job.splits) || (biased && !global_order && within >= (job.qblocks >> 3) * job.splits)) return;
@@ -431,8 +439,8 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     uint32_t s0 = min(split * job.t_per_split, job_nt);
     uint32_t s1 = min(s0 + job.t_per_split, job_nt);
     if (biased && !global_order) {
-        s0 = min(((bias_e >> 8) & 0xFFFu) * 32u, job_nt);
-        s1 = min(s0 + (bias_e >> 20) * 32u, job_nt);
+        s0 = min(((bias_e >> kBiasBeginShift) & kBiasBeginMask) * 32u, job_nt);
+        s1 = min(s0 + (bias_e >> kBiasSizeShift) * 32u, job_nt);
     }
     if (global_order) {
         // the query block's splits in id order: n0 on slot 0 with bias_a tiles each, n1 on slot 1 with bias_b, the rest on slot 2 with c
@@ -782,13 +790,15 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
             // every query block's split sizes as the kernel derives them: all within the 13-bit index field (256 tiles), the slot-0 and
             // slot-1 splits inside the train set
             const uint32_t nqx = jb.qblocks >> 3;
-            bool ok = a >= 1u && b >= 1u && a <= 255u && b <= 255u;
+            // ... and everything the 32-bit table entry carries inside its field (a 12-bit begin field silently clamped train
+            // sets beyond 4096 tiles), no slot-2 split below the two tiles the equal plan guarantees (min_per)
+            bool ok = a >= 1u && b >= 1u && a <= 255u && b <= 255u && nqx <= kBiasQlMask + 1u && nt_tiles <= kBiasBeginMask;
             for (uint32_t ql = 0; ok && ql < nqx; ++ql) {
                 const uint32_t n0 = std::min((32u - ql + nqx - 1u) / nqx, jb.splits);
                 const uint32_t n1 = std::min((64u - ql + nqx - 1u) / nqx, jb.splits) - n0;
                 const uint32_t n2 = jb.splits - n0 - n1;
                 const uint32_t used = n0 * a + n1 * b;
-                ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u;
+                ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u && (nt_tiles - used) / n2 >= 2u;
             }
             if (ok) { jb.bias_a = a; jb.bias_b = b; jb.bias_magic = 0u; }
         }
@@ -808,7 +818,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
                 const uint32_t n1 = std::min((512u - q + QB - 1u) / QB, sp) - n0;
                 const uint32_t n2 = sp - n0 - n1;
                 const uint32_t used = n0 * a + n1 * b;
-                ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u;
+                ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u && (nt_tiles - used) / n2 >= 2u;
             }
             if (ok) {
                 jb.bias_a = a; jb.bias_b = b;
@@ -874,7 +884,8 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
                 const uint32_t begin = k0 * jb.bias_a + k1 * jb.bias_b + k2 * c + std::min(k2, extra);
                 uint32_t size = k < n0 ? jb.bias_a : (k < n0 + n1 ? jb.bias_b : c + (k2 < extra ? 1u : 0u));
                 if (k + 1u == jb.splits) size = nt_tiles > begin ? nt_tiles - begin : 0u;      // the last split takes what is left
-                list.bias_tab[w] = ql | (std::min(begin, 4095u) << 8) | (std::min(size, 4095u) << 20);
+                // (k2nn_plan has checked that every field holds its value; the clamps only keep a corrupted job record from aliasing)
+                list.bias_tab[w] = (ql & kBiasQlMask) | (std::min(begin, kBiasBeginMask) << kBiasBeginShift) | (std::min(size, kBiasSizeMax) << kBiasSizeShift);
             }
         }
         if (max_nq == 0) continue;

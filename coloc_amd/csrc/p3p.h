@@ -27,12 +27,16 @@
 #endif
 
 // The solver is one long dependent chain per lane (a P3P launch is 128 x 4 lanes: latency, not throughput), so it is written
-// for few instructions: fused multiply-adds (the library is otherwise built with -ffp-contract=off for the kernels whose
-// results are compared bit for bit with the oracle; nothing here is -- the poses are checked against an independent solver to a
-// tolerance, and the a-contrario oracle takes its minimal solutions from this very code), and reciprocals by v_rcp_f64 + two
-// Newton steps (1 ulp) instead of the IEEE division sequence (57 divisions per solve, ~10 instructions each).
+// for few instructions: fused multiply-adds and reciprocals by v_rcp_f64 + two Newton steps (1 ulp) instead of the IEEE division
+// sequence (57 divisions per solve, ~10 instructions each).
+// Round 5: every fusion is SPELLED (fma()) and the file is compiled with contraction OFF.  Rounds 2-4 built it under
+// `#pragma clang fp contract(fast)`, which lets the compiler fuse a multiply into an add wherever it likes -- per inlining context:
+// p3p_sample_root is force-inlined into p3p_kernel (whose poses the tests hand to the a-contrario oracle) and into acr_round_kernel
+// (which solves its own samples), and the "winning pose == the oracle's, bit for bit" tests held only while both contexts happened
+// to get the same choices.  With contraction off an expression is exactly the IEEE operations written here, in
+// this order, wherever it is inlined: the two kernels agree by construction, not by coincidence.
 #if defined(__clang__)
-#pragma clang fp contract(fast)
+#pragma clang fp contract(off)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double p3p_rcp(const double x)
@@ -50,23 +54,24 @@ P3P_HD double p3p_rcp(const double x) { return 1.0 / x; }
 P3P_HD int p3p_solve_cubic(double a, double b, double c, double* x)
 {
     const double a3 = a * (1.0 / 3.0);
-    const double p = b - a * a3;
-    const double q = 2.0 * a3 * a3 * a3 - a3 * b + c;
-    const double disc = 0.25 * q * q + p * p * p * (1.0 / 27.0);
+    const double p = fma(-a, a3, b);
+    const double q = fma(2.0 * a3 * a3, a3, fma(-a3, b, c));
+    const double p3 = p * p * p * (1.0 / 27.0);
+    const double disc = fma(0.25 * q, q, p3);
     if (disc > 0.0) {
         const double s = sqrt(disc);
         const double u = cbrt(-0.5 * q + s), v = cbrt(-0.5 * q - s);
         x[0] = u + v - a3;
         return 1;
     }
-    const double r = sqrt(-p * p * p * (1.0 / 27.0));
+    const double r = sqrt(-p3);
     double cosphi = r > 0.0 ? -0.5 * q * p3p_rcp(r) : 0.0;
     cosphi = cosphi > 1.0 ? 1.0 : (cosphi < -1.0 ? -1.0 : cosphi);
     const double phi = acos(cosphi);
     const double m = 2.0 * sqrt(-p * (1.0 / 3.0));
-    x[0] = m * cos(phi * (1.0 / 3.0)) - a3;
-    x[1] = m * cos((phi + 2.0 * M_PI) * (1.0 / 3.0)) - a3;
-    x[2] = m * cos((phi + 4.0 * M_PI) * (1.0 / 3.0)) - a3;
+    x[0] = fma(m, cos(phi * (1.0 / 3.0)), -a3);
+    x[1] = fma(m, cos((phi + 2.0 * M_PI) * (1.0 / 3.0)), -a3);
+    x[2] = fma(m, cos((phi + 4.0 * M_PI) * (1.0 / 3.0)), -a3);
     return 3;
 }
 
@@ -80,14 +85,14 @@ P3P_HD int p3p_solve_quartic(const double* co, double* roots)
     const double a = co[3] * i4, b = co[2] * i4, c = co[1] * i4, d = co[0] * i4;
     // depressed quartic y^4 + p y^2 + q y + r, x = y - a/4
     const double a2 = a * a;
-    const double p = b - 0.375 * a2;
-    const double q = c - 0.5 * a * b + 0.125 * a2 * a;
-    const double r = d - 0.25 * a * c + 0.0625 * a2 * b - (3.0 / 256.0) * a2 * a2;
+    const double p = fma(-0.375, a2, b);
+    const double q = fma(0.125 * a2, a, fma(-0.5 * a, b, c));
+    const double r = fma(-(3.0 / 256.0) * a2, a2, fma(0.0625 * a2, b, fma(-0.25 * a, c, d)));
     int mask = 0;
     double y0 = 0.0, y1 = 0.0, y2 = 0.0, y3 = 0.0;
     if (fabs(q) < 1e-14 * (1.0 + fabs(p) + fabs(r))) {
         // biquadratic
-        const double disc = p * p - 4.0 * r;
+        const double disc = fma(p, p, -4.0 * r);
         if (disc >= 0.0) {
             const double s = sqrt(disc);
             const double z0 = 0.5 * (-p + s), z1 = 0.5 * (-p - s);
@@ -97,21 +102,22 @@ P3P_HD int p3p_solve_quartic(const double* co, double* roots)
     } else {
         // resolvent: m^3 + p m^2 + (p^2/4 - r) m - q^2/8 = 0, take the largest real root (it is > 0)
         double m3[3];
-        const int nm = p3p_solve_cubic(p, 0.25 * p * p - r, -0.125 * q * q, m3);
+        const int nm = p3p_solve_cubic(p, fma(0.25 * p, p, -r), -0.125 * q * q, m3);
         double m = m3[0];
         if (nm == 3) { m = m3[1] > m ? m3[1] : m; m = m3[2] > m ? m3[2] : m; }
         if (m > 0.0) {
             const double s = sqrt(2.0 * m);
-            const double t0 = 0.5 * p + m;
+            const double t0 = fma(0.5, p, m);
             const double t1 = q * p3p_rcp(2.0 * s);
             // y^2 + s y + (t0 - t1) = 0  and  y^2 - s y + (t0 + t1) = 0
-            double disc = s * s - 4.0 * (t0 - t1);
+            double disc = fma(s, s, -4.0 * (t0 - t1));
             if (disc >= 0.0) { const double sq = sqrt(disc); y0 = 0.5 * (-s + sq); y1 = 0.5 * (-s - sq); mask |= 3; }
-            disc = s * s - 4.0 * (t0 + t1);
+            disc = fma(s, s, -4.0 * (t0 + t1));
             if (disc >= 0.0) { const double sq = sqrt(disc); y2 = 0.5 * (s + sq); y3 = 0.5 * (s - sq); mask |= 12; }
         }
     }
-    roots[0] = y0 - 0.25 * a; roots[1] = y1 - 0.25 * a; roots[2] = y2 - 0.25 * a; roots[3] = y3 - 0.25 * a;
+    const double a4 = 0.25 * a;
+    roots[0] = y0 - a4; roots[1] = y1 - a4; roots[2] = y2 - a4; roots[3] = y3 - a4;
     return mask;
 }
 
@@ -119,21 +125,21 @@ P3P_HD int p3p_solve_quartic(const double* co, double* roots)
 P3P_HD double p3p_polish_root(const double* co, double x)
 {
     for (int it = 0; it < 3; ++it) {
-        const double f = (((co[4] * x + co[3]) * x + co[2]) * x + co[1]) * x + co[0];
-        const double df = ((4.0 * co[4] * x + 3.0 * co[3]) * x + 2.0 * co[2]) * x + co[1];
+        const double f = fma(fma(fma(fma(co[4], x, co[3]), x, co[2]), x, co[1]), x, co[0]);
+        const double df = fma(fma(fma(4.0 * co[4], x, 3.0 * co[3]), x, 2.0 * co[2]), x, co[1]);
         if (df == 0.0) break;
-        x -= f * p3p_rcp(df);
+        x = fma(-f, p3p_rcp(df), x);
     }
     return x;
 }
 
 P3P_HD void p3p_cross(const double* a, const double* b, double* c)
 {
-    c[0] = a[1] * b[2] - a[2] * b[1];
-    c[1] = a[2] * b[0] - a[0] * b[2];
-    c[2] = a[0] * b[1] - a[1] * b[0];
+    c[0] = fma(a[1], b[2], -(a[2] * b[1]));
+    c[1] = fma(a[2], b[0], -(a[0] * b[2]));
+    c[2] = fma(a[0], b[1], -(a[1] * b[0]));
 }
-P3P_HD double p3p_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+P3P_HD double p3p_dot(const double* a, const double* b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
 P3P_HD bool p3p_normalize(double* a)
 {
     const double n = sqrt(p3p_dot(a, a));
@@ -184,12 +190,12 @@ P3P_HD bool p3p_prepare(const double X[3][3], const double f[3][3], P3PProblem& 
     const double* N = p.N; const double* D = p.D; const double* W = p.W;
     double DD[3] = { D[0] * D[0], 2.0 * D[0] * D[1], D[1] * D[1] };
     double NN[5] = { 0, 0, 0, 0, 0 }, ND[4] = { 0, 0, 0, 0 }, DDW[5] = { 0, 0, 0, 0, 0 };
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) NN[i + j] += N[i] * N[j];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) ND[i + j] += N[i] * D[j];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) DDW[i + j] += DD[i] * W[j];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) NN[i + j] = fma(N[i], N[j], NN[i + j]);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 2; ++j) ND[i + j] = fma(N[i], D[j], ND[i + j]);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) DDW[i + j] = fma(DD[i], W[j], DDW[i + j]);
     for (int k = 0; k < 5; ++k) {
         const double dd = k < 3 ? DD[k] : 0.0, nd = k < 4 ? ND[k] : 0.0;
-        p.co[k] = b2 * (dd + NN[k] - 2.0 * cg * nd) - c2 * DDW[k];
+        p.co[k] = fma(b2, fma(-2.0 * cg, nd, dd + NN[k]), -(c2 * DDW[k]));
     }
     const double* co = p.co;
     const double scale = fabs(co[0]) + fabs(co[1]) + fabs(co[2]) + fabs(co[3]) + fabs(co[4]);
@@ -216,11 +222,11 @@ P3P_HD bool p3p_pose_from_root(const P3PProblem& p, const double X[3][3], const 
     const double rk = k == 0 ? p.roots[0] : (k == 1 ? p.roots[1] : (k == 2 ? p.roots[2] : p.roots[3]));   // no dynamic index
     const double v = p.polish ? p3p_polish_root(p.co, rk) : rk;
     if (!(v > 0.0)) return false;
-    const double den = p.D[0] + p.D[1] * v;
+    const double den = fma(p.D[1], v, p.D[0]);
     if (fabs(den) < 1e-12) return false;
-    const double u = (p.N[0] + (p.N[1] + p.N[2] * v) * v) * p3p_rcp(den);
+    const double u = fma(fma(p.N[2], v, p.N[1]), v, p.N[0]) * p3p_rcp(den);
     if (!(u > 0.0)) return false;
-    const double w = p.W[0] + (p.W[1] + p.W[2] * v) * v;
+    const double w = fma(fma(p.W[2], v, p.W[1]), v, p.W[0]);
     if (!(w > 0.0)) return false;
     const double s1 = sqrt(p.b2 * p3p_rcp(w)), s2 = u * s1, s3 = v * s1;
     const double Q0[3] = { s1 * f[0][0], s1 * f[0][1], s1 * f[0][2] };
@@ -229,8 +235,8 @@ P3P_HD bool p3p_pose_from_root(const P3PProblem& p, const double X[3][3], const 
     double G[3][3];
     if (!p3p_triad(Q0, Q1, Q2, G)) return false;
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) P[4 * i + j] = G[i][0] * p.E[j][0] + G[i][1] * p.E[j][1] + G[i][2] * p.E[j][2];   // R = G E^T
-    for (int i = 0; i < 3; ++i) P[4 * i + 3] = Q0[i] - (P[4 * i] * X[0][0] + P[4 * i + 1] * X[0][1] + P[4 * i + 2] * X[0][2]);
+        for (int j = 0; j < 3; ++j) P[4 * i + j] = fma(G[i][2], p.E[j][2], fma(G[i][1], p.E[j][1], G[i][0] * p.E[j][0]));   // R = G E^T
+    for (int i = 0; i < 3; ++i) P[4 * i + 3] = fma(-P[4 * i + 2], X[0][2], fma(-P[4 * i + 1], X[0][1], fma(-P[4 * i], X[0][0], Q0[i])));
     bool finite = true;
     for (int i = 0; i < 12; ++i) finite = finite && (P[i] == P[i]) && fabs(P[i]) < 1e300;
     return finite;
@@ -251,10 +257,10 @@ P3P_HD int p3p_solve(const double X[3][3], const double f[3][3], double* Rt_out)
 // One root of one sample, straight from the correspondence arrays: pose slot `root` (12 doubles [R|t], NaNs when the root has no
 // valid pose or a sample index is out of range) of the P3P problem on points i0, i1, i2 of (X: N x 3 world points, x: N x 2 pixels,
 // K: 3 x 3 row-major).  Shared by p3p_kernel (the hypothesis generator the tests hand to the a-contrario oracle) and
-// acr_round_kernel (which solves its own sample in place); `out` may point to global memory or to LDS.  (As a call to ONE
-// not-inlined body the two would agree bit for bit by construction, but the call costs 140-200 B of callee-saved spills per lane
-// and 6 us per solve; inlined, with aggressive contraction on the same expression trees, they agree as well -- every a-contrario
-// test compares the winning pose bit for bit with the oracle's, which gets its poses from p3p_kernel.)
+// acr_round_kernel (which solves its own sample in place); `out` may point to global memory or to LDS.  Both inline it (a call to one
+// not-inlined body costs 140-200 B of callee-saved spills per lane and 6 us per solve); since round 5 every fused multiply-add in here
+// is written out and nothing else may be contracted (top of the file), so the two agree bit for bit by construction -- and every
+// a-contrario test still compares the winning pose bit for bit with the oracle's, which gets its poses from p3p_kernel.
 static __device__ __forceinline__ void p3p_sample_root(const double* X, const double* x, const double* K, const int i0, const int i1,
                                                        const int i2, const int N, const int root, double* out)
 {
@@ -271,8 +277,8 @@ static __device__ __forceinline__ void p3p_sample_root(const double* X, const do
         if (i < 0 || i >= N) { ok = false; i = 0; }
         Xs[p][0] = X[3 * i]; Xs[p][1] = X[3 * i + 1]; Xs[p][2] = X[3 * i + 2];
         const double yn = (x[2 * i + 1] - cy) * ify;
-        const double xn = (x[2 * i] - cx - sk * yn) * ifx;
-        const double inrm = p3p_rcp(sqrt(xn * xn + yn * yn + 1.0));
+        const double xn = fma(-sk, yn, x[2 * i] - cx) * ifx;
+        const double inrm = p3p_rcp(sqrt(fma(xn, xn, fma(yn, yn, 1.0))));
         f[p][0] = xn * inrm; f[p][1] = yn * inrm; f[p][2] = inrm;
     }
     P3PProblem prob;
@@ -285,10 +291,6 @@ static __device__ __forceinline__ void p3p_sample_root(const double* X, const do
 #endif
     for (int e = 0; e < 12; ++e) out[e] = have ? P[e] : qnan;
 }
-#endif
-
-#if defined(__clang__)
-#pragma clang fp contract(off)
 #endif
 
 #endif

@@ -87,6 +87,7 @@ public:
             std::cerr << "HIPDetector: clc_ctx_create failed: " << clc_status_string(rc) << std::endl;
             ctx_ = nullptr;
         }
+        trustPublishedRegions(true);
     }
     HIPDetector(const HIPDetector&) = delete;
     HIPDetector& operator=(const HIPDetector&) = delete;
@@ -96,6 +97,16 @@ public:
     {
         if (ctx_) clc_ctx_destroy(ctx_);
         ctx_ = nullptr;
+    }
+
+    // The descriptor block this detector stores in regions[idx] is published to the matcher without a second upload (below).  true (the
+    // default of the policy classes): the block is published for TRUSTING lookups -- the statement that nobody rewrites a stored
+    // regions block in place, which holds for the reference's flow (only the detectors write Descriptors(): GPUDetector.hpp:181,210,
+    // AKAZE.hpp:67).  false: it is published with a fold of all its rows, and a HIPMatcher switched the same way re-checks the whole
+    // block on every call (include/coloc_hip.h, clc_desc_cache_mode).
+    void trustPublishedRegions(bool on)
+    {
+        if (ctx_) (void)clc_desc_cache_mode(ctx_, on ? CLC_DESC_CACHE_TRUST : CLC_DESC_CACHE_VERIFY);
     }
 
     // Process an image read from disk (GPUDetector.hpp:158-184).

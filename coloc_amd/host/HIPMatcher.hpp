@@ -41,6 +41,7 @@ public:
             std::cerr << "HIPMatcher: clc_ctx_create failed: " << clc_status_string(rc) << std::endl;
             ctx_ = nullptr;
         }
+        trustPublishedRegions(true);
     }
     HIPMatcher(const HIPMatcher&) = delete;
     HIPMatcher& operator=(const HIPMatcher&) = delete;
@@ -50,6 +51,16 @@ public:
     {
         if (ctx_) clc_ctx_destroy(ctx_);
         ctx_ = nullptr;
+    }
+
+    // Descriptor blocks HIPDetector published are read on the device instead of being uploaded again (the reference uploads per call,
+    // GPUMatcher.hpp:188-196).  true (default): a published block is recognised by address, count and 18 sampled rows -- the caller's
+    // statement that regions blocks are not rewritten in place (true of the reference's flow); false: every lookup folds the whole
+    // host block and compares it with the fold taken at publish time, so a block changed anywhere is uploaded
+    // (clc_desc_cache_mode; the detector must be switched the same way, a trusting detector publishes no fold).
+    void trustPublishedRegions(bool on)
+    {
+        if (ctx_) (void)clc_desc_cache_mode(ctx_, on ? CLC_DESC_CACHE_TRUST : CLC_DESC_CACHE_VERIFY);
     }
 
     void setMapData(int kpNum, void* desc)

@@ -36,7 +36,10 @@
 extern "C" {
 #endif
 
-#define CLC_ABI_VERSION 1
+/* 1: rounds 1-3.  2: round 4's additions (clc_detect_batch_dev, clc_desc_cache_*, clc_k2nn_plan_query, clc_mc_open_peers,
+ * clc_pnp_localize_ac_batch / clc_pose_job, one-rank communicators in clc_mc_create) + round 5's (clc_desc_cache_mode, ...).
+ * Bindings check clc_abi_version() BEFORE resolving symbols an older library does not export. */
+#define CLC_ABI_VERSION 2
 #define CLC_DESC_BYTES 64
 #define CLC_MAX_LEVELS 8
 #define CLC_MAX_BATCH 8    /* cameras per clc_describe_batch_dev / clc_detect_batch_dev call */
@@ -206,9 +209,17 @@ int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt
  * (FeatureMap regions, GPUDetector.hpp:181 -> GPUMatcher.hpp:188-196) and uploads them again in every match call.  A host that has
  * just copied n rows from device memory (d_src; NULL = this context's own descriptor array, i.e. what clc_detect_and_describe filled)
  * to the host block h_desc can publish that fact: the rows are kept in a process-wide, per-device cache, and clc_match_2nn /
- * clc_match_map / clc_match_pairs skip the upload of any block they are given whose ADDRESS and COUNT match an entry and whose first
- * and last 64-byte rows still equal the published ones (compared byte for byte).  Anything else is uploaded as before, so a stale or
- * rewritten block can only miss.  Up to 32 blocks, least recently used replaced; CLC_DESC_CACHE=0 in the environment disables it. */
+ * clc_match_map / clc_match_pairs skip the upload of a block whose ADDRESS and COUNT match an entry and which the looking-up
+ * context's mode accepts as unchanged:
+ *   CLC_DESC_CACHE_VERIFY (default): a 64-bit position-keyed fold of ALL rows of the host block equals the one taken when it was
+ *       published -- a stale, rewritten (anywhere) or re-used block can only miss, at the price of one pass over the host block;
+ *   CLC_DESC_CACHE_TRUST: first, last and 16 sampled rows are compared; the caller STATES that it does not rewrite a published block
+ *       in place (the policy classes do, for FeatureMap regions, which only the detector writes: HIPMatcher::trustPublishedRegions);
+ *   CLC_DESC_CACHE_OFF: every block is uploaded, like the reference (GPUMatcher.hpp:188-196).
+ * A block published by a TRUST context carries no fold and is invisible to VERIFY lookups.  Up to 32 blocks, least recently used
+ * replaced; CLC_DESC_CACHE=0|verify|trust in the environment sets the mode contexts start with. */
+enum { CLC_DESC_CACHE_OFF = 0, CLC_DESC_CACHE_VERIFY = 1, CLC_DESC_CACHE_TRUST = 2 };
+int clc_desc_cache_mode(clc_ctx* ctx, int mode);
 int clc_desc_cache_publish(clc_ctx* ctx, const void* d_src, const void* h_desc, int n);
 int clc_desc_cache_clear(void);
 /* lookups of the host-pointer match entry points answered from the cache / uploaded, since the process started */
