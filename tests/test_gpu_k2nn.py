@@ -449,7 +449,7 @@ def test_unequal_shares_with_train_sets_beyond_4096_tiles(oracle, k2nn_formulati
     rng = np.random.default_rng(nq + nt)
     T = rng.integers(0, 256, size=(nt, 64), dtype=np.uint8)
     Q = rng.integers(0, 256, size=(nq, 64), dtype=np.uint8)
-    tail = np.concatenate([np.arange(nt - 300, nt), np.arange(4096 * 32, 4096 * 32 + 300), rng.integers(0, nt, 400)])
+    tail = np.concatenate([np.arange(nt - 301, nt - 1), np.arange(4096 * 32, 4096 * 32 + 300), rng.integers(8, nt - 1, 400)])
     Q[:len(tail)] = T[tail]
     Q[np.arange(len(tail)), np.arange(len(tail)) % 64] ^= 0x41
     T[nt - 1] = T[7]; Q[len(tail)] = T[7]                               # exact duplicate pair 7 / nt-1 -> tie -> rejected, best index 7
