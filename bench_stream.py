@@ -105,6 +105,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="plane scene, frame-batched loop: no pipelining -- a frame's front end is enqueued and waited for inside its own timed region")
     ap.add_argument("--unique-frames", type=int, default=6, help="plane scene: rendered frames per camera (the trajectory loops over them)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed without a launcher: start the ranks as a child torch.distributed.run (before anything here touches the GPU), relay its
+        # output and exit code -- the same helper as bench.py
+        import bench
+        sys.exit(bench.self_launch(args.gpus, script=os.path.abspath(__file__)))
 
     import numpy as np
     import torch
@@ -115,6 +120,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d needs %d GPUs (one camera per GPU, RCCL), this host shows %d; one GPU runs --cams cameras with --gpus 1"
+                         % (world, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

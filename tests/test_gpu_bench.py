@@ -58,6 +58,42 @@ def test_default_line_has_contract_fields():
     assert d["value"] > 10 * c["value"]          # north-star target: >= 10x the host-CPU matcher
 
 
+def _check_two_rank_line(d):
+    assert d["n_gpus"] == 2 and d["config"]["pairs"] == 1 and d["value"] > 0 and "REHEARSAL" in d["collective"]
+    # the guarded legs that run the same step through the C multi-camera entry points (clc-rccl / clc-peer at N > 1; rehearsal handles
+    # here: the ranks share the one GPU) went through their whole control flow and reproduced the headline exchange's matches
+    legs = d["exchange_legs"]
+    assert set(legs) == {"clc-rccl", "clc-peer"}
+    for leg in legs.values():
+        assert leg["identical"] is True and leg["us_per_step"] > 0 and "error" not in leg and leg["steps"] == d["steps"]
+    assert d["value_cold"] > 0 and d["warmup_effective"] >= d["warmup"]
+    # round 5: the product's exchange, having agreed with the torch step on both ranks, IS the headline: its K timed steps give value /
+    # ms_per_step, the torch exchange's figure stays beside it, nothing fell back; and the line says what an efficiency against N = 1 means
+    assert d["collective"].startswith("clc_mc_gather_enqueue_dev") and d["collective_fallback"] is None
+    assert abs(d["ms_per_step"] - legs["clc-rccl"]["us_per_step"] / 1e3) < 1e-9 and d["torch_exchange"]["ms_per_step"] > 0
+    assert abs(d["value"] - 1e8 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert "E(2)" in d["efficiency_note"] and "section_errors" not in d
+
+
+def test_gpus_2_typed_directly_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` (the form of the driver's N = 1 command, no launcher in front) used to raise
+    SystemExit.  It now starts `python -m torch.distributed.run` as a child before anything touches the GPU, relays its output and
+    exit code -- and the N = 2 line comes out (rehearsal: two ranks share the one GPU)."""
+    env = dict(os.environ, BENCH_FAULT_AFTER="200")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "4", "--settle-steps", "6"],
+                         capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "starting the ranks myself" in out.stderr
+    _check_two_rank_line(_last_json(out.stdout))
+    # and the RCCL form on a host with fewer GPUs than ranks says so instead of failing somewhere inside (one-GPU boxes only)
+    import torch
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--settle-steps", "2"],
+                             capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
+        assert bad.returncode != 0 and "needs 2 GPUs" in (bad.stdout + bad.stderr)
+
+
 def test_two_rank_rehearsal_runs():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", BENCH_FAULT_AFTER="200")   # a hung rank dumps its stacks and exits
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -65,15 +101,13 @@ def test_two_rank_rehearsal_runs():
            "--settle-steps", "6", "--backend", "gloo"]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    _check_two_rank_line(_last_json(out.stdout))
+    # --exchange torch: never promote -- the torch exchange is the headline, the legs stay informational
+    out = subprocess.run(cmd + ["--exchange", "torch"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     d = _last_json(out.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["pairs"] == 1 and d["value"] > 0 and "REHEARSAL" in d["collective"]
-    # the guarded legs that run the same step through the C multi-camera entry points (clc-rccl / clc-peer at N > 1; rehearsal handles
-    # here: the ranks share the one GPU) went through their whole control flow and reproduced the headline exchange's matches
-    legs = d["exchange_legs"]
-    assert set(legs) == {"clc-rccl", "clc-peer"}
-    for leg in legs.values():
-        assert leg["identical"] is True and leg["us_per_step"] > 0 and "error" not in leg
-    assert d["value_cold"] > 0 and d["warmup_effective"] >= d["warmup"]
+    assert d["collective"].startswith("REHEARSAL: gloo") and d["torch_exchange"] is None and d["collective_fallback"] is None
+    assert all(leg["identical"] is True for leg in d["exchange_legs"].values())
 
 
 def test_four_rank_rehearsal_runs():
