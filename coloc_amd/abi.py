@@ -59,7 +59,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_describe_match_pair_dev", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
@@ -134,6 +134,7 @@ def load_library():
     lib.clc_desc_cache_clear.argtypes = []
     lib.clc_desc_cache_stats.argtypes = [vp, vp]
     lib.clc_desc_cache_mode.argtypes = [vp, ci]
+    lib.clc_describe_match_pair_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, ci, vp, ci, vp]
     lib.clc_pnp_localize_ac_batch.argtypes = [vp, vp, ci]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
@@ -466,6 +467,15 @@ class Context:
         cnt = (C.c_void_p * n)(*d_counts)
         out = (C.c_void_p * n)(*d_desc) if d_desc is not None else None
         self._chk(self.lib.clc_detect_batch_dev(self.h, n, imgs, width, height, pitch, kps, cnt, out, stream))
+
+    def describe_match_pair_dev(self, d_imgs, width, height, pitch, d_kps, counts, d_desc, threshold, d_match, chunks=0, stream=None):
+        """clc_describe_match_pair_dev: pyramid + CLATCH of the pair's two cameras and the sweep camera 0 -> camera 1, the sweep of a
+        finished chunk of camera 0 running beside the rest of the describe launch (chunks: 0 default list, 1 no overlap, K chunks)."""
+        imgs = (C.c_void_p * 2)(*d_imgs)
+        kps = (C.c_void_p * 2)(*d_kps)
+        cnt = (C.c_int * 2)(*[int(c) for c in counts])
+        out = (C.c_void_p * 2)(*d_desc)
+        self._chk(self.lib.clc_describe_match_pair_dev(self.h, imgs, width, height, pitch, kps, cnt, out, int(threshold), d_match, int(chunks), stream))
 
     def desc_cache_mode(self, mode):
         """clc_desc_cache_mode: "off" | "verify" (whole-block fold, default) | "trust" (address + count + 18 sampled rows)."""

@@ -120,6 +120,14 @@ struct clc_ctx {
     int bias_a = 326, bias_b = 249;  // matrix sweep, one-round single-job plans: train share of a workgroup on wave slot 0 / 1 in 1/256 of the
                                      // equal share (k2nn.hip; measured optimum 21 : 16 : 12-13 tiles at 10k x 10k); CLC_K2NN_BIAS=a,b, 0,0 = equal shares
     bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
+    // pair step (clc_describe_match_pair_dev): the second stream the chunk sweeps run on, fork / join events, the describe launch's
+    // progress counters, the gates' error word (pinned host memory)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t* d_progress = nullptr;
+    uint32_t* h_gate_err = nullptr;
+    int pair_chunks[kClatchMaxChunks] = {};   // default chunk list in groups of 8 query blocks (CLC_PAIR_CHUNKS), 0-terminated
+    int pair_target_blocks = 0;               // sweep workgroups aimed at per chunk launch (CLC_PAIR_TARGET_BLOCKS; 0 = the context's)
     int cache_mode = CLC_DESC_CACHE_VERIFY;   // how this context's host-pointer match entry points treat published blocks (clc_desc_cache_mode)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
@@ -290,6 +298,16 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
     }
     if (const char* e = getenv("CLC_K2NN_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     ctx->cache_mode = cache_mode_default();
+    if (const char* e = getenv("CLC_PAIR_CHUNKS")) {
+        int k = 0;
+        for (const char* q = e; *q && k < (int)kClatchMaxChunks - 1;) {
+            const int v = atoi(q);
+            if (v > 0) ctx->pair_chunks[k++] = v;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    if (const char* e = getenv("CLC_PAIR_TARGET_BLOCKS")) ctx->pair_target_blocks = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("CLC_K2NN_BIAS")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a < 1024 && b < 1024) { ctx->bias_a = a; ctx->bias_b = b; }
@@ -347,6 +365,11 @@ int clc_ctx_destroy(clc_ctx* ctx)
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->d_progress) (void)hipFree(ctx->d_progress);
+    if (ctx->h_gate_err) (void)hipHostFree(ctx->h_gate_err);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CLC_OK;
@@ -357,6 +380,12 @@ int clc_sync(clc_ctx* ctx)
     if (!ctx) return CLC_ERR_BAD_ARG;
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) CLC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    if (ctx->h_gate_err && *ctx->h_gate_err) {
+        *ctx->h_gate_err = 0;
+        ctx->partial_dirty = true;
+        return fail(ctx, CLC_ERR_HIP, "pair step: a gate gave up waiting for the describe launch (results of that step are invalid)");
+    }
     return CLC_OK;
 }
 
@@ -788,6 +817,148 @@ int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, in
     jobs[0].nt = (uint32_t)nt;
     jobs[0].thr = (uint32_t)(uint8_t)threshold;   // CUDAK2NN.cu:46: the kernel parameter is uint8_t
     return run_jobs(ctx, jobs, pick(ctx, stream));
+}
+
+/* ---- describe both cameras of a pair and match them, as ONE step (round 5) -------------------------------------------------
+ * The reference's call pattern for a pair is detectAndDescribe of each camera (GPUDetector.hpp:216-291) and then
+ * computeMatchesPair (GPUMatcher.hpp:165-172, :180-226): the sweep starts when both describes have ended.  CLATCH keeps the LDS
+ * and the vector-memory path busy, the sweep the matrix pipe: here the sweep over a CHUNK of the query camera's rows starts as
+ * soon as that chunk (and the whole train camera) has been described, while the same describe launch is still working on the
+ * later chunks.  One describe launch (train camera dispatched first, its waves count themselves into per-chunk progress
+ * counters after an agent-scope store of their descriptor), and on a second stream per chunk a one-wave gate (waits for the
+ * chunk's counters, bounded) followed by the chunk's sweep launch; the caller's stream joins at the end.  Results are those of
+ * the two calls it replaces: the fold over train splits is order-free and chunks own disjoint query blocks. */
+static int ensure_pair(clc_ctx* ctx)
+{
+    if (ctx->stream2) return CLC_OK;
+    // the chunk sweeps' queue takes precedence over the describe launch's: a sweep workgroup (19.5 KB of LDS, 4 x 152 VGPRs) fits a CU
+    // only in the moment one of its twelve CLATCH waves (12.7 KB each, 152 of the 160 KB) has retired -- at equal priority the next
+    // CLATCH wave takes that room every time and the sweeps start when the describe launch has drained (measured: no overlap at all)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    const char* pe = getenv("CLC_PAIR_PRIORITY");
+    if (pe && pe[0] == '0') CLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    else CLC_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi));
+    CLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    CLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    const size_t bytes = (size_t)(1 + kClatchMaxChunks * 4) * kClatchProgressWays * kClatchProgressStride * sizeof(uint32_t);
+    CLC_HIP(ctx, hipMalloc((void**)&ctx->d_progress, bytes));
+    CLC_HIP(ctx, hipMemsetAsync(ctx->d_progress, 0, bytes, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CLC_HIP(ctx, hipHostMalloc((void**)&ctx->h_gate_err, sizeof(uint32_t), hipHostMallocDefault));
+    *ctx->h_gate_err = 0;
+    return CLC_OK;
+}
+
+int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_t width, uint32_t height, size_t pitch,
+                                const clc_keypoint* const* d_kps, const int* counts, void* const* d_desc, int threshold,
+                                int32_t* d_match, int chunks, void* stream)
+{
+    if (!ctx || !d_imgs || !d_kps || !counts || !d_desc || !d_imgs[0] || !d_imgs[1] || counts[0] < 0 || counts[1] < 0 ||
+        (counts[0] > 0 && (!d_kps[0] || !d_desc[0] || !d_match)) || (counts[1] > 0 && (!d_kps[1] || !d_desc[1])) || chunks < 0)
+        return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: bad argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "describe_match_pair: context created without detector options");
+    if (width != ctx->dopts.width || height != ctx->dopts.height || pitch < width || pitch > 0xFFFFFFFFull)
+        return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: image size differs from DetectorOptions width/height");
+    for (int b = 0; b < 2; ++b)
+        if (((uintptr_t)d_desc[b] & 15u) || ((uintptr_t)d_kps[b] & 3u)) return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: misaligned device pointer");
+    if ((uintptr_t)d_match & 3u) return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: misaligned device pointer");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    { const int rc = ensure_pair(ctx); if (rc != CLC_OK) return rc; }
+    if (*ctx->h_gate_err) {
+        *ctx->h_gate_err = 0;
+        ctx->partial_dirty = true;
+        return fail(ctx, CLC_ERR_HIP, "describe_match_pair: a gate of an earlier step gave up waiting for its describe launch");
+    }
+    { const int rc = ensure_slots(ctx, 2, st); if (rc != CLC_OK) return rc; }
+    // pyramid slot 0 = the TRAIN camera (camera 1 of the pair), slot 1 = the query camera: the describe launch dispatches slot 0 first
+    const uint8_t* srcs[2] = { (const uint8_t*)d_imgs[1], (const uint8_t*)d_imgs[0] };
+    ClatchBatch batch{};
+    batch.kps[0] = d_kps[1]; batch.desc[0] = (uint64_t*)d_desc[1]; batch.n[0] = counts[1];
+    batch.kps[1] = d_kps[0]; batch.desc[1] = (uint64_t*)d_desc[0]; batch.n[1] = counts[0];
+    ctx->pyramid_valid = false;
+    CLC_HIP(ctx, launch_pyramid_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, srcs, 2, (uint32_t)pitch, st, &ctx->prof));
+    ctx->pyramid_valid = true;
+    const uint32_t nq = (uint32_t)counts[0], nt = (uint32_t)counts[1];
+    const uint32_t group_rows = (uint32_t)k2nn_queries_per_block(ctx->formulation) * 8u;       // eight query blocks: one per XCD
+    const uint32_t ngroups = (nq + group_rows - 1u) / group_rows;
+    // the chunk list in groups: the caller's count (equal parts), or the context's default
+    uint32_t csz[kClatchMaxChunks] = {};
+    uint32_t nchunks = 0;
+    if (chunks == 0 && ctx->pair_chunks[0] == 0) {
+        // default: NO chunking.  Measured on MI355X (profiles/r05_step_overlap.txt): twelve CLATCH waves hold 152 of a CU's 160 KB of LDS,
+        // a sweep workgroup needs 19.5 KB, so the chunk sweeps only get onto the CUs when the describe launch drains -- 2 / 3 / 5 chunks
+        // took 124 / 138 / 175 us per step against 95 without (stream priority changes nothing).  The chunked path stays for A/B runs.
+        nchunks = 0;
+    } else if (chunks == 0) {
+        for (uint32_t k = 0; k < kClatchMaxChunks && ctx->pair_chunks[k] > 0; ++k) csz[nchunks++] = (uint32_t)ctx->pair_chunks[k];
+    } else {
+        const uint32_t K = std::min<uint32_t>((uint32_t)chunks, kClatchMaxChunks);
+        for (uint32_t k = 0; k < K; ++k) csz[nchunks++] = (ngroups * (k + 1u)) / K - (ngroups * k) / K;
+    }
+    // clip to the groups there are; what the list leaves over goes to the last chunk
+    uint32_t used = 0, kept = 0;
+    for (uint32_t k = 0; k < nchunks && used < ngroups; ++k) {
+        if (csz[k] == 0u) continue;
+        csz[kept] = std::min(csz[k], ngroups - used);
+        used += csz[kept++];
+    }
+    nchunks = kept;
+    if (nchunks && used < ngroups) csz[nchunks - 1u] += ngroups - used;
+    const bool overlap = nchunks >= 2u && nt > 0u && nt <= (1u << 22) && ngroups <= kClatchMaxChunks * 4u;
+    if (!overlap) {
+        // one stream, one describe launch, one sweep launch: the two calls this entry replaces
+        CLC_HIP(ctx, launch_clatch_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, 2, st, &ctx->prof));
+        if (nq == 0u) return CLC_OK;
+        std::vector<K2nnJobDev> jobs(1);
+        jobs[0] = K2nnJobDev{};
+        jobs[0].q = (const uint4*)d_desc[0]; jobs[0].t = (const uint4*)d_desc[1]; jobs[0].out = d_match;
+        jobs[0].nq = nq; jobs[0].nt = nt; jobs[0].thr = (uint32_t)(uint8_t)threshold;
+        return run_jobs(ctx, jobs, st);
+    }
+    // every chunk's sweep planned on its own (its launch has the slots the describe launch leaves to itself), rows and counters of
+    // the chunks one behind the other in the context's workspace
+    const int target = ctx->pair_target_blocks > 0 ? ctx->pair_target_blocks
+                                                   : (ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation));
+    std::vector<K2nnJobDev> jobs(nchunks);
+    size_t base = 0;
+    uint32_t g0 = 0;
+    for (uint32_t k = 0; k < nchunks; ++k) {
+        const uint32_t r0 = g0 * group_rows, r1 = std::min(nq, (g0 + csz[k]) * group_rows);
+        K2nnJobDev& jb = jobs[k];
+        jb = K2nnJobDev{};
+        jb.q = (const uint4*)((const uint8_t*)d_desc[0] + (size_t)r0 * CLC_DESC_BYTES);
+        jb.t = (const uint4*)d_desc[1];
+        jb.out = d_match + r0;
+        jb.nq = r1 - r0; jb.nt = nt; jb.thr = (uint32_t)(uint8_t)threshold;
+        const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, 0, 0);
+        if (!plan.atomic_merge) return fail(ctx, CLC_ERR_STATE, "describe_match_pair: chunk plan without the atomic fold");
+        jb.partial_off += (uint32_t)base;
+        jb.cnt_off += (uint32_t)(2u * base);
+        base += plan.partial_elems;
+        g0 += csz[k];
+    }
+    { const int rc = ensure_partial(ctx, base); if (rc != CLC_OK) return rc; }
+    if (ctx->partial_dirty) {
+        CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
+        ctx->partial_dirty = false;
+    }
+    CLC_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+    CLC_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    CLC_HIP(ctx, launch_clatch_progress(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, ctx->d_progress, group_rows, st, &ctx->prof));
+    g0 = 0;
+    for (uint32_t k = 0; k < nchunks; ++k) {
+        // chunk 0 also waits for the train camera (group 0); query groups are numbered from 1
+        const uint32_t first = k == 0u ? 0u : 1u + g0, groups = k == 0u ? 1u + csz[k] : csz[k];
+        CLC_HIP(ctx, launch_clatch_gate(ctx->d_progress, first, groups, nt, nq, group_rows, ctx->h_gate_err, ctx->stream2));
+        const hipError_t e = launch_k2nn(&jobs[k], 1, ctx->d_partial, ctx->stream2, &ctx->prof, ctx->formulation);
+        if (e != hipSuccess) { ctx->partial_dirty = true; return fail(ctx, CLC_ERR_HIP, "describe_match_pair: launch_k2nn", e); }
+        g0 += csz[k];
+    }
+    CLC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    CLC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
+    return CLC_OK;
 }
 
 int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs, int njobs,

@@ -49,6 +49,20 @@ struct ClatchBatch {
 hipError_t launch_clatch_batch(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
                                int n_img, hipStream_t stream, Profiler* prof = nullptr);
 
+// The pair step (capi.hip clc_describe_match_pair_dev): CLATCH of camera 0 (train side, dispatched first) and camera 1 (query side) in one
+// launch whose waves count themselves into progress groups -- group 0 = camera 0, group 1 + k = rows [k chunk_rows, (k + 1) chunk_rows)
+// of camera 1, kClatchProgressWays counters each -- and the one-wave gate that waits for groups to fill (and re-arms them).
+// (ways: atomics of agent scope are performed at the memory side, and those to ONE address one after the other -- measured round 5: 10 000
+// keypoints counted into 16 addresses made the describe launch 2.3 x longer; 128 addresses in cache lines of their own)
+static constexpr uint32_t kClatchProgressWays = 128;       // a multiple of 64
+static constexpr uint32_t kClatchProgressStride = 16;      // uint32 words between two counters
+static constexpr uint32_t kClatchMaxChunks = 16;
+hipError_t launch_clatch_progress(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
+                                  uint32_t* progress, uint32_t chunk_rows, hipStream_t stream, Profiler* prof = nullptr);
+// waits for groups first .. first + groups - 1 (group 0 = the n_train keypoints of camera 0; group k = rows of camera 1, n_query in all)
+hipError_t launch_clatch_gate(uint32_t* progress, uint32_t first, uint32_t groups, uint32_t n_train, uint32_t n_query, uint32_t chunk_rows,
+                              uint32_t* gate_error, hipStream_t stream);
+
 // ---- detector (FAST-9 + NMS + orientation) ---------------------------------------------------
 // Two launches for the pyramids of n_img cameras (pyramid b at arena + b * slot_stride, score map b at score + b * slot_stride):
 // d_mask: n_img x detect_total_tiles() x 16 keypoint-mask words, d_tcount: n_img x detect_total_tiles() tile counts (both rewritten

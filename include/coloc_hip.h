@@ -227,6 +227,20 @@ int clc_desc_cache_stats(unsigned long long* hits, unsigned long long* misses);
 /* Device-resident form; d_q / d_t must be 16-byte aligned. */
 int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt,
                       int threshold, int32_t* d_match, void* stream);
+/* Describe both cameras of a pair and match them as ONE step: replaces detectAndDescribe of each camera (GPUDetector.hpp:216-291)
+ * followed by computeMatchesPair (GPUMatcher.hpp:165-172 -> :180-226).  Camera 0 is the query side (regions[pair.first]), camera 1 the
+ * train side; d_desc[b] receives counts[b] x 64 B, d_match counts[0] indices into camera 1 (or -1), exactly what clc_describe_batch_dev +
+ * clc_match_2nn_dev give.  The sweep over a chunk of camera 0's rows starts while the describe launch is still working on the later
+ * chunks (second stream inside the context, one-wave gates on the describe launch's progress counters; the caller's stream joins before
+ * the call's work is complete from its point of view).  chunks: 0 = the context's default: no chunking, unless CLC_PAIR_CHUNKS=a,b,..
+ * (groups of eight query blocks) is set; 1 = no overlap (one describe launch, then one sweep launch, on the caller's stream); K = K
+ * about equal chunks.  On MI355X the chunked form is SLOWER (CLATCH leaves a CU's LDS no room for a sweep workgroup until its launch
+ * drains: profiles/r05_step_overlap.txt) -- it is kept for A/B runs; what does overlap describe and sweep is two contexts on two
+ * streams taking alternate steps (bench.py's headline loop).
+ * Enqueue only; capturable.  16-byte aligned descriptor pointers. */
+int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_t width, uint32_t height, size_t pitch,
+                                const clc_keypoint* const* d_kps, const int* counts, void* const* d_desc, int threshold,
+                                int32_t* d_match, int chunks, void* stream);
 /* Many (query-slice, train-set) jobs over one descriptor arena in ONE sweep launch: the
  * all-pairs loop of GPUMatcher::computeMatches (GPUMatcher.hpp:143-155) and the per-rank share
  * of it after the multi-GPU all-gather.  h_jobs is host memory. */
