@@ -95,6 +95,7 @@ static constexpr SlotTable make_slot_table()
 __device__ __attribute__((aligned(16))) const SlotTable k_slots = make_slot_table();
 
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 8 bytes at a dword-aligned LDS address (gfx950 executes a 4-byte-aligned ds_read_b64 at full rate; a
 // byte-misaligned one is legal but was measured 4.6x slower end to end, hence the shifted copies)
@@ -171,14 +172,20 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
 
     // ---- window fill: tile (by, bx) covers rows 5+8*by.., cols 5+8*bx.. with an 8x8 lane tile
-    float xc[kTiles], xs[kTiles], ys[kTiles], yc[kTiles];
+    // Round 5: the sample coordinates as PACKED fp32 pairs (v_pk_add_f32: two IEEE additions per instruction, the same roundings as two
+    // v_add_f32 -- nothing is fused, the file is built with contraction off): {x, y} = ({fpx, fpy} + ({xo c, xo s} + {-(yo s), yo c})) + 0.5
+    // is three instructions per sample instead of six.  a - b == a + (-b) in IEEE arithmetic, so the x coordinate's subtraction
+    // (CLATCH.cu:166: xo*c - yo*s) keeps its bits.  The kernel issues vector instructions 77 % of the time (PMC, profiles/r05_clatch_notes.txt):
+    // these 147 instructions per keypoint are a tenth of them.
+    f32x2 XT[kTiles], YT[kTiles];
 #pragma unroll
     for (int b = 0; b < kTiles; ++b) {
         const float xo = (float)(kTile0 + b * 8 + dx - 32);
         const float yo = (float)(kTile0 + b * 8 + dy - 32);
-        xc[b] = xo * c; xs[b] = xo * s;
-        ys[b] = yo * s; yc[b] = yo * c;
+        XT[b] = f32x2{ xo * c, xo * s };
+        YT[b] = f32x2{ -(yo * s), yo * c };
     }
+    const f32x2 fp = { fpx, fpy }, half2 = { 0.5f, 0.5f };
     // (A clamp-free variant for keypoints >= 42 px inside the level was measured 17 % SLOWER in round 1 -- the second copy of the
     // unrolled fill costs more in instruction fetch than the two v_med3 save; round 3's stamps put the clamps at 0.5 k of the
     // fill's 7 k cycles.)
@@ -186,8 +193,8 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
     for (int by = 0; by < kTiles; ++by) {
 #pragma unroll
         for (int bx = 0; bx < kTiles; ++bx) {
-            const float fx = (fpx + (xc[bx] - ys[by])) + 0.5f;   // CLATCH.cu:166
-            const float fy = (fpy + (xs[bx] + yc[by])) + 0.5f;
+            const f32x2 f = (fp + (XT[bx] + YT[by])) + half2;     // CLATCH.cu:166
+            const float fx = f.x, fy = f.y;
             const int sx = clamp_i32((int)fx, wmax);
             const int sy = clamp_i32((int)fy, hmax);
             const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
@@ -402,14 +409,15 @@ __global__ __launch_bounds__(128) void clatch8_kernel(const ClatchArgs args, con
     const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
 
     // ---- window fill into copy 0: the 49 tiles of 8 x 8 pixels are dealt to the two waves like the squares of a chess board
-    float xc[kTiles], xs[kTiles], ys[kTiles], yc[kTiles];
+    f32x2 XT[kTiles], YT[kTiles];
 #pragma unroll
     for (int b = 0; b < kTiles; ++b) {
         const float xo = (float)(kTile0 + b * 8 + dx - 32);
         const float yo = (float)(kTile0 + b * 8 + dy - 32);
-        xc[b] = xo * c; xs[b] = xo * s;
-        ys[b] = yo * s; yc[b] = yo * c;
+        XT[b] = f32x2{ xo * c, xo * s };
+        YT[b] = f32x2{ -(yo * s), yo * c };
     }
+    const f32x2 fp = { fpx, fpy }, half2 = { 0.5f, 0.5f };
     uint8_t* const win = roi + kCopy8[0];
     auto fill = [&](auto parity) {
         constexpr int P = decltype(parity)::value;
@@ -418,8 +426,8 @@ __global__ __launch_bounds__(128) void clatch8_kernel(const ClatchArgs args, con
 #pragma unroll
             for (int bx = 0; bx < kTiles; ++bx) {
                 if (((by + bx) & 1) != P) continue;
-                const float fx = (fpx + (xc[bx] - ys[by])) + 0.5f;   // CLATCH.cu:166
-                const float fy = (fpy + (xs[bx] + yc[by])) + 0.5f;
+                const f32x2 f = (fp + (XT[bx] + YT[by])) + half2;     // CLATCH.cu:166
+                const float fx = f.x, fy = f.y;
                 const int sx = clamp_i32((int)fx, wmax);
                 const int sy = clamp_i32((int)fy, hmax);
                 const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
