@@ -248,7 +248,12 @@ def main():
                          "first step on (no fallback).")
     ap.add_argument("--no-exchange-legs", action="store_true",
                     help="N > 1 only: skip the informational legs that run the same step through clc-rccl and clc-peer and compare the matches")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events; implies --one-stream)")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="N = 1: every step on ONE stream, a step's sweep waiting for its own describe and the next step's describe for that sweep "
+                         "(rounds 1-4's headline).  Default since round 5: consecutive steps alternate between two contexts / streams / descriptor "
+                         "arenas, so that step i's sweep (matrix pipe) runs beside step i + 1's pyramid + CLATCH -- the only describe / sweep overlap "
+                         "this machine allows (profiles/r05_step_overlap.txt); the one-stream figure is then reported as `one_stream`.")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the informational side sections (other formulation, shares, config[2], front end, pose, two-view, host path): "
                          "the rocprofv3 passes use it so that a kernel's average in their summaries is the average of the step's own launches")
@@ -353,8 +358,33 @@ def main():
         if abi_jobs:
             ctx.match_jobs_dev(arena.data_ptr(), abi_jobs, d_match.data_ptr(), sptr)
 
+    # N = 1 headline loop (round 5): consecutive steps on alternating lanes = (context, stream, descriptor arena, match buffer).  A lane's
+    # step is the whole step -- pyramid + CLATCH of both cameras, then the pair's sweep, in stream order --; what changes against ONE lane is
+    # that the device is not drained between step i's sweep and step i + 1's describe: the sweep, dispatched first, holds 58 KB of a CU's
+    # LDS and the matrix pipe, the next step's CLATCH waves fill the rest (profiles/r05_step_overlap.txt: inside one step the same overlap
+    # is impossible).  One context per concurrently running stream is the library's rule (include/coloc_hip.h).
+    pipelined = world == 1 and not args.one_stream and not args.graph and not args.per_camera_launches
+    ctx_b = None
+    if pipelined:
+        ctx_b = Context(device=dev_index, width=W, height=H, maxkp=NKP)
+        stream_b = torch.cuda.Stream(device=dev)
+        arena_b = torch.zeros_like(arena)
+        d_match_b = torch.empty_like(d_match)
+        lanes = [(ctx, sptr, arena, d_match, desc_ptrs),
+                 (ctx_b, stream_b.cuda_stream, arena_b, d_match_b, [arena_b[c].data_ptr() for c in cams])]
+    tick = [0]
+
+    def step_h():
+        """one step of the headline loop"""
+        if not pipelined:
+            return step()
+        c_, s_, a_, m_, dp_ = lanes[tick[0] & 1]
+        tick[0] += 1
+        c_.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP] * len(cams), dp_, s_)
+        c_.match_jobs_dev(a_.data_ptr(), abi_jobs, m_.data_ptr(), s_)
+
     def fence():
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()            # every stream of the device
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -363,21 +393,21 @@ def main():
     # (reported as value_cold / ms_per_step_cold; every rank runs the same steps)
     cold_steps = 20
     for _ in range(args.warmup):
-        step()
+        step_h()
     fence()
     tc = time.perf_counter()
     for _ in range(cold_steps):
-        step()
+        step_h()
     fence()
     dt_cold = time.perf_counter() - tc
     # clock settling (not part of W or K: the same step, untimed; every rank runs the same count -- a step may hold a collective)
     for i in range(max(args.settle_steps, 0)):
-        step()
+        step_h()
         if (i & 255) == 255:
             torch.cuda.synchronize()           # keep the queue bounded
     fence()
     for _ in range(args.warmup):
-        step()
+        step_h()
     fence()
     graph = None
     if args.graph and world == 1:
@@ -386,20 +416,52 @@ def main():
             step()
         graph.replay()
         fence()
-    # timed region: K steps; the sweep kernel is bracketed by HIP events on its stream
+    # timed region: K steps; the sweep kernel is bracketed by HIP events on its stream (both lanes' when the loop is pipelined)
     ctx.profile_reset()
+    if ctx_b is not None:
+        ctx_b.profile_reset()
     if graph is None:
         ctx.profile_enable(True, only=["k2nn_sweep_kernel"])
+        if ctx_b is not None:
+            ctx_b.profile_enable(True, only=["k2nn_sweep_kernel"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if graph is not None:
             graph.replay()
         else:
-            step()
+            step_h()
     fence()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile_read()
+    one_stream = None
+    pipelined_info = None
+    if pipelined:
+        ctx_b.profile_enable(False)
+        pb = ctx_b.profile_read()["k2nn_sweep_kernel"]
+        pa = prof["k2nn_sweep_kernel"]
+        same_lanes = bool(torch.equal(d_match[:n_out], d_match_b[:n_out]))
+        pipelined_info = {"sweep_us_while_overlapped": (pa[0] + pb[0]) / max(pa[1] + pb[1], 1) * 1e3, "sweep_launches": pa[1] + pb[1],
+                          "lanes_identical_results": same_lanes}
+        # the same K steps on ONE stream (the device drained between a step's kernels): rounds 1-4's headline, and the region the
+        # roofline's per-kernel duration comes from -- a kernel's duration says something about the kernel only while it has the machine
+        want_h = d_match[:n_out].clone()
+        for _ in range(max(args.warmup, 10)):
+            step()
+        fence()
+        ctx.profile_reset()
+        ctx.profile_enable(True, only=["k2nn_sweep_kernel"])
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dt_one = time.perf_counter() - t1
+        ctx.profile_enable(False)
+        prof = ctx.profile_read()
+        one_stream = {"ms_per_step": dt_one / args.steps * 1e3, "value": total_cmp / (dt_one / args.steps) / 1e6, "steps": args.steps,
+                      "identical_results": bool(torch.equal(want_h, d_match[:n_out])) and same_lanes,
+                      "what": "the same K steps on ONE stream: every kernel of a step has the machine to itself (rounds 1-4's headline loop); "
+                              "`roofline` is measured here"}
     # sustained leg: the same step back to back for >= sustain_seconds (no events inside), then the in-kernel clock of a
     # stamped diagnostic sweep launched straight behind it (MI355X guide, DVFS item 6)
     sustained = None
@@ -418,7 +480,9 @@ def main():
             if graph is not None:
                 graph.replay()
             else:
-                step()
+                step_h()
+        if pipelined:
+            torch.cuda.synchronize()           # the clock check below wants the sweep alone on the device, straight behind the load
         if formulation == "matrix" and abi_jobs:
             j0 = abi_jobs[0]
             try:
@@ -568,6 +632,10 @@ def main():
                         "avg_launch_us": sweep_us,
                         "peak_note": "256 CU x 64 lanes/clk x 2.4 GHz: measured 4-cycle issue of v_bcnt / SGPR-operand ops",
                         "lane_ops_per_comparison": 32, "Gcmp_per_s_kernel": cmp_per_launch / t / 1e9, "hbm": hbm}
+            if pipelined and roof is not None:
+                roof["measured_in"] = ("the one-stream region of this run (K steps, the sweep bracketed by HIP events on its stream, the kernel alone on the "
+                                       "device); in the headline region the sweep shares the device with the next step's describe launch: "
+                                       "pipelined.sweep_us_while_overlapped")
             if isinstance(clock, tuple):
                 roof["clock_ghz_in_kernel"] = {"median": clock[0], "min": clock[1], "max": clock[2], "workgroups": clock[3],
                                                "what": "s_memtime / s_memrealtime inside a stamped diagnostic sweep launched right behind the sustained leg",
@@ -602,7 +670,13 @@ def main():
                        "Mdesc_per_s_kernel": (n_desc_launch / clatch_us) if clatch_us else None,
                        "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6},
             "roofline": roof,
-            "launch_mode": "hipGraph replay" if graph is not None else "eager launches",
+            "launch_mode": ("hipGraph replay" if graph is not None else
+                            ("eager launches, consecutive steps on ALTERNATING lanes (two contexts / streams / descriptor arenas): step i's sweep runs beside "
+                             "step i + 1's pyramid + CLATCH; every step does all of its work, results identical to the one-stream loop's; "
+                             "`one_stream` = the same K steps with the device drained between a step's kernels (rounds 1-4's value)") if pipelined
+                            else "eager launches, one stream"),
+            "one_stream": one_stream,
+            "pipelined": pipelined_info,
             "collective": ("none" if world == 1 else
                            ("clc_mc_gather_enqueue_dev: " + promoted["exchange"] + " (product exchange, promoted after agreeing with the torch step)") if promoted else
                            (("RCCL all_gather_into_tensor" if mc is None else
@@ -674,8 +748,9 @@ def main():
             # K2NN sweep of one step (matrix pipe) runs beside the pyramid + CLATCH of the next (vector ALU + LDS).  Every step does all
             # of its work and the results are checked against the sequential run; what changes is that the GPU is not drained between
             # a step's sweep and the next step's describe -- how a streaming host would drive it.
-            if world != 1 or not abi_jobs or args.sustain_seconds <= 0:      # --sustain-seconds 0 (the rocprofv3 passes): one stream only,
-                return                                                          # so that per-kernel averages are of kernels that had the machine
+            if world != 1 or not abi_jobs or args.sustain_seconds <= 0 or pipelined:   # --sustain-seconds 0 (the rocprofv3 passes): one stream only,
+                return                                                          # so that per-kernel averages are of kernels that had the machine;
+                                                                                # pipelined: the headline loop IS this loop
             ctx2 = Context(device=dev_index, width=W, height=H, maxkp=NKP)
             try:
                 st2 = torch.cuda.Stream(device=dev)
@@ -995,20 +1070,27 @@ def main():
                 tm, td = float(np.median(tm[5:])), float(np.median(td[5:]))
                 # the same call when the detector has PUBLISHED the two blocks (clc_desc_cache_publish: what HIPDetector does for the
                 # regions it fills): the match finds the rows on the device, only the 40 KB of indices cross PCIe
-                ctx.desc_cache_publish(hq, d_src=arena[0].data_ptr())
-                ctx.desc_cache_publish(ht, d_src=arena[1].data_ptr())
                 want_m = ctx.match_2nn(hq.copy(), ht.copy(), THR)
-                tc = []
-                for it in range(25):
-                    t1 = time.perf_counter(); got_m = ctx.match_2nn(hq, ht, THR); tc.append(time.perf_counter() - t1)
-                tc = float(np.median(tc[5:]))
-                if not np.array_equal(want_m, got_m):
-                    raise RuntimeError("cached and uploaded descriptor blocks gave different matches")
+                tcache = {}
+                for mode in ("verify", "trust"):
+                    ctx.desc_cache_mode(mode)
+                    ctx.desc_cache_publish(hq, d_src=arena[0].data_ptr())
+                    ctx.desc_cache_publish(ht, d_src=arena[1].data_ptr())
+                    tc = []
+                    for it in range(25):
+                        t1 = time.perf_counter(); got_m = ctx.match_2nn(hq, ht, THR); tc.append(time.perf_counter() - t1)
+                    tcache[mode] = float(np.median(tc[5:]))
+                    if not np.array_equal(want_m, got_m):
+                        raise RuntimeError("cached and uploaded descriptor blocks gave different matches (%s)" % mode)
+                ctx.desc_cache_mode("verify")
                 out["host_path"] = {"what": "same work through the host-pointer entry points (PCIe copies + one sync per call included)",
                                     "match_2nn_10k_x_10k_us": tm * 1e6, "Mmatches_per_s_incl_transfers": NKP * NKP / tm / 1e6,
-                                    "match_2nn_10k_x_10k_published_blocks_us": tc * 1e6,
-                                    "published_what": "both descriptor blocks published by the detector (clc_desc_cache_publish): no upload, "
-                                                      "the call is sweep + 40 KB of indices back + one synchronisation; identical matches",
+                                    "match_2nn_10k_x_10k_published_blocks_us": tcache["trust"] * 1e6,
+                                    "match_2nn_10k_x_10k_published_blocks_verified_us": tcache["verify"] * 1e6,
+                                    "published_what": "both descriptor blocks published by the detector (clc_desc_cache_publish): no upload, the call is sweep + 40 KB "
+                                                      "of indices back + one synchronisation; identical matches.  *_us: a TRUSTING context (what HIPDetector / "
+                                                      "HIPMatcher use: address + count + 18 sampled rows); *_verified_us: the default for raw callers, every "
+                                                      "lookup folds the whole 640 KB host block (two of them per call) and compares with the fold taken at publish time",
                                     "pyramid_plus_describe_10k_us": td * 1e6, "Mdesc_per_s_incl_transfers": NKP / td / 1e6}
 
         def sec_cpu_baseline():
@@ -1051,6 +1133,8 @@ def main():
         os._exit(3)
     if mc is not None:
         mc.close()
+    if ctx_b is not None:
+        ctx_b.close()
     ctx.close()
     if world > 1:
         dist.barrier()                  # nobody tears the group down while another rank still uses it
