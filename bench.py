@@ -446,7 +446,14 @@ def main():
         # the same K steps on ONE stream (the device drained between a step's kernels): rounds 1-4's headline, and the region the
         # roofline's per-kernel duration comes from -- a kernel's duration says something about the kernel only while it has the machine
         want_h = d_match[:n_out].clone()
-        for _ in range(max(args.warmup, 10)):
+        # (its own settling: behind the heavier pipelined load the chip holds a lower clock for some tens of milliseconds -- a one-stream
+        # region started straight behind it read 0.114 ms per step and a 28.9 us sweep where the same loop settled reads 0.099 / 25.3)
+        for i in range(max(args.settle_steps // 2, args.warmup, 10)):
+            step()
+            if (i & 255) == 255:
+                torch.cuda.synchronize()
+        fence()
+        for _ in range(args.warmup):
             step()
         fence()
         ctx.profile_reset()
@@ -460,6 +467,7 @@ def main():
         prof = ctx.profile_read()
         one_stream = {"ms_per_step": dt_one / args.steps * 1e3, "value": total_cmp / (dt_one / args.steps) / 1e6, "steps": args.steps,
                       "identical_results": bool(torch.equal(want_h, d_match[:n_out])) and same_lanes,
+                      "settle_steps": max(args.settle_steps // 2, args.warmup, 10),
                       "what": "the same K steps on ONE stream: every kernel of a step has the machine to itself (rounds 1-4's headline loop); "
                               "`roofline` is measured here"}
     # sustained leg: the same step back to back for >= sustain_seconds (no events inside), then the in-kernel clock of a
