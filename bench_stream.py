@@ -338,66 +338,64 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
         st["poses"][(cam, f)] = Rt
         return dict(C=Ce, cov=Cc, gt=gt, Rt=Rt, n=n, kps=kps, m=m)   # feature coordinates are derived for the rows a later stage needs
 
+    inter_pool = {"ctxs": [], "d_pairs": None}
+
     def inter_and_fuse(c, cptr, f, est, desc_ptr, d_pair, st):
-        """inter-camera step + fusion: destination = cam, source = its neighbour (coloc.hpp:274-392)"""
+        """inter-camera step + fusion for every camera of the frame: destination = cam, source = its neighbour (coloc.hpp:274-392).
+        Round 5: the pairs' match sweeps are enqueued together and fetched behind ONE synchronisation, and everything between the putative
+        matches and the covariance intersection -- a-contrario five-point filter, relative pose from E, temporary map, scale, refinement
+        -- is ONE clc_inter_pose_batch call for all pairs (rounds 3-4 did that geometry in numpy, pair after pair)."""
+        from coloc_amd.abi import inter_pose_batch
         lat = st["lat"]
+        todo = []
         for cam in my_cams:
             nb = (cam + 1) % n_cams
-            if cam not in est or nb not in est or nb == cam:
-                continue
+            if cam in est and nb in est and nb != cam:
+                todo.append((cam, nb))
+        if not todo:
+            return
+        t4 = time.perf_counter()
+        if inter_pool["d_pairs"] is None or inter_pool["d_pairs"].shape[0] < len(todo):
+            inter_pool["d_pairs"] = torch.empty((len(my_cams), CAP), dtype=torch.int32, device=dev)
+        while len(inter_pool["ctxs"]) < len(todo):
+            inter_pool["ctxs"].append(Context(device=local_rank, detector=False, matcher=False))
+        dp = inter_pool["d_pairs"]
+        # computeMatchesPair(source, dest): Q = the source frame's descriptors, T = the destination's (GPUMatcher.hpp:165-172)
+        for k, (cam, nb) in enumerate(todo):
+            c.match_2nn_dev(desc_ptr[nb], est[nb]["n"], desc_ptr[cam], est[cam]["n"], 60, dp[k].data_ptr(), cptr)
+        with torch.cuda.stream(torch.cuda.ExternalStream(cptr)):
+            pms = [dp[k, :est[nb]["n"]].cpu().numpy() for k, (cam, nb) in enumerate(todo)]
+        probs, meta = [], []
+        for (cam, nb), pm in zip(todo, pms):
             S, D = est[nb], est[cam]
-            t4 = time.perf_counter()
-            # computeMatchesPair(source, dest): Q = the source frame's descriptors, T = the destination's (GPUMatcher.hpp:165-172)
-            c.match_2nn_dev(desc_ptr[nb], S["n"], desc_ptr[cam], D["n"], 60, d_pair.data_ptr(), cptr)
-            with torch.cuda.stream(torch.cuda.ExternalStream(cptr)):
-                pm = d_pair[:S["n"]].cpu().numpy()
             q = np.nonzero(pm >= 0)[0]
-            ok = False
-            if len(q) >= 16:
-                x1 = feature_xy(S["kps"][q]) if "kps" in S else S["xy"][q]
-                x2 = feature_xy(D["kps"][pm[q]]) if "kps" in D else D["xy"][pm[q]]
-                # filterMatchesPair: a-contrario five-point + relative pose from E (RobustMatcher.hpp:153-186)
-                e = c.essential_acransac(x1, x2, K, K, (W, H), max_iteration=256, seed=f + 1)
-                if e["E"] is not None and len(e["inliers"]) >= 13:
-                    inl = e["inliers"]
-                    rp = relative_pose_from_essential(e["E"], K, x1[inl], x2[inl])
-                    if rp is not None:
-                        Rr, tr, Xtmp, front = rp
-                        qi = q[inl][front]                       # source keypoints of the temporary map's points
-                        Xtmp, x2i = Xtmp[front], x2[inl][front]
-                        # scale of the temporary map against the global one through the features both hold (the source frame's map
-                        # matches, threshold 60): a depth-ratio screen, then the reference's mean of consecutive distance ratios
-                        # (colocUtils.hpp:184-211)
-                        ms = S["m"][qi]
-                        com = np.nonzero(ms >= 0)[0]
-                        scale = None
-                        if len(com) >= 8:
-                            Xg = Xmap[ms[com]]
-                            Xg_s = Xg @ S["Rt"][:, :3].T + S["Rt"][:, 3]
-                            ratio = np.linalg.norm(Xg_s, axis=1) / np.maximum(np.linalg.norm(Xtmp[com], axis=1), 1e-12)
-                            keep = np.abs(ratio / np.median(ratio) - 1.0) < 0.2
-                            com, Xg = com[keep], Xg[keep]
-                            if len(com) >= 8:
-                                d1 = np.linalg.norm(Xg[1:] - Xg[:-1], axis=1)
-                                d2 = np.linalg.norm(Xtmp[com][1:] - Xtmp[com][:-1], axis=1)
-                                good = d2 > 1e-9
-                                scale = float(np.mean(d1[good] / d2[good]))
-                        if scale is not None and np.isfinite(scale) and scale > 0:
-                            # the destination's pose through the source: X_d = R_rel X_s + s t_rel, X_s = R_s X_w + t_s
-                            Rt0 = np.c_[Rr @ S["Rt"][:, :3], Rr @ S["Rt"][:, 3] + scale * tr]
-                            Xw = (scale * Xtmp - S["Rt"][:, 3]) @ S["Rt"][:, :3]           # temporary map in world coordinates
-                            Rt_i, cov_i, rmse_i, _ = c.pnp_refine(Xw, x2i, K, Rt0)         # refinePose(tempScene, extrinsics only) :340
-                            Ci = -Rt_i[:, :3].T @ Rt_i[:, 3]
-                            Cci = Rt_i[:, :3].T @ cov_i[3:, 3:] @ Rt_i[:, :3] + S["cov"]     # covInter = currentCov[source] + cov (:366)
-                            t5 = time.perf_counter()
-                            om, Cf, pf = cov_intersection(D["cov"], Cci + 1e-12 * np.eye(3), D["C"], Ci)
-                            t6 = time.perf_counter()
-                            lat["inter"].append(t5 - t4); lat["fuse"].append(t6 - t5)
-                            st["pos_err_inter"].append(np.linalg.norm(Ci - D["gt"])); st["pos_err_fused"].append(np.linalg.norm(pf - D["gt"]))
-                            st["n_pair"].append(len(q)); st["n_pair_inl"].append(len(inl)); st["n_common"].append(len(com))
-                            ok = True
-            if not ok:
+            if len(q) < 16:
                 st["inter_fail"] += 1
+                continue
+            x1 = feature_xy(S["kps"][q]) if "kps" in S else S["xy"][q]
+            x2 = feature_xy(D["kps"][pm[q]]) if "kps" in D else D["xy"][pm[q]]
+            # filterMatchesPair + RelativePoseFromEssential + interReconstruct + scale + refinePose (coloc.hpp:296-340); the source frame's
+            # map matches (threshold 60) say which of its features the global map holds
+            probs.append(dict(x1=x1, x2=x2, K=K, wh=(W, H), seed=f + 1, map_index=S["m"][q], Rt_source=S["Rt"]))
+            meta.append((cam, nb, len(q)))
+        res = inter_pose_batch(inter_pool["ctxs"][:len(probs)], probs, Xmap) if probs else []
+        t5 = time.perf_counter()
+        n_ok = 0
+        for (cam, nb, nq), r in zip(meta, res):
+            S, D = est[nb], est[cam]
+            if r["stage"] != 0 or r["status"] != 0:
+                st["inter_fail"] += 1
+                continue
+            Rt_i, cov_i = r["Rt"], r["cov"]
+            Ci = -Rt_i[:, :3].T @ Rt_i[:, 3]
+            Cci = Rt_i[:, :3].T @ cov_i[3:, 3:] @ Rt_i[:, :3] + S["cov"]     # covInter = currentCov[source] + cov (:366)
+            om, Cf, pf = cov_intersection(D["cov"], Cci + 1e-12 * np.eye(3), D["C"], Ci)
+            st["pos_err_inter"].append(np.linalg.norm(Ci - D["gt"])); st["pos_err_fused"].append(np.linalg.norm(pf - D["gt"]))
+            st["n_pair"].append(nq); st["n_pair_inl"].append(len(r["inliers"])); st["n_common"].append(r["n_common"])
+            n_ok += 1
+        t6 = time.perf_counter()
+        for _ in range(n_ok):
+            lat["inter"].append((t5 - t4) / len(todo)); lat["fuse"].append((t6 - t5) / max(n_ok, 1))
 
     # ---------------------------------------------------------------------------------------------------------------------
     # sequential: camera by camera, a synchronisation between the stages (every rank count; the only mode at world > 1)
@@ -732,6 +730,11 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
                "frames_per_camera": args.frames, "localized_frames": len(pos_err), "map_points": int(len(desc_m)),
                "camera_frames_per_s_per_gpu": (1000.0 / p50(lat["frame"])) if lat["frame"] else None,
                "cameras_at_30fps_per_gpu": (1000.0 / p50(lat["frame"]) / 30.0) if lat["frame"] else None,
+               "camera_frames_per_s_incl_inter": (len(pos_err) / st["wall"]) if st.get("wall") else None,
+               "cameras_at_30fps_per_gpu_incl_inter": (len(pos_err) / st["wall"] / 30.0) if st.get("wall") else None,
+               "throughput_what": "camera_frames_per_s_per_gpu / cameras_at_30fps_per_gpu = 1 / the p50 of a camera frame's front end + map match + "
+                                  "pose (the intra-camera stages); *_incl_inter = localized camera frames / the loop's wall time, i.e. WITH the "
+                                  "inter-camera step and the fusion of every frame -- the figure for the loop BASELINE config[4] names",
                "wall_s": st["wall"], "required": "30 fps per camera (config[4]: 8 cameras on 8 GPUs)",
                "p50_ms": {k: p50(v) for k, v in lat.items()},
                "keypoints_p50": med(st["n_kp"]), "map_matches_p50": med(st["n_match"]), "inliers_p50": med(st["n_inl"]),
@@ -742,7 +745,8 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
                "pair_matches_p50": med(st["n_pair"]), "pair_inliers_p50": med(st["n_pair_inl"]), "common_map_features_p50": med(st["n_common"]),
                "inter_rule": "frame-to-frame K2NN (thr 60) -> a-contrario five-point -> relative pose from E -> scale from the features the "
                              "temporary and the global map share -> LM refinement of the destination pose -> covariance intersection "
-                             "(coloc.hpp:274-392); nothing taken from the rendered poses",
+                             "(coloc.hpp:274-392); nothing taken from the rendered poses; since round 5 one clc_inter_pose_batch call per "
+                             "frame for all pairs (p50_ms.inter = that call + the pairs' match sweeps, per pair)",
                "camera_height": HEIGHT,
                "pose_rule": "a-contrario P3P, 256 iterations, error_max = inf (Localizer.hpp:82-93) + LM refinement",
                "note": "frames are rendered on the host before the loop; everything from the uploaded frame to the fused position is timed"}
@@ -765,6 +769,8 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
         print(json.dumps(out))
         if not same:
             sys.exit(3)
+    for c_ in inter_pool["ctxs"]:
+        c_.close()
     ctx.close()
 
 

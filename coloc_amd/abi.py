@@ -52,6 +52,21 @@ class PoseJob(C.Structure):
 ABI_VERSION = 2          # CLC_ABI_VERSION of include/coloc_hip.h
 DESC_CACHE_OFF, DESC_CACHE_VERIFY, DESC_CACHE_TRUST = 0, 1, 2
 
+class TwoViewJob(C.Structure):
+    """clc_two_view_job (include/coloc_hip.h)"""
+    _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("K1", C.c_void_p), ("K2", C.c_void_p), ("n", C.c_int), ("img_w", C.c_int), ("img_h", C.c_int),
+                ("max_iteration", C.c_int), ("seed", C.c_uint64), ("precision", C.c_double),
+                ("E", C.c_void_p), ("F", C.c_void_p), ("inlier_mask", C.c_void_p), ("inliers", C.c_void_p),
+                ("n_inliers", C.c_int), ("iterations", C.c_int), ("status", C.c_int), ("error_max", C.c_double), ("min_nfa", C.c_double)]
+
+
+class InterPoseJob(C.Structure):
+    """clc_inter_pose_job (include/coloc_hip.h)"""
+    _fields_ = [("tv", TwoViewJob), ("map_index", C.c_void_p), ("map_X", C.c_void_p), ("Rt_source", C.c_void_p), ("huber_a", C.c_double),
+                ("Rt", C.c_double * 12), ("cov", C.c_double * 36), ("rmse", C.c_double), ("scale", C.c_double),
+                ("n_front", C.c_int), ("n_common", C.c_int), ("n_refined", C.c_int), ("stage", C.c_int)]
+
+
 EXPORTS = [
     "clc_abi_version", "clc_status_string", "clc_ctx_create", "clc_ctx_destroy", "clc_last_error_string",
     "clc_sync", "clc_stream", "clc_pyramid_build", "clc_pyramid_build_dev", "clc_pyramid_level",
@@ -59,7 +74,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_describe_match_pair_dev", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_describe_match_pair_dev", "clc_essential_acransac_batch", "clc_inter_pose_batch", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
@@ -134,6 +149,8 @@ def load_library():
     lib.clc_desc_cache_clear.argtypes = []
     lib.clc_desc_cache_stats.argtypes = [vp, vp]
     lib.clc_desc_cache_mode.argtypes = [vp, ci]
+    lib.clc_essential_acransac_batch.argtypes = [vp, vp, ci]
+    lib.clc_inter_pose_batch.argtypes = [vp, vp, ci]
     lib.clc_describe_match_pair_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, ci, vp, ci, vp]
     lib.clc_pnp_localize_ac_batch.argtypes = [vp, vp, ci]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
@@ -208,6 +225,68 @@ def cov_intersection(CA, CB, ca, cb):
     if rc != CLC_OK:
         raise CLCError(rc, lib.clc_status_string(rc).decode())
     return om.value, cov.reshape(3, 3), pos
+
+
+def _two_view_fill(tv, keep, x1, x2, K1, K2, img_wh, max_iteration, seed, precision):
+    x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2); x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+    K1 = np.ascontiguousarray(K1, dtype=np.float64).reshape(9); K2 = np.ascontiguousarray(K2, dtype=np.float64).reshape(9)
+    n = x1.shape[0]
+    E, F = np.zeros(9), np.zeros(9)
+    mask, inl = np.zeros(max(n, 1), dtype=np.uint8), np.zeros(max(n, 1), dtype=np.int32)
+    keep.append((x1, x2, K1, K2, E, F, mask, inl))
+    tv.x1, tv.x2, tv.K1, tv.K2, tv.n = x1.ctypes.data, x2.ctypes.data, K1.ctypes.data, K2.ctypes.data, n
+    tv.img_w, tv.img_h, tv.max_iteration, tv.seed, tv.precision = int(img_wh[0]), int(img_wh[1]), int(max_iteration), int(seed), float(precision)
+    tv.E, tv.F, tv.inlier_mask, tv.inliers = E.ctypes.data, F.ctypes.data, mask.ctypes.data, inl.ctypes.data
+    return E, F, mask, inl
+
+
+def _two_view_result(tv, E, F, mask, inl):
+    ok = tv.n_inliers > 0
+    return dict(E=E.reshape(3, 3).copy() if ok else None, F=F.reshape(3, 3).copy() if ok else None, mask=mask[:tv.n].astype(bool),
+                inliers=inl[:tv.n_inliers].copy(), error_max=tv.error_max, min_nfa=tv.min_nfa, iterations=tv.iterations, status=tv.status)
+
+
+def essential_acransac_batch(ctxs, problems, max_iteration=256, precision=float("inf")):
+    """clc_essential_acransac_batch: problems = [(x1, x2, K1, K2, (w, h), seed), ...], one Context per problem; -> list of result dicts."""
+    lib = load_library()
+    n = len(problems)
+    jobs = (TwoViewJob * n)()
+    keep, outs = [], []
+    for j, (x1, x2, K1, K2, wh, seed) in zip(jobs, problems):
+        outs.append(_two_view_fill(j, keep, x1, x2, K1, K2, wh, max_iteration, seed, precision))
+    hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+    rc = lib.clc_essential_acransac_batch(hs, jobs, n)
+    if rc != CLC_OK:
+        raise CLCError(rc, lib.clc_status_string(rc).decode())
+    return [_two_view_result(j, *o) for j, o in zip(jobs, outs)]
+
+
+def inter_pose_batch(ctxs, problems, map_X, max_iteration=256, huber_a=16.0):
+    """clc_inter_pose_batch: problems = [dict(x1, x2, K, wh, seed, map_index, Rt_source), ...] (x1 = source frame's features, x2 = the
+    destination's), one Context per problem, map_X the global map's points (M x 3); -> list of dicts (two-view result + Rt, cov, rmse,
+    scale, n_front, n_common, stage)."""
+    lib = load_library()
+    n = len(problems)
+    jobs = (InterPoseJob * n)()
+    map_X = np.ascontiguousarray(map_X, dtype=np.float64).reshape(-1, 3)
+    keep, outs = [map_X], []
+    for j, p in zip(jobs, problems):
+        outs.append(_two_view_fill(j.tv, keep, p["x1"], p["x2"], p["K"], p["K"], p["wh"], max_iteration, p["seed"], float("inf")))
+        mi = np.ascontiguousarray(p["map_index"], dtype=np.int32)
+        rs = np.ascontiguousarray(p["Rt_source"], dtype=np.float64).reshape(12)
+        keep.append((mi, rs))
+        j.map_index, j.map_X, j.Rt_source, j.huber_a = mi.ctypes.data, map_X.ctypes.data, rs.ctypes.data, float(huber_a)
+    hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+    rc = lib.clc_inter_pose_batch(hs, jobs, n)
+    if rc != CLC_OK:
+        raise CLCError(rc, lib.clc_status_string(rc).decode())
+    res = []
+    for j, o in zip(jobs, outs):
+        d = _two_view_result(j.tv, *o)
+        d.update(Rt=np.array(j.Rt).reshape(3, 4), cov=np.array(j.cov).reshape(6, 6), rmse=j.rmse, scale=j.scale, n_front=j.n_front,
+                 n_common=j.n_common, n_refined=j.n_refined, stage=j.stage)
+        res.append(d)
+    return res
 
 
 def mc_plan(counts, world, rank, grain):

@@ -8,6 +8,7 @@
 // stream per context, every HIP status checked and mapped to an int code.
 #include "clc_internal.h"
 #include "../host/HIPCovIntersection.hpp"
+#include "../host/HIPRobustMatcher.hpp"      // hipgeom::motion_from_essential (host arithmetic of the inter-camera step)
 #include "clc_acr.h"
 
 #include <algorithm>
@@ -2156,6 +2157,289 @@ int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2,
     if (h_E) memcpy(h_E, EF, sizeof(double) * 9);
     if (h_F) memcpy(h_F, EF + 9, sizeof(double) * 9);
     return rc;
+}
+
+} // extern "C"
+
+// ---- several two-view problems at once / the inter-camera step behind the C ABI (round 5) -----------------------------------
+namespace {
+
+void two_view_begin(AcrRun& r, clc_ctx* ctx, clc_two_view_job& jb, double* EF)
+{
+    if (jb.E) memset(jb.E, 0, sizeof(double) * 9);
+    if (jb.F) memset(jb.F, 0, sizeof(double) * 9);
+    jb.n_inliers = 0; jb.iterations = 0; jb.error_max = 0.0; jb.min_nfa = INFINITY;
+    r.ctx = ctx; r.kind = 1; r.h_a = jb.x1; r.h_b = jb.x2; r.N = jb.n; r.h_K1 = jb.K1; r.h_K2 = jb.K2; r.img_w = jb.img_w; r.img_h = jb.img_h;
+    r.max_iteration = jb.max_iteration; r.seed = jb.seed; r.precision = jb.precision; r.refine_huber = -1.0;
+    r.h_model = EF; r.h_mask = jb.inlier_mask; r.h_inliers = jb.inliers; r.n_inliers = &jb.n_inliers; r.error_max = &jb.error_max;
+    r.min_nfa = &jb.min_nfa; r.iterations = &jb.iterations;
+    jb.status = r.begin();
+}
+
+// all runs to their end from one thread: whichever solve's round has come out gets its next one enqueued
+void drive_runs(std::vector<AcrRun>& runs)
+{
+    int live = 0;
+    for (AcrRun& r : runs) if (r.phase != AcrRun::DONE) ++live;
+    while (live > 0)
+        for (AcrRun& r : runs) {
+            if (r.phase == AcrRun::DONE) continue;
+            (void)r.poll();
+            if (r.phase == AcrRun::DONE) --live;
+        }
+}
+
+int check_batch_contexts(clc_ctx* const* ctxs, int n_jobs, const char* what)
+{
+    for (int i = 0; i < n_jobs; ++i) {
+        if (!ctxs[i]) return CLC_ERR_BAD_ARG;
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j] == ctxs[i]) return fail(ctxs[i], CLC_ERR_BAD_ARG, what);
+        if (ctxs[i]->device != ctxs[0]->device) return fail(ctxs[i], CLC_ERR_BAD_ARG, "batch: the contexts must live on one device");
+    }
+    return CLC_OK;
+}
+
+// pixel -> normalised camera plane for an upper-triangular K (row-major)
+inline void normalise_px(const double* K, const double x, const double y, double* n)
+{
+    n[1] = (y - K[5]) / K[4];
+    n[0] = (x - K[2] - K[1] * n[1]) / K[0];
+}
+
+// The host part of the inter-camera step between the two-view filter and the refinement (coloc.hpp:296-340): relative pose from E with
+// the chirality vote (RobustMatcher.hpp:176-183), the pair's temporary map in the source camera's frame, its scale against the global
+// map through the features both hold (colocUtils.hpp:184-211: mean of consecutive distance ratios, behind a depth-ratio screen), the
+// destination's first pose through the source's.  Triangulation: the depths along the two rays that bring them closest (closed form;
+// OpenMVG's TriangulateDLT differs from it by less than the measurement noise).  Returns 0, or which stage failed (CLC_INTER_*).
+int inter_geometry(clc_inter_pose_job& jb, std::vector<double>& Xw, std::vector<double>& x2f)
+{
+    const clc_two_view_job& tv = jb.tv;
+    const int ni = tv.n_inliers;
+    jb.n_front = 0; jb.n_common = 0; jb.scale = 0.0;
+    if (ni < 13 || !tv.E || !tv.inliers) return CLC_INTER_NO_MODEL;
+    openMVG::Mat3 E;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E(i, j) = tv.E[3 * i + j];
+    std::vector<openMVG::geometry::Pose3> cand;
+    coloc::hipgeom::motion_from_essential(E, &cand);
+    std::vector<double> n1((size_t)2 * ni), n2((size_t)2 * ni);
+    for (int k = 0; k < ni; ++k) {
+        const int i = tv.inliers[k];
+        normalise_px(tv.K1, tv.x1[2 * i], tv.x1[2 * i + 1], &n1[2 * (size_t)k]);
+        normalise_px(tv.K2, tv.x2[2 * i], tv.x2[2 * i + 1], &n2[2 * (size_t)k]);
+    }
+    int best = -1, best_cnt = -1;
+    std::vector<double> l1((size_t)ni), bl1;
+    std::vector<uint8_t> fr((size_t)ni), bfr;
+    double Rb[9] = {}, tb[3] = {};
+    for (size_t c = 0; c < cand.size(); ++c) {
+        const openMVG::Mat3& R = cand[c].rotation();
+        const openMVG::Vec3 t = cand[c].translation();
+        int cnt = 0;
+        for (int k = 0; k < ni; ++k) {
+            const double p[3] = { n1[2 * (size_t)k], n1[2 * (size_t)k + 1], 1.0 }, b[3] = { n2[2 * (size_t)k], n2[2 * (size_t)k + 1], 1.0 };
+            double a[3];
+            for (int r = 0; r < 3; ++r) a[r] = R(r, 0) * p[0] + R(r, 1) * p[1] + R(r, 2) * p[2];
+            // min | l1 a - l2 b + t |^2
+            const double aa = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], bb = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+            const double ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+            const double at = a[0] * t[0] + a[1] * t[1] + a[2] * t[2], bt = b[0] * t[0] + b[1] * t[1] + b[2] * t[2];
+            double det = aa * bb - ab * ab;
+            if (std::fabs(det) < 1e-18) det = 1e-18;
+            const double d1 = (-at * bb + bt * ab) / det, d2 = (-at * ab + bt * aa) / det;
+            l1[(size_t)k] = d1;
+            fr[(size_t)k] = d1 > 0.0 && d2 > 0.0;
+            cnt += fr[(size_t)k];
+        }
+        if (cnt > best_cnt) {
+            best_cnt = cnt; best = (int)c; bl1 = l1; bfr = fr;
+            for (int r = 0; r < 3; ++r) { for (int q = 0; q < 3; ++q) Rb[3 * r + q] = R(r, q); tb[r] = t[r]; }
+        }
+    }
+    if (best < 0 || best_cnt < 8) return CLC_INTER_NO_RELATIVE_POSE;
+    jb.n_front = best_cnt;
+    // the temporary map (source camera's frame, unit baseline) of the correspondences in front of both cameras
+    const size_t nf = (size_t)best_cnt;
+    std::vector<double> Xt(3 * nf);
+    std::vector<int32_t> mi(nf);
+    x2f.resize(2 * nf);
+    size_t w = 0;
+    for (int k = 0; k < ni; ++k) {
+        if (!bfr[(size_t)k]) continue;
+        const int i = tv.inliers[k];
+        Xt[3 * w] = n1[2 * (size_t)k] * bl1[(size_t)k]; Xt[3 * w + 1] = n1[2 * (size_t)k + 1] * bl1[(size_t)k]; Xt[3 * w + 2] = bl1[(size_t)k];
+        x2f[2 * w] = tv.x2[2 * i]; x2f[2 * w + 1] = tv.x2[2 * i + 1];
+        mi[w] = jb.map_index ? jb.map_index[i] : -1;
+        ++w;
+    }
+    // scale through the features both maps hold
+    const double* Rs = jb.Rt_source;          // [R|t] row-major 3 x 4
+    std::vector<size_t> com;
+    std::vector<double> ratio;
+    for (size_t k = 0; k < nf; ++k) {
+        if (mi[k] < 0) continue;
+        const double* Xg = jb.map_X + 3 * (size_t)mi[k];
+        double xs[3];
+        for (int r = 0; r < 3; ++r) xs[r] = Rs[4 * r] * Xg[0] + Rs[4 * r + 1] * Xg[1] + Rs[4 * r + 2] * Xg[2] + Rs[4 * r + 3];
+        const double ng = std::sqrt(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
+        const double nt = std::sqrt(Xt[3 * k] * Xt[3 * k] + Xt[3 * k + 1] * Xt[3 * k + 1] + Xt[3 * k + 2] * Xt[3 * k + 2]);
+        com.push_back(k);
+        ratio.push_back(ng / (nt > 1e-12 ? nt : 1e-12));
+    }
+    jb.n_common = (int)com.size();
+    if (com.size() < 8) return CLC_INTER_NO_SCALE;
+    std::vector<double> srt(ratio);
+    std::sort(srt.begin(), srt.end());
+    const double med = (srt.size() & 1) ? srt[srt.size() / 2] : 0.5 * (srt[srt.size() / 2 - 1] + srt[srt.size() / 2]);
+    std::vector<size_t> keep;
+    for (size_t k = 0; k < com.size(); ++k) if (std::fabs(ratio[k] / med - 1.0) < 0.2) keep.push_back(com[k]);
+    jb.n_common = (int)keep.size();
+    if (keep.size() < 8) return CLC_INTER_NO_SCALE;
+    double sum = 0.0; size_t good = 0;
+    for (size_t k = 0; k + 1 < keep.size(); ++k) {
+        const double* g0 = jb.map_X + 3 * (size_t)mi[keep[k]]; const double* g1 = jb.map_X + 3 * (size_t)mi[keep[k + 1]];
+        const double* t0 = &Xt[3 * keep[k]]; const double* t1 = &Xt[3 * keep[k + 1]];
+        const double d1 = std::sqrt((g1[0] - g0[0]) * (g1[0] - g0[0]) + (g1[1] - g0[1]) * (g1[1] - g0[1]) + (g1[2] - g0[2]) * (g1[2] - g0[2]));
+        const double d2 = std::sqrt((t1[0] - t0[0]) * (t1[0] - t0[0]) + (t1[1] - t0[1]) * (t1[1] - t0[1]) + (t1[2] - t0[2]) * (t1[2] - t0[2]));
+        if (d2 > 1e-9) { sum += d1 / d2; ++good; }
+    }
+    if (good == 0) return CLC_INTER_NO_SCALE;
+    const double scale = sum / (double)good;
+    if (!(scale > 0.0) || !std::isfinite(scale)) return CLC_INTER_NO_SCALE;
+    jb.scale = scale;
+    // the destination's pose through the source: X_d = R_rel X_s + s t_rel, X_s = R_s X_w + t_s
+    for (int r = 0; r < 3; ++r) {
+        for (int q = 0; q < 3; ++q) jb.Rt[4 * r + q] = Rb[3 * r] * Rs[q] + Rb[3 * r + 1] * Rs[4 + q] + Rb[3 * r + 2] * Rs[8 + q];
+        jb.Rt[4 * r + 3] = Rb[3 * r] * Rs[3] + Rb[3 * r + 1] * Rs[7] + Rb[3 * r + 2] * Rs[11] + scale * tb[r];
+    }
+    // the temporary map in world coordinates: X_w = R_s^T (s X_tmp - t_s)
+    Xw.resize(3 * nf);
+    for (size_t k = 0; k < nf; ++k) {
+        const double v[3] = { scale * Xt[3 * k] - Rs[3], scale * Xt[3 * k + 1] - Rs[7], scale * Xt[3 * k + 2] - Rs[11] };
+        for (int q = 0; q < 3; ++q) Xw[3 * k + q] = Rs[q] * v[0] + Rs[4 + q] * v[1] + Rs[8 + q] * v[2];
+    }
+    return CLC_INTER_OK;
+}
+
+// one refinement staged and enqueued on the context's stream, its record going to pinned memory; returns the `ready` word to poll
+int refine_enqueue(clc_ctx* ctx, const double* h_X, const double* h_x, int N, const double* h_K, const double* h_Rt_in, double huber_a,
+                   int32_t** ready, double** h_rec)
+{
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t in_d = (size_t)5 * N + 16 + 12;
+    const size_t out_d = (pnp_refine_out_bytes() + 7) / 8;
+    int rc = ensure_pnp(ctx, in_d + out_d + 8);
+    if (rc != CLC_OK) return rc;
+    rc = ensure_pinned(ctx, (in_d + out_d) * sizeof(double) + 64);
+    if (rc != CLC_OK) return rc;
+    double* dX = ctx->d_pnp;
+    double* dx = dX + (size_t)3 * N;
+    double* dK = dx + (size_t)2 * N;
+    double* dRt = dK + 16;
+    double* hp = (double*)ctx->h_pin;
+    memcpy(hp, h_X, sizeof(double) * 3 * N);
+    memcpy(hp + (size_t)3 * N, h_x, sizeof(double) * 2 * N);
+    memset(hp + (size_t)5 * N, 0, sizeof(double) * 16);
+    memcpy(hp + (size_t)5 * N, h_K, sizeof(double) * 9);
+    memcpy(hp + (size_t)5 * N + 16, h_Rt_in, sizeof(double) * 12);
+    *h_rec = hp + in_d;
+    *ready = (int32_t*)((uint8_t*)*h_rec + pnp_refine_ready_offset());
+    __atomic_store_n(*ready, 0, __ATOMIC_RELAXED);
+    CLC_HIP(ctx, launch_acr_stage(hp, ctx->d_pnp, (in_d + 1) & ~(size_t)1, ctx->stream));          // inputs by a launch, not a copy command
+    CLC_HIP(ctx, launch_pnp_refine(dRt, dX, dx, nullptr, N, dK, huber_a > 0.0 ? huber_a : 16.0, 50, ctx->d_pnp + in_d, ctx->stream, &ctx->prof, nullptr,
+                                   *h_rec));
+    return CLC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int clc_essential_acransac_batch(clc_ctx* const* ctxs, clc_two_view_job* jobs, int n_jobs)
+{
+    if (n_jobs < 0 || (n_jobs > 0 && (!ctxs || !jobs))) return CLC_ERR_BAD_ARG;
+    if (n_jobs == 0) return CLC_OK;
+    const int rc0 = check_batch_contexts(ctxs, n_jobs, "essential_acransac_batch: every job needs a context of its own");
+    if (rc0 != CLC_OK) return rc0;
+    std::vector<AcrRun> runs((size_t)n_jobs);
+    std::vector<double> EF((size_t)18 * n_jobs, 0.0);
+    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i], &EF[(size_t)18 * i]);
+    drive_runs(runs);
+    int worst = CLC_OK;
+    for (int i = 0; i < n_jobs; ++i) {
+        AcrRun& r = runs[(size_t)i];
+        r.finish();
+        jobs[i].status = r.status;
+        if (jobs[i].E) memcpy(jobs[i].E, &EF[(size_t)18 * i], sizeof(double) * 9);
+        if (jobs[i].F) memcpy(jobs[i].F, &EF[(size_t)18 * i + 9], sizeof(double) * 9);
+        if (r.status != CLC_OK && worst == CLC_OK) worst = r.status;
+    }
+    return worst;
+}
+
+int clc_inter_pose_batch(clc_ctx* const* ctxs, clc_inter_pose_job* jobs, int n_jobs)
+{
+    if (n_jobs < 0 || (n_jobs > 0 && (!ctxs || !jobs))) return CLC_ERR_BAD_ARG;
+    if (n_jobs == 0) return CLC_OK;
+    const int rc0 = check_batch_contexts(ctxs, n_jobs, "inter_pose_batch: every job needs a context of its own");
+    if (rc0 != CLC_OK) return rc0;
+    for (int i = 0; i < n_jobs; ++i) {
+        clc_inter_pose_job& jb = jobs[i];
+        if (!jb.tv.E || !jb.tv.inliers || !jb.Rt_source || (jb.map_index && !jb.map_X))
+            return fail(ctxs[i], CLC_ERR_BAD_ARG, "inter_pose_batch: a job needs tv.E, tv.inliers, Rt_source (and map_X with map_index)");
+        memset(jb.Rt, 0, sizeof jb.Rt); memset(jb.cov, 0, sizeof jb.cov);
+        jb.rmse = 0.0; jb.scale = 0.0; jb.n_front = 0; jb.n_common = 0; jb.n_refined = 0; jb.stage = CLC_INTER_NO_MODEL;
+    }
+    // 1. the a-contrario five-point filters of all pairs, their chains of launches interleaved
+    std::vector<AcrRun> runs((size_t)n_jobs);
+    std::vector<double> EF((size_t)18 * n_jobs, 0.0);
+    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i].tv, &EF[(size_t)18 * i]);
+    drive_runs(runs);
+    int worst = CLC_OK;
+    struct Pending { int job; int32_t* ready; double* rec; };
+    std::vector<Pending> pend;
+    std::vector<std::vector<double>> Xw((size_t)n_jobs), x2f((size_t)n_jobs);
+    for (int i = 0; i < n_jobs; ++i) {
+        AcrRun& r = runs[(size_t)i];
+        clc_inter_pose_job& jb = jobs[i];
+        r.finish();
+        jb.tv.status = r.status;
+        memcpy(jb.tv.E, &EF[(size_t)18 * i], sizeof(double) * 9);
+        if (jb.tv.F) memcpy(jb.tv.F, &EF[(size_t)18 * i + 9], sizeof(double) * 9);
+        if (r.status != CLC_OK) { if (worst == CLC_OK) worst = r.status; continue; }
+        // 2. host geometry, 3. the refinement enqueued on the job's own context
+        jb.stage = inter_geometry(jb, Xw[(size_t)i], x2f[(size_t)i]);
+        if (jb.stage != CLC_INTER_OK) continue;
+        Pending p{ i, nullptr, nullptr };
+        const int rc = refine_enqueue(ctxs[i], Xw[(size_t)i].data(), x2f[(size_t)i].data(), jb.n_front, jb.tv.K2, jb.Rt, jb.huber_a, &p.ready, &p.rec);
+        if (rc != CLC_OK) { jb.tv.status = rc; jb.stage = CLC_INTER_NO_REFINEMENT; if (worst == CLC_OK) worst = rc; continue; }
+        pend.push_back(p);
+    }
+    // 4. collect: poll the pinned records, fall back to the stream synchronisation after 5 ms
+    const auto t0 = std::chrono::steady_clock::now();
+    for (const Pending& p : pend) {
+        clc_inter_pose_job& jb = jobs[p.job];
+        uint32_t spins = 0;
+        while (__atomic_load_n(p.ready, __ATOMIC_ACQUIRE) == 0) {
+            if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+                const hipError_t e = hipStreamSynchronize(ctxs[p.job]->stream);
+                if (e != hipSuccess || __atomic_load_n(p.ready, __ATOMIC_ACQUIRE) == 0) {
+                    jb.tv.status = fail(ctxs[p.job], CLC_ERR_HIP, "inter_pose_batch: refinement did not complete", e);
+                    jb.stage = CLC_INTER_NO_REFINEMENT;
+                    if (worst == CLC_OK) worst = jb.tv.status;
+                    break;
+                }
+            }
+        }
+        if (jb.stage != CLC_INTER_OK) continue;
+        struct { double Rt[12]; double cov[36]; double cost; double rmse; int32_t iterations; int32_t n_used; } f;
+        memcpy(&f, p.rec, sizeof f);
+        memcpy(jb.Rt, f.Rt, sizeof f.Rt);
+        memcpy(jb.cov, f.cov, sizeof f.cov);
+        jb.rmse = f.rmse;
+        jb.n_refined = f.n_used;
+    }
+    return worst;
 }
 
 } // extern "C"

@@ -488,6 +488,51 @@ int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2,
                            double* h_E, double* h_F, uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers,
                            double* error_max, double* min_nfa, int* iterations);
 
+/* Several two-view filters at once (round 5): what RobustMatcher::filterMatches runs pair after pair (RobustMatcher.hpp:455-483 ->
+ * filterEssential :153-171).  As clc_pnp_localize_ac_batch: one context per job (all on one device), ONE host thread drives all the chains
+ * of launches so that they interleave on the device; every job's result is clc_essential_acransac's for the same arguments. */
+typedef struct clc_two_view_job {
+    /* in */
+    const double* x1;         /* n x 2 undistorted pixels, image 1                        */
+    const double* x2;         /* n x 2, image 2                                           */
+    const double* K1;         /* 3 x 3 row-major                                          */
+    const double* K2;
+    int           n, img_w, img_h, max_iteration;
+    uint64_t      seed;
+    double        precision;  /* +inf: a-contrario threshold                              */
+    /* out (pointers nullable) */
+    double*       E;          /* 9                                                        */
+    double*       F;          /* 9                                                        */
+    uint8_t*      inlier_mask;/* n                                                        */
+    int32_t*      inliers;    /* n                                                        */
+    int           n_inliers, iterations, status;
+    double        error_max, min_nfa;
+} clc_two_view_job;
+int clc_essential_acransac_batch(clc_ctx* const* ctxs, clc_two_view_job* jobs, int n_jobs);
+
+/* The inter-camera step of ColoC::interPoseEstimator(source, dest) between the pair's putative matches and the covariance intersection
+ * (coloc.hpp:296-340), for several camera pairs at once: a-contrario five-point filter (filterMatchesPair, :296) -> relative pose from
+ * E with the chirality vote (RobustMatcher.hpp:176-183) -> the pair's temporary map triangulated in the source camera's frame (:306) ->
+ * its scale against the global map through the features both hold (map_index; colocUtils.hpp:184-211) -> the destination's pose through
+ * the source's, refined against the temporary map with its 6 x 6 covariance (refinePose, :340; Huber(huber_a)).  tv.x1 = the SOURCE
+ * frame's features, tv.x2 = the destination's; tv.E and tv.inliers must be given.  stage says how far a job got. */
+enum { CLC_INTER_OK = 0, CLC_INTER_NO_MODEL = 1 /* filter found < 13 inliers */, CLC_INTER_NO_RELATIVE_POSE = 2 /* < 8 points in front of both cameras */,
+       CLC_INTER_NO_SCALE = 3 /* < 8 features shared with the global map */, CLC_INTER_NO_REFINEMENT = 4 };
+typedef struct clc_inter_pose_job {
+    clc_two_view_job tv;
+    /* in */
+    const int32_t* map_index; /* tv.n: index of correspondence i's SOURCE feature in the global map, -1 = none (nullable: no scale) */
+    const double*  map_X;     /* global map points, 3 doubles each                         */
+    const double*  Rt_source; /* 12: [R|t] of the source camera, x_cam = R X + t           */
+    double         huber_a;   /* <= 0: 16                                                  */
+    /* out */
+    double         Rt[12];    /* the destination's pose through the source, refined        */
+    double         cov[36];   /* [angle-axis | translation] order, as clc_pnp_refine       */
+    double         rmse, scale;
+    int            n_front, n_common, n_refined, stage;
+} clc_inter_pose_job;
+int clc_inter_pose_batch(clc_ctx* const* ctxs, clc_inter_pose_job* jobs, int n_jobs);
+
 /* ---- fusion (host arithmetic; no GPU work) ---------------------------------------------------------
  * Covariance intersection of two 3-D position estimates as CoLoC fuses intra- and inter-camera poses
  * (include/coloc/CovIntersection.hpp:24-49, called at include/coloc/coloc.hpp:362-389): omega in [0,1]

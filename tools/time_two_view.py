@@ -1,0 +1,26 @@
+"""clc_essential_acransac on bench.py's two-view problem (1000 correspondences, 30 % outliers): p50 over 100 solves, rounds and iterations;
+under rocprofv3 --kernel-trace --stats the per-kernel averages of its launches.  usage: time_two_view.py [n_pairs_in_batch]"""
+import os, sys, time
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np
+from coloc_amd import Context
+rng2 = np.random.default_rng(11)
+Nc = 1000
+Xs = np.stack([rng2.uniform(-5, 5, Nc), rng2.uniform(-5, 5, Nc), rng2.uniform(4, 20, Nc)], 1)
+Kc = np.array([[1000.0, 0, 640], [0, 1000.0, 360], [0, 0, 1]])
+ang = 0.2
+Rc = np.array([[np.cos(ang), 0, -np.sin(ang)], [0, 1, 0], [np.sin(ang), 0, np.cos(ang)]])
+p1 = Xs @ Kc.T; p1 = p1[:, :2] / p1[:, 2:3]
+p2 = (Xs @ Rc.T + np.array([0.5, 0.1, 0.2])) @ Kc.T; p2 = p2[:, :2] / p2[:, 2:3] + rng2.normal(0, 0.5, (Nc, 2))
+oi = rng2.choice(Nc, 300, replace=False)
+p2[oi] = np.stack([rng2.uniform(0, 1280, 300), rng2.uniform(0, 720, 300)], 1)
+ctx = Context(device=0, detector=False, matcher=False)
+te, its, rounds = [], [], []
+for it in range(105):
+    t1 = time.perf_counter()
+    r = ctx.essential_acransac(p1, p2, Kc, Kc, (1280, 720), max_iteration=256, seed=it + 1)
+    te.append((time.perf_counter() - t1) * 1e3); its.append(r["iterations"]); rounds.append(r.get("rounds", -1))
+te = np.sort(te[5:])
+print("essential_acransac p50 %.3f ms  p95 %.3f  iterations median %.0f  rounds median %.0f  inliers %d" % (te[len(te) // 2], te[int(len(te) * .95)], np.median(its), np.median(rounds), len(r["inliers"])))
+ctx.close()
