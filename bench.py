@@ -972,9 +972,31 @@ def main():
                 t1 = time.perf_counter()
                 ctx.essential_ransac(p1, p2, Kc, Kc, n_samples=256, seed=it + 1, thr2=4.0)
                 tf.append((time.perf_counter() - t1) * 1e3)
-            out["two_view"] = {"what": "clc_essential_acransac: a-contrario five-point RANSAC (RobustMatcher.hpp:161-171), 256 iterations max, 1000 correspondences",
+            out["two_view"] = {"what": "clc_essential_acransac: a-contrario five-point RANSAC (RobustMatcher.hpp:161-171), 256 iterations max, 1000 correspondences; "
+                                       "a round = two launches since round 5 (replay + samples + five-point solve ~44 us; nfa ~11 us)",
                                "p50_ms": float(np.median(te[5:])), "inliers": int(len(r["inliers"])), "iterations": int(r["iterations"]),
                                "fixed_threshold_p50_ms": float(np.median(tf[5:]))}
+            # the same filter for 4 / 8 camera pairs in ONE clc_essential_acransac_batch call (what a frame of the streaming loop asks for):
+            # the chains of launches interleave on the device, results job by job those of the single calls
+            from coloc_amd.abi import essential_acransac_batch
+            for npair in (4, 8):
+                tcs = [Context(device=dev_index, detector=False, matcher=False) for _ in range(npair)]
+                try:
+                    tb, same = [], True
+                    for it in range(30):
+                        probs = [(p1, p2, Kc, Kc, (1280, 720), it + 1 + k) for k in range(npair)]
+                        t1 = time.perf_counter()
+                        rb = essential_acransac_batch(tcs, probs)
+                        tb.append((time.perf_counter() - t1) * 1e3)
+                    one = ctx.essential_acransac(p1, p2, Kc, Kc, (1280, 720), max_iteration=256, seed=30 + npair - 1)
+                    same = bool(np.array_equal(rb[-1]["inliers"], one["inliers"]) and np.array_equal(rb[-1]["E"], one["E"]))
+                    out["two_view"]["batch_of_%d" % npair] = {"per_pair_p50_ms": float(np.median(tb[5:])) / npair, "batch_p50_ms": float(np.median(tb[5:])),
+                                                               "identical_to_single_call": same}
+                    if not same:
+                        raise RuntimeError("batched two-view filter differs from the single call")
+                finally:
+                    for c_ in tcs:
+                        c_.close()
 
         def sec_shares():
             # What the driver's N = 2 / 4 / 8 runs will depend on, measured HERE on one GPU (informational, no collective, no

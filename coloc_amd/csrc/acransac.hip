@@ -26,6 +26,7 @@
 #include "clc_internal.h"
 #include "clc_acr.h"
 #include "p3p.h"
+#include "fivept_wave.h"
 
 namespace clc {
 
@@ -871,6 +872,56 @@ __global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ 
                           reinterpret_cast<uint64_t*>(acr_lds), &pre);
 }
 
+// ---- the five-point round in TWO launches (round 5) ---------------------------------------------------------------------------
+// The two-view round was solve -> nfa -> select: three launches, 39 + 11 + 6.5 us of kernels and three launch boundaries of ~4.4 us.
+// The select launch goes the way it went for resection: every solver workgroup replays the previous round for itself (one wave, one
+// memory round trip) to learn this round's batch, iteration numbers and index set, draws its own sample and solves it; the last
+// workgroup of the grid is the keeper (side effects of the replayed round, the word the host polls).  The nfa launch follows -- the
+// solve is one WAVE per iteration (ten models), the nfa one workgroup per MODEL, and a slot workgroup cannot start before its solve
+// has ended, so the two stay two launches; state, slots, sorted lists and models live in two copies indexed by launch parity exactly
+// as for resection.  The solve is fpw::models_of_sample, the one not-inlined body fivept_kernel runs: same bits as the hypotheses the
+// tests hand to the sequential oracle.
+__global__ __launch_bounds__(64) void acr_solve5_kernel(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
+                                                        const int par, const AcrProblem pb, uint32_t* __restrict__ sorted /* [2][slots * n] */,
+                                                        double* __restrict__ models /* [2][slots * 18] */,
+                                                        uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
+                                                        unsigned long long* __restrict__ h_word, const AcrFinish fin)
+{
+    constexpr int kSlots = kAcrMaxBatch * 10;
+    __shared__ AcrCore s_core;
+    __shared__ AcrPick s_pick;
+    __shared__ AcrState s_full;
+    const int tid = threadIdx.x, it = blockIdx.x;
+    const bool keeper = blockIdx.x == gridDim.x - 1;
+    const AcrState* st_in = states + (par ^ 1);
+    const AcrHyp* hyp_in = hyps + (size_t)(par ^ 1) * kSlots;
+    const uint32_t* sorted_in = sorted + (size_t)(par ^ 1) * kSlots * pb.n;
+    const double* models_in = models + (size_t)(par ^ 1) * kSlots * 18;
+    {
+        AcrCore c = acr_core_load(st_in);
+        AcrPick pick{ -1, 0, 0 };
+        if (c.evaluated && c.cur_batch > 0) pick = acr_select_wave<10>(pb, c, hyp_in, tid);
+        c.evaluated = 1;
+        if (tid == 0) { s_core = c; s_pick = pick; }
+    }
+    __syncthreads();
+    const AcrCore s = s_core;
+    const AcrPick pick = s_pick;
+    if (keeper) {
+        acr_keep(pb, s, pick, models_in, sorted_in, st_in, states + par, best_inliers, index_set, h_word, fin, s_full, tid, 64);
+        return;
+    }
+    if (it >= s.cur_batch) return;                                   // the grid covers an upper bound of the batch
+    const uint32_t* win = pick.best_h >= 0 ? sorted_in + (size_t)pick.best_h * pb.n : nullptr;
+    const uint32_t* src = acr_sample_source(s, pick, win, best_inliers, index_set);
+    uint32_t pos[5];
+    clc_acr_sample_t<5>(pb.seed, (uint32_t)(s.iter + it), (uint32_t)s.n_index, pos);
+    int id[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) id[j] = (int)(src ? src[pos[j]] : pos[j]);
+    fpw::models_of_sample(pb.a, pb.b, pb.K1, pb.K2, id[0], id[1], id[2], id[3], id[4], pb.n, models + ((size_t)par * kSlots + (size_t)it * 10) * 18);
+}
+
 // ---- finish: mask, inlier list and the result record, straight into pinned host memory ---------------------------
 __global__ __launch_bounds__(256) void acr_finish_kernel(const AcrProblem pb, const AcrState* __restrict__ state,
                                                          const uint32_t* __restrict__ best_inliers, uint8_t* __restrict__ d_mask,
@@ -961,6 +1012,33 @@ hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_state
     if (P == 4096) return acr_launch_round_p3p<4>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
     if (P == 8192) return acr_launch_round_p3p<8>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
     return acr_launch_round_p3p<16>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+}
+
+// the two-view round: acr_solve5_kernel (replay + samples + five-point; the keeper publishes the PREVIOUS round's word) and the nfa
+// launch over this round's models, both on the copies of launch parity `par`
+hipError_t launch_acr_round_5pt(const AcrProblem& pb, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted, double* d_models,
+                                uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word, hipStream_t stream,
+                                int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res)
+{
+    const int B = batch_bound < 1 ? 1 : (batch_bound > kAcrMaxBatch ? kAcrMaxBatch : batch_bound);
+    constexpr int kSlots = kAcrMaxBatch * 10;
+    int P = 64;
+    while (P < pb.n) P <<= 1;
+    const AcrFinish fin{ d_mask, d_res, h_mask, h_inliers, h_res };
+    hipLaunchKernelGGL(acr_solve5_kernel, dim3(B + 1 /* the keeper */), dim3(64), 0, stream, d_states, d_hyps, par, pb, d_sorted, d_models,
+                       d_best_inliers, d_index_set, h_word, fin);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const double* mo = d_models + (size_t)par * kSlots * 18;
+    AcrHyp* hy = d_hyps + (size_t)par * kSlots;
+    uint32_t* so = d_sorted + (size_t)par * kSlots * pb.n;
+    const AcrState* stp = d_states + par;                 // what this round's keeper has just written: cur_batch = this round's batch
+    if (P <= 1024) e = acr_launch_nfa<1>(pb, B, P, mo, hy, so, stp, stream);
+    else if (P == 2048) e = acr_launch_nfa<2>(pb, B, P, mo, hy, so, stp, stream);
+    else if (P == 4096) e = acr_launch_nfa<4>(pb, B, P, mo, hy, so, stp, stream);
+    else if (P == 8192) e = acr_launch_nfa<8>(pb, B, P, mo, hy, so, stp, stream);
+    else e = acr_launch_nfa<16>(pb, B, P, mo, hy, so, stp, stream);
+    return e;
 }
 
 // inputs of a solve: pinned host block -> device workspace, by a launch instead of a copy command (a copy command runs on another

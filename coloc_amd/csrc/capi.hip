@@ -1787,6 +1787,7 @@ struct AcrRun {
     AcrProblem pb{};
     hipStream_t st = nullptr;
     int launches = 0, bound = 0, reserve0 = 0;
+    bool five_point_three_launches = false;
     uint32_t round = 0, spins = 0;
     std::chrono::steady_clock::time_point wait_start;
     unsigned long long* h_word = nullptr;
@@ -1813,10 +1814,16 @@ struct AcrRun {
             // out of launch r + 1
             CLC_HIP(ctx, launch_acr_round_p3p(pb, launches & 1, d_state, d_hyp, d_sorted, d_models, d_best, d_index, h_word, st, S, d_mask,
                                               d_res, nullptr, p_inl, h_res));
-        } else {
+        } else if (five_point_three_launches) {
+            // rounds 2-4's form (CLC_ACR_5PT_LAUNCHES=3, A/B runs): solve, nfa, select as three launches on ONE copy of the state
             CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, S, d_models, st, d_cnt));
             CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st, S, d_mask, d_res,
                                           nullptr, p_inl, h_res));
+        } else {
+            // two launches: replay of the previous round + this round's samples + five-point solve, then nfa; the word of round r
+            // comes out of round r + 1's first launch
+            CLC_HIP(ctx, launch_acr_round_5pt(pb, launches & 1, d_state, d_hyp, d_sorted, d_models, d_best, d_index, h_word, st, S, d_mask,
+                                              d_res, nullptr, p_inl, h_res));
         }
         ++launches;
         return CLC_OK;
@@ -1856,7 +1863,9 @@ struct AcrRun {
         const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d + samples_d;
         // the resection round is ONE launch per round that reads what the launch before it wrote: two copies of state, models, slots
         // and sorted lists, indexed by launch parity (acransac.hip: acr_round_kernel)
-        const int copies = kind == 0 ? 2 : 1;
+        { const char* e = getenv("CLC_ACR_5PT_LAUNCHES"); five_point_three_launches = kind == 1 && e && e[0] == '3'; }
+        const bool two_copies = kind == 0 || !five_point_three_launches;
+        const int copies = two_copies ? 2 : 1;
         const size_t models_d = (size_t)copies * kAcrMaxBatch * M * md;
         const size_t hyp_d = dbl(acr_hyp_bytes() * copies * kAcrMaxBatch * M);
         const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)copies * kAcrMaxBatch * M * N);
@@ -1901,7 +1910,7 @@ struct AcrRun {
         int32_t* h_samples = (int32_t*)((double*)h_states + state_d);
         memset(h_states, 0, 2 * sizeof(AcrState));
         // resection: launch 0 (parity 0) reads copy 1; the five-point path keeps its single state in copy 0
-        AcrState* h_init = h_states + (kind == 0 ? 1 : 0);
+        AcrState* h_init = h_states + (two_copies ? 1 : 0);
         h_init->min_nfa = INFINITY; h_init->error_max = INFINITY;
         h_init->best_iter = -1;
         h_init->reserve = max_iteration / 10;
@@ -1910,7 +1919,7 @@ struct AcrRun {
         h_init->ac_mode = std::isinf(precision) ? 1 : 0;
         h_init->grow = 32;
         h_init->cur_batch = h_init->n_iter < 32 ? h_init->n_iter : 32;
-        if (kind == 1) {                                   // (the resection round draws its own samples on the device)
+        if (kind == 1 && five_point_three_launches) {      // (the other rounds draw their own samples on the device)
             const int nb = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
             for (int it = 0; it < nb; ++it) {
                 uint32_t pos[8];
@@ -1956,7 +1965,7 @@ struct AcrRun {
         // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
         reserve0 = h_init->reserve;
         bound = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
-        int rc2 = enqueue_round(kind == 0 ? h_init->cur_batch : bound);     // (the resection launch takes its first batch as it stands)
+        int rc2 = enqueue_round(two_copies ? h_init->cur_batch : bound);     // (a replaying launch takes its first batch as it stands)
         if (rc2 != CLC_OK) return drained(rc2);
         rc2 = enqueue_round(bound);                                     // speculative: the round after the one being waited for
         if (rc2 != CLC_OK) return drained(rc2);

@@ -642,13 +642,6 @@ struct EpiResult {      // one packed record so the host needs a single D2H copy
     int32_t count;
 };
 
-__device__ __forceinline__ void normalise_px(const double* __restrict__ K, double u, double v, double* out)
-{
-    const double yn = (v - K[5]) / K[4];
-    out[0] = (u - K[2] - K[1] * yn) / K[0];
-    out[1] = yn;
-}
-
 __global__ __launch_bounds__(64) void fivept_kernel(const double* __restrict__ x1, const double* __restrict__ x2,
                                                     const double* __restrict__ K1, const double* __restrict__ K2,
                                                     const int32_t* __restrict__ samples, const int S, const int N,
@@ -656,46 +649,12 @@ __global__ __launch_bounds__(64) void fivept_kernel(const double* __restrict__ x
 {
     // ONE sample per wave: the solver is full of data-dependent steps (pivoting, iterations that stop on convergence), and 64
     // different problems in one wave serialise every divergent branch -- measured 4.8 ms for 256 samples with a problem per
-    // lane.  The wave's lanes share the work of their problem instead (csrc/fivept_wave.h); lane 0 writes the result
+    // lane.  The wave's lanes share the work of their problem instead (csrc/fivept_wave.h); lane 0 writes the result.  The body is
+    // fpw::models_of_sample: one not-inlined function shared with the a-contrario round's own solve (acransac.hip).
     const int sidx = blockIdx.x;
     if (sidx >= S || (n_dev && sidx >= *n_dev)) return;
-    double q1[5][2], q2[5][2];
-    bool ok = true;
-    for (int p = 0; p < 5; ++p) {
-        int i = samples[5 * sidx + p];
-        if (i < 0 || i >= N) { ok = false; i = 0; }
-        normalise_px(K1, x1[2 * i], x1[2 * i + 1], q1[p]);
-        normalise_px(K2, x2[2 * i], x2[2 * i + 1], q2[p]);
-    }
-    __shared__ FptWorkspace ws;      // one problem per wave: every lane reads and writes the same values
-    __shared__ double E[90];
-    const int n = ok ? fpw::solve(q1, q2, E, ws) : 0;
-    // F = K2^-T E K1^-1 for upper-triangular K = [fx s cx; 0 fy cy; 0 0 1]: K^-1 = [1/fx, -s/(fx fy), (s cy - cx fy)/(fx fy); 0, 1/fy, -cy/fy; 0 0 1]
-    double A1[9], A2[9];
-    {
-        const double* Ks[2] = { K1, K2 };
-        double* As[2] = { A1, A2 };
-        for (int w = 0; w < 2; ++w) {
-            const double fx = Ks[w][0], sk = Ks[w][1], cx = Ks[w][2], fy = Ks[w][4], cy = Ks[w][5];
-            double* A = As[w];
-            A[0] = 1.0 / fx; A[1] = -sk / (fx * fy); A[2] = (sk * cy - cx * fy) / (fx * fy);
-            A[3] = 0.0; A[4] = 1.0 / fy; A[5] = -cy / fy;
-            A[6] = 0.0; A[7] = 0.0; A[8] = 1.0;
-        }
-    }
-    if (threadIdx.x != 0) return;
-    double* out = FE + (size_t)180 * sidx;
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int k = 0; k < 10; ++k) {
-        if (k >= n) { for (int e = 0; e < 18; ++e) out[18 * k + e] = qnan; continue; }
-        const double* Ek = E + 9 * k;
-        double T[9];                                   // T = E K1^-1
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) T[3 * r + c] = Ek[3 * r] * A1[c] + Ek[3 * r + 1] * A1[3 + c] + Ek[3 * r + 2] * A1[6 + c];
-        for (int r = 0; r < 3; ++r)                    // F = K2^-T T : F[r][c] = sum_m A2[m][r] T[m][c]
-            for (int c = 0; c < 3; ++c) out[18 * k + 3 * r + c] = A2[r] * T[c] + A2[3 + r] * T[3 + c] + A2[6 + r] * T[6 + c];
-        for (int e = 0; e < 9; ++e) out[18 * k + 9 + e] = Ek[e];
-    }
+    const int32_t* sp = samples + 5 * sidx;
+    fpw::models_of_sample(x1, x2, K1, K2, sp[0], sp[1], sp[2], sp[3], sp[4], N, FE + (size_t)180 * sidx);
 }
 
 // score the F part of every slot (stride 18 doubles)
