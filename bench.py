@@ -678,6 +678,7 @@ def main():
                        "Mdesc_per_s_kernel": (n_desc_launch / clatch_us) if clatch_us else None,
                        "Mdesc_per_s_step": len(cams) * NKP * world / (dt / args.steps) / 1e6},
             "roofline": roof,
+            "k2nn_device": ctx.k2nn_device_info(),        # XCDs / CUs the sweep planner reads from the device, and where its unequal shares come from
             "launch_mode": ("hipGraph replay" if graph is not None else
                             ("eager launches, consecutive steps on ALTERNATING lanes (two contexts / streams / descriptor arenas): step i's sweep runs beside "
                              "step i + 1's pyramid + CLATCH; every step does all of its work, results identical to the one-stream loop's; "

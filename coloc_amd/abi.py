@@ -76,7 +76,7 @@ EXPORTS = [
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
     "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_describe_match_pair_dev", "clc_essential_acransac_batch", "clc_inter_pose_batch", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
-    "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
+    "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_k2nn_device_info", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
     "clc_mc_gather_enqueue_dev", "clc_mc_match_enqueue_dev", "clc_mc_counts", "clc_match_jobs_counted_dev",
 ]
@@ -204,6 +204,7 @@ def load_library():
     lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
     lib.clc_k2nn_queries_per_block.argtypes = [vp]
     lib.clc_k2nn_plan_query.argtypes = [vp, ci, ci, vp]
+    lib.clc_k2nn_device_info.argtypes = [vp, vp, vp]
     _lib = lib
     return lib
 
@@ -593,6 +594,16 @@ class Context:
     @property
     def k2nn_queries_per_block(self):
         return int(self.lib.clc_k2nn_queries_per_block(self.h))
+
+    def k2nn_device_info(self):
+        """clc_k2nn_device_info: what the sweep planner knows about the device and where its unequal shares come from (dict)."""
+        info = (C.c_int32 * 8)()
+        us = (C.c_float * 4)()
+        self._chk(self.lib.clc_k2nn_device_info(self.h, info, us))
+        d = dict(zip(("xcds", "cus", "default_target_blocks", "bias_a", "bias_b", "bias_source", "kernel_xcds", "target_blocks_env"), [int(v) for v in info]))
+        d["bias_source"] = ("default", "CLC_K2NN_BIAS", "probe")[d["bias_source"]]
+        d["probe_us"] = dict(zip(("295:264", "311:256", "326:249", "326:233"), [float(v) for v in us]))
+        return d
 
     def k2nn_plan_query(self, nq, nt):
         """clc_k2nn_plan_query: how one nq x nt pair would be cut into sweep workgroups (dict)."""

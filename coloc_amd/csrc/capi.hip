@@ -121,6 +121,9 @@ struct clc_ctx {
     int bias_a = 326, bias_b = 249;  // matrix sweep, one-round single-job plans: train share of a workgroup on wave slot 0 / 1 in 1/256 of the
                                      // equal share (k2nn.hip; measured optimum 21 : 16 : 12-13 tiles at 10k x 10k); CLC_K2NN_BIAS=a,b, 0,0 = equal shares
     bool xcd_map = true;         // XCD-aware K2NN tile order (CLC_K2NN_XCD_MAP=0 switches it off for A/B runs)
+    K2nnDevice k2dev{};          // XCDs and CUs of this context's device (the sweep planner's balance arguments)
+    int bias_source = 0;         // 0: built-in default, 1: CLC_K2NN_BIAS, 2: timed probe on this device (k2nn_probe_bias)
+    float bias_probe_us[4] = {}; // the probe's sweep times per candidate (0: not probed)
     // pair step (clc_describe_match_pair_dev): the second stream the chunk sweeps run on, fork / join events, the describe launch's
     // progress counters, the gates' error word (pinned host memory)
     hipStream_t stream2 = nullptr;
@@ -227,13 +230,14 @@ int cache_mode_default()
     return CLC_DESC_CACHE_VERIFY;
 }
 
-// matrix: 3 workgroups of 4 waves per CU (152 VGPRs); popcount: 10 rounds of 8-wave workgroups (measured optima)
-int default_target_blocks(int formulation) { return formulation == K2NN_POPCOUNT ? 2560 : 768; }
+// matrix: 3 workgroups of 4 waves per CU (152 VGPRs) = ONE resident round; popcount: 10 workgroups of 8 waves per CU (measured optima);
+// per CU of the context's device (768 / 2560 on MI355X's 256)
+int default_target_blocks(int formulation, const K2nnDevice& dev = K2nnDevice{}) { return (int)((formulation == K2NN_POPCOUNT ? 10u : 3u) * dev.n_cu); }
 
 int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
 {
-    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
-    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b);
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b, ctx->k2dev);
     const int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;
     if (!plan.atomic_merge) ctx->partial_dirty = true;           // slab mode scribbles over the armed rows
@@ -244,6 +248,79 @@ int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
     const hipError_t e = launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, &ctx->prof, ctx->formulation);
     if (e != hipSuccess) { ctx->partial_dirty = true; return fail(ctx, CLC_ERR_HIP, "launch_k2nn", e); }
     return CLC_OK;
+}
+
+// ---- which unequal shares suit THIS device (round 5) ---------------------------------------------------------------------------------
+// The share a slot-0 / slot-1 workgroup takes of a one-round sweep has an optimum that moves from device to device (19 : 17 ... 21 : 15
+// tiles of a 313-tile train set across the MI355X boxes of rounds 4-5: the chips hold different clocks under the sweep's load).  The first
+// matcher context a process creates on a device times the 10k x 10k sweep under four candidate pairs -- behind 4 ms of the same sweep, so
+// that the clocks are up -- and every later context on that device takes the winner.  ~15 ms once per process and device; results do not
+// depend on it (the fold is order-free).  CLC_K2NN_BIAS=a,b or CLC_K2NN_PROBE=0 skip it.
+__global__ void k2nn_probe_fill_kernel(uint32_t* p, const size_t n, const uint32_t salt)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i * 2654435761u + salt;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = x;
+}
+struct K2nnProbeCache { std::mutex mu; bool done[64] = {}; int a[64] = {}, b[64] = {}; float us[64][4] = {}; };
+static K2nnProbeCache& probe_cache() { static K2nnProbeCache c; return c; }
+static constexpr int kProbeCand[4][2] = { { 295, 264 }, { 311, 256 }, { 326, 249 }, { 326, 233 } };     // 19:17, 20:16.5, 21:16 (rounds 4's default), 21:15
+
+static void k2nn_probe_bias(clc_ctx* ctx)
+{
+    const int N = 10000;
+    if (!ctx->has_mat || ctx->mopts.maxkp < (uint32_t)N || ctx->formulation == K2NN_POPCOUNT || ctx->device < 0 || ctx->device >= 64) return;
+    if (ctx->k2dev.n_xcd != kK2nnXcds || ctx->target_blocks > 0) return;
+    if (const char* e = getenv("CLC_K2NN_PROBE")) if (e[0] == '0') return;
+    K2nnProbeCache& pc = probe_cache();
+    std::lock_guard<std::mutex> lk(pc.mu);
+    const int d = ctx->device;
+    if (!pc.done[d]) {
+        pc.done[d] = true; pc.a[d] = ctx->bias_a; pc.b[d] = ctx->bias_b;             // whatever happens below: probe once
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
+        const size_t words = (size_t)N * CLC_DESC_BYTES / 4;
+        hipLaunchKernelGGL(k2nn_probe_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->d_q, words, 1u);
+        hipLaunchKernelGGL(k2nn_probe_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->d_t, words, 2u);
+        std::vector<K2nnJobDev> jobs(1);
+        auto sweep = [&](const int a, const int b, const int reps) -> bool {
+            const int sa = ctx->bias_a, sb = ctx->bias_b;
+            ctx->bias_a = a; ctx->bias_b = b;
+            bool ok = true;
+            for (int r = 0; r < reps && ok; ++r) {
+                jobs[0] = K2nnJobDev{};
+                jobs[0].q = (const uint4*)ctx->d_q; jobs[0].t = (const uint4*)ctx->d_t; jobs[0].out = ctx->d_match;
+                jobs[0].nq = (uint32_t)N; jobs[0].nt = (uint32_t)N; jobs[0].thr = 40u;
+                ok = run_jobs(ctx, jobs, ctx->stream) == CLC_OK;
+            }
+            ctx->bias_a = sa; ctx->bias_b = sb;
+            return ok;
+        };
+        bool ok = sweep(ctx->bias_a, ctx->bias_b, 160);                                  // ~4 ms: clocks up
+        float best = 0.f; int best_i = -1;
+        for (int pass = 0; pass < 2 && ok; ++pass)                                        // two interleaved passes, the smaller time counts
+            for (int c = 0; c < 4 && ok; ++c) {
+                ok = hipEventRecord(e0, ctx->stream) == hipSuccess && sweep(kProbeCand[c][0], kProbeCand[c][1], 40) && hipEventRecord(e1, ctx->stream) == hipSuccess &&
+                     hipEventSynchronize(e1) == hipSuccess;
+                float ms = 0.f;
+                if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+                    const float us = ms * 1000.f / 40.f;
+                    if (pc.us[d][c] == 0.f || us < pc.us[d][c]) pc.us[d][c] = us;
+                }
+            }
+        if (ok)
+            for (int c = 0; c < 4; ++c) if (pc.us[d][c] > 0.f && (best_i < 0 || pc.us[d][c] < best)) { best = pc.us[d][c]; best_i = c; }
+        // the winner must beat rounds 4's default by more than the noise of such a short measurement (1 %), else the default stays
+        if (ok && best_i >= 0 && pc.us[d][2] > 0.f && best < 0.99f * pc.us[d][2]) { pc.a[d] = kProbeCand[best_i][0]; pc.b[d] = kProbeCand[best_i][1]; }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (!ok) { ctx->partial_dirty = true; for (int c = 0; c < 4; ++c) pc.us[d][c] = 0.f; }
+    }
+    ctx->bias_a = pc.a[d]; ctx->bias_b = pc.b[d];
+    for (int c = 0; c < 4; ++c) ctx->bias_probe_us[c] = pc.us[d][c];
+    if (pc.us[d][0] > 0.f) ctx->bias_source = 2;
 }
 
 } // namespace
@@ -293,6 +370,11 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
     } while (0)
     CREATE_HIP(hipSetDevice(device_id));
     CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ctx->k2dev.n_cu = (uint32_t)v;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeNumberOfXccs, device_id) == hipSuccess && v > 0) ctx->k2dev.n_xcd = (uint32_t)v;
+    }
     if (const char* e = getenv("CLC_K2NN_TARGET_BLOCKS")) {
         const int v = atoi(e);
         if (v > 0) ctx->target_blocks = v;
@@ -311,7 +393,7 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
     if (const char* e = getenv("CLC_PAIR_TARGET_BLOCKS")) ctx->pair_target_blocks = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("CLC_K2NN_BIAS")) {
         int a = 0, b = 0;
-        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a < 1024 && b < 1024) { ctx->bias_a = a; ctx->bias_b = b; }
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a < 1024 && b < 1024) { ctx->bias_a = a; ctx->bias_b = b; ctx->bias_source = 1; }
     }
     if (const char* e = getenv("CLC_K2NN_FORMULATION"))
         ctx->formulation = (e[0] == 'p' || e[0] == '1') ? K2NN_POPCOUNT : ((e[0] == '2' || strstr(e, "plain")) ? K2NN_MATRIX_PLAIN : K2NN_MATRIX);
@@ -352,6 +434,7 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
     }
     CREATE_HIP(hipStreamSynchronize(ctx->stream));
 #undef CREATE_HIP
+    if (ctx->bias_source == 0) k2nn_probe_bias(ctx);
     *out_ctx = ctx;
     return CLC_OK;
 }
@@ -742,10 +825,19 @@ int clc_k2nn_plan_query(const clc_ctx* ctx, int nq, int nt, int32_t* info)
     if (!ctx || nq < 0 || nt < 0 || !info) return CLC_ERR_BAD_ARG;
     K2nnJobDev jb{};
     jb.nq = (uint32_t)nq; jb.nt = (uint32_t)nt;
-    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
-    const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b);
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev);
+    const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b, ctx->k2dev);
     info[0] = (int32_t)jb.qblocks; info[1] = (int32_t)jb.splits; info[2] = (int32_t)jb.t_per_split; info[3] = plan.atomic_merge ? 1 : 0;
     info[4] = (int32_t)jb.bias_a; info[5] = (int32_t)jb.bias_b; info[6] = k2nn_queries_per_block(ctx->formulation); info[7] = target;
+    return CLC_OK;
+}
+
+int clc_k2nn_device_info(const clc_ctx* ctx, int32_t* info, float* probe_us)
+{
+    if (!ctx || !info) return CLC_ERR_BAD_ARG;
+    info[0] = (int32_t)ctx->k2dev.n_xcd; info[1] = (int32_t)ctx->k2dev.n_cu; info[2] = default_target_blocks(ctx->formulation, ctx->k2dev);
+    info[3] = ctx->bias_a; info[4] = ctx->bias_b; info[5] = ctx->bias_source; info[6] = (int32_t)kK2nnXcds; info[7] = ctx->target_blocks;
+    if (probe_us) for (int c = 0; c < 4; ++c) probe_us[c] = ctx->bias_probe_us[c];
     return CLC_OK;
 }
 
@@ -761,8 +853,8 @@ int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t,
     jobs[0] = K2nnJobDev{};
     jobs[0].q = (const uint4*)d_q; jobs[0].t = (const uint4*)d_t; jobs[0].out = d_match;
     jobs[0].nq = (uint32_t)nq; jobs[0].nt = (uint32_t)nt; jobs[0].thr = 40u;
-    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation);
-    const K2nnPlan plan = k2nn_plan(jobs.data(), 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b);
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b, ctx->k2dev);
     if (!plan.atomic_merge) return fail(ctx, CLC_ERR_CAPACITY, "k2nn_clock_check: train set too large");
     int rc = ensure_partial(ctx, plan.partial_elems);
     if (rc != CLC_OK) return rc;
@@ -921,7 +1013,7 @@ int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_
     // every chunk's sweep planned on its own (its launch has the slots the describe launch leaves to itself), rows and counters of
     // the chunks one behind the other in the context's workspace
     const int target = ctx->pair_target_blocks > 0 ? ctx->pair_target_blocks
-                                                   : (ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation));
+                                                   : (ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev));
     std::vector<K2nnJobDev> jobs(nchunks);
     size_t base = 0;
     uint32_t g0 = 0;
@@ -933,7 +1025,7 @@ int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_
         jb.t = (const uint4*)d_desc[1];
         jb.out = d_match + r0;
         jb.nq = r1 - r0; jb.nt = nt; jb.thr = (uint32_t)(uint8_t)threshold;
-        const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, 0, 0);
+        const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, 0, 0, ctx->k2dev);
         if (!plan.atomic_merge) return fail(ctx, CLC_ERR_STATE, "describe_match_pair: chunk plan without the atomic fold");
         jb.partial_off += (uint32_t)base;
         jb.cnt_off += (uint32_t)(2u * base);

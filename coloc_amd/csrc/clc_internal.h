@@ -111,6 +111,13 @@ struct K2nnJobDev {
     // (0 = equal shares); the slot-2 splits of a query block take what is left.
     uint32_t     bias_a, bias_b;
     uint32_t     bias_magic;  // ceil(2^32 / qblocks): workgroup id / qblocks as a multiply-high (exact for ids below 2^16)
+    uint32_t     slot_wgs;    // biased plans: workgroup ids per wave slot in the plan's id space (CUs of one XCD, or of the device)
+};
+// what the planner needs to know about the device (clc_ctx_create fills it from the HIP device attributes)
+static constexpr uint32_t kK2nnXcds = 8;       // XCDs the sweep kernel's workgroup map is compiled for (every gfx950 part has eight)
+struct K2nnDevice {
+    uint32_t n_xcd = kK2nnXcds;                // hipDeviceAttributeNumberOfXccs
+    uint32_t n_cu = 256;                       // multiProcessorCount
 };
 // the sizes a sweep workgroup works with (scalar loads when the counts live in device memory)
 __device__ __forceinline__ uint32_t k2nn_job_nq(const K2nnJobDev& job)
@@ -142,7 +149,8 @@ struct K2nnPlan {
 enum { K2NN_MATRIX = 0, K2NN_POPCOUNT = 1, K2NN_MATRIX_PLAIN = 2 };   // PLAIN: round 2's tile loop (no MFMA / top-2 interleave)
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
 // bias_a / bias_b: train share of a workgroup on wave slot 0 / 1 in 1/256 of the equal share (0: equal shares); used by single-job one-round plans only
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true, int formulation = K2NN_MATRIX, int bias_a = 0, int bias_b = 0);
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true, int formulation = K2NN_MATRIX, int bias_a = 0, int bias_b = 0,
+                   K2nnDevice dev = K2nnDevice{});
 // Sweep + merge over all jobs (chunks of kK2nnJobsPerLaunch per launch pair).
 // In atomic mode d_partial must hold 0xFF bytes in every entry the jobs use (top-2 rows and arrival counters);
 // the workgroup that completes a query block leaves it that way again (self re-arming workspace).

@@ -74,6 +74,8 @@ static constexpr uint32_t kMxIdxBits = 13;               // train index inside a
 static constexpr uint32_t kMxMaxSplit = 1u << kMxIdxBits;
 static constexpr uint32_t kMxMagic = 0x4B000000u;        // float bits of 2^23
 static constexpr uint32_t kMxInf = 0x7F800000u;          // "no key yet": above every accumulator value
+static constexpr uint32_t kMxResident = 3;               // workgroups of the matrix sweep a CU holds (152 VGPRs x 4 waves, 19.5 KB of LDS)
+static_assert((kK2nnXcds & (kK2nnXcds - 1u)) == 0u && kK2nnXcds == 8u, "k2nn_sweep_mx_kernel's id -> (query block, split) map is written with & 7 / >> 3");
 // per-XCD unequal-share table entry (K2nnJobList.bias_tab, bias_magic == 0): query block of the XCD in bits 0..4 (at most 32 per XCD),
 // first train tile in bits 5..22 (2^18 tiles = 2^23 rows: above the 2^22 rows of the atomic fold), train tiles in bits 23..31 (a
 // split holds at most 256 tiles, the 13-bit index inside a split).  k2nn_plan refuses the plan when a field would not hold its value.
@@ -714,8 +716,17 @@ __global__ __launch_bounds__(kMergeQ * kMergeGroups) void k2nn_merge_kernel(cons
     if (job.second_out) job.second_out[qi] = (uint16_t)min(a.second_v, 65535);
 }
 
-K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map, int formulation, int bias_a, int bias_b)
+K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map, int formulation, int bias_a, int bias_b, K2nnDevice dev)
 {
+    // Everything below that speaks of XCDs, CUs or wave slots takes the numbers from the DEVICE (hipDeviceAttributeNumberOfXccs,
+    // multiProcessorCount; clc_ctx_create) -- rounds 3-4 had 8 / 32 / 768 written in.  The sweep kernel's workgroup -> (query block, split)
+    // map is compiled for kK2nnXcds XCDs; it is a permutation of the work on any device, but the balance arguments (one XCD's share of the
+    // slots, the slot a workgroup id lands on) only hold where the device has that many: elsewhere the plan keeps equal shares and skips
+    // the per-XCD fit.
+    const bool xcd_known = dev.n_xcd == kK2nnXcds && dev.n_cu % kK2nnXcds == 0u;
+    const uint32_t cu_x = dev.n_cu / kK2nnXcds;                    // CUs of one XCD = workgroups per wave slot and XCD (32 on MI355X)
+    const uint32_t slots = kMxResident * dev.n_cu;                // resident workgroups of the matrix sweep (768)
+
     const bool mx = formulation != K2NN_POPCOUNT;
     const uint32_t qpb = mx ? kMxQPerBlock : kQPerBlock;
     K2nnPlan plan{0, true};
@@ -736,9 +747,9 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         // of the slots against the most query blocks any XCD takes.  34 query blocks (8.5 k queries) at 768 / 34 = 22 splits put
         // 5 x 22 = 110 workgroups on the 96 slots of XCDs 0 and 1 -- a second round there, measured 33 us instead of 26 for such a
         // grid.  Jobs continue round the XCDs where the previous one stopped (xcd_rot), so the maximum is ceil(total / 8).
-        const uint32_t per_xcd = (total_qblocks + 7u) / 8u;
-        const uint32_t fit = (uint32_t)target_blocks / 8u / per_xcd;
-        if (fit < want) want = fit;
+        const uint32_t per_xcd = (total_qblocks + kK2nnXcds - 1u) / kK2nnXcds;
+        const uint32_t fit = (uint32_t)target_blocks / kK2nnXcds / per_xcd;
+        if (xcd_known && fit < want) want = fit;
     }
     if (want < 1) want = 1;
     size_t off = 0;
@@ -746,7 +757,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
     for (int j = 0; j < njobs; ++j) {
         K2nnJobDev& jb = jobs[j];
         jb.xcd_rot = mx ? rot : 0u;
-        rot = (rot + jb.qblocks) & 7u;
+        rot = (rot + jb.qblocks) & (kK2nnXcds - 1u);
         uint32_t splits = want;
         // popcount: >= 16 train vectors per wave; matrix: >= 2 tiles of 32 per workgroup
         const uint32_t min_per = mx ? 64u : 16u * kWaves;
@@ -765,6 +776,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         jb.splits = splits;
         jb.t_per_split = per;
         jb.bias_a = jb.bias_b = jb.bias_magic = 0u;
+        jb.slot_wgs = 0u;
         jb.nq_pad = (jb.nq + 63u) & ~63u;
         jb.partial_off = (uint32_t)off;
         jb.atomic_merge = plan.atomic_merge ? 1u : 0u;
@@ -774,7 +786,10 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
             off += (jb.qblocks + 1u) / 2u;
         }
     }
-    if (mx && njobs == 1 && plan.atomic_merge && bias_a > 0 && bias_b > 0) {
+    // (one job only: the slot a workgroup id lands on is a property of the FIRST resident round of a launch -- the workgroups of a
+    // launch's later jobs are dispatched as slots fall free, in no fixed relation to their ids; multi-pair launches also amortise the
+    // tail the unequal shares remove: 22 us per pair in a 6-pair launch against 25 for one pair alone)
+    if (mx && njobs == 1 && plan.atomic_merge && bias_a > 0 && bias_b > 0 && xcd_known && kMxResident * cu_x <= 96u) {
         // unequal shares by wave slot (K2nnJobDev.bias_a): one job whose grid is one round of three workgroups per CU -- every XCD holds
         // more than 64 and at most 96 of them -- with whole eights of query blocks (nothing padded) and counts known on the host
         K2nnJobDev& jb = jobs[0];
@@ -782,7 +797,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
         const uint32_t nt_tiles = (jb.nt + 31u) >> 5;
         const uint32_t mean = jb.splits ? nt_tiles / jb.splits : 0u;
         // (with one or two query blocks per XCD the biased plan measured 0.3-0.8 us SLOWER -- 2048 x 60000, 4096 x 30000 --, from three on 1-2 us faster)
-        if ((jb.qblocks & 7u) == 0u && jb.qblocks >= 24u && per_xcd > 64u && per_xcd <= 96u && !jb.cnt_q && !jb.cnt_t && jb.splits >= 6u && mean >= 8u) {
+        if ((jb.qblocks & 7u) == 0u && jb.qblocks >= 24u && per_xcd > 2u * cu_x && per_xcd <= 3u * cu_x && !jb.cnt_q && !jb.cnt_t && jb.splits >= 6u && mean >= 8u) {
             // bias_a / bias_b arrive in 1/256 of the equal share (values below 64: tiles, for experiments)
             const uint32_t den = jb.splits * 256u;
             const uint32_t a = bias_a < 64 ? (uint32_t)bias_a : (nt_tiles * (uint32_t)bias_a + den / 2u) / den;
@@ -794,28 +809,28 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
             // sets beyond 4096 tiles), no slot-2 split below the two tiles the equal plan guarantees (min_per)
             bool ok = a >= 1u && b >= 1u && a <= 255u && b <= 255u && nqx <= kBiasQlMask + 1u && nt_tiles <= kBiasBeginMask;
             for (uint32_t ql = 0; ok && ql < nqx; ++ql) {
-                const uint32_t n0 = std::min((32u - ql + nqx - 1u) / nqx, jb.splits);
-                const uint32_t n1 = std::min((64u - ql + nqx - 1u) / nqx, jb.splits) - n0;
+                const uint32_t n0 = std::min((cu_x - ql + nqx - 1u) / nqx, jb.splits);
+                const uint32_t n1 = std::min((2u * cu_x - ql + nqx - 1u) / nqx, jb.splits) - n0;
                 const uint32_t n2 = jb.splits - n0 - n1;
                 const uint32_t used = n0 * a + n1 * b;
                 ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u && (nt_tiles - used) / n2 >= 2u;
             }
-            if (ok) { jb.bias_a = a; jb.bias_b = b; jb.bias_magic = 0u; }
+            if (ok) { jb.bias_a = a; jb.bias_b = b; jb.bias_magic = 0u; jb.slot_wgs = cu_x; }
         }
         // the same for query-block counts that are NOT whole eights: interleaved over all workgroup ids (K2nnJobDev.bias_magic), the split
         // count taken anew (no per-XCD fit, nothing padded)
         const uint32_t QB = jb.qblocks;
         uint32_t sp = QB ? (uint32_t)target_blocks / QB : 0u;
         if (sp > nt_tiles / 8u) sp = nt_tiles / 8u;                            // >= 8 tiles per split on average
-        if (jb.bias_a == 0u && (QB & 7u) != 0u && QB >= 24u && QB <= 128u && sp >= 6u && QB * sp > 512u && QB * sp <= 768u && !jb.cnt_q && !jb.cnt_t &&
-            target_blocks == 768) {
+        if (jb.bias_a == 0u && (QB & 7u) != 0u && QB >= 24u && QB <= 128u && sp >= 6u && QB * sp > 2u * dev.n_cu && QB * sp <= slots && !jb.cnt_q && !jb.cnt_t &&
+            (uint32_t)target_blocks == slots) {
             const uint32_t den = sp * 256u;
             const uint32_t a = bias_a < 64 ? (uint32_t)bias_a : (nt_tiles * (uint32_t)bias_a + den / 2u) / den;
             const uint32_t b = bias_b < 64 ? (uint32_t)bias_b : (nt_tiles * (uint32_t)bias_b + den / 2u) / den;
             bool ok = a >= 1u && b >= 1u && a <= 255u && b <= 255u;
             for (uint32_t q = 0; ok && q < QB; ++q) {
-                const uint32_t n0 = std::min((256u - q + QB - 1u) / QB, sp);
-                const uint32_t n1 = std::min((512u - q + QB - 1u) / QB, sp) - n0;
+                const uint32_t n0 = std::min((dev.n_cu - q + QB - 1u) / QB, sp);
+                const uint32_t n1 = std::min((2u * dev.n_cu - q + QB - 1u) / QB, sp) - n0;
                 const uint32_t n2 = sp - n0 - n1;
                 const uint32_t used = n0 * a + n1 * b;
                 ok = n2 >= 1u && used < nt_tiles && (nt_tiles - used + n2 - 1u) / n2 <= 255u && (nt_tiles - used) / n2 >= 2u;
@@ -823,6 +838,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
             if (ok) {
                 jb.bias_a = a; jb.bias_b = b;
                 jb.bias_magic = (uint32_t)((0x100000000ull + QB - 1u) / QB);
+                jb.slot_wgs = dev.n_cu;
                 jb.splits = sp;
                 jb.t_per_split = ((nt_tiles + sp - 1u) / sp) * 32u;             // (the equal share: reporting only)
             }
@@ -856,8 +872,8 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             const K2nnJobDev& jb = list.j[0];
             const uint32_t QB = jb.qblocks, nt_tiles = (jb.nt + 31u) >> 5;
             for (uint32_t q = 0; q < QB && q < 128u; ++q) {
-                const uint32_t n0 = std::min((256u - q + QB - 1u) / QB, jb.splits);
-                const uint32_t n1 = std::min((512u - q + QB - 1u) / QB, jb.splits) - n0;
+                const uint32_t n0 = std::min((jb.slot_wgs - q + QB - 1u) / QB, jb.splits);
+                const uint32_t n1 = std::min((2u * jb.slot_wgs - q + QB - 1u) / QB, jb.splits) - n0;
                 const uint32_t n2 = jb.splits - n0 - n1;
                 const uint32_t used = n0 * jb.bias_a + n1 * jb.bias_b;
                 const uint32_t rest = nt_tiles > used ? nt_tiles - used : 0u;
@@ -874,8 +890,8 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             const uint32_t nqx = jb.qblocks >> 3, nt_tiles = (jb.nt + 31u) >> 5;
             for (uint32_t w = 0; w < nqx * jb.splits && w < 96u; ++w) {
                 const uint32_t ql = w % nqx, k = w / nqx;
-                const uint32_t n0 = std::min((32u - ql + nqx - 1u) / nqx, jb.splits);
-                const uint32_t n1 = std::min((64u - ql + nqx - 1u) / nqx, jb.splits) - n0;
+                const uint32_t n0 = std::min((jb.slot_wgs - ql + nqx - 1u) / nqx, jb.splits);
+                const uint32_t n1 = std::min((2u * jb.slot_wgs - ql + nqx - 1u) / nqx, jb.splits) - n0;
                 const uint32_t n2 = jb.splits - n0 - n1;
                 const uint32_t used = n0 * jb.bias_a + n1 * jb.bias_b;
                 const uint32_t rest = nt_tiles > used ? nt_tiles - used : 0u;

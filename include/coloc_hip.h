@@ -270,6 +270,13 @@ int clc_k2nn_queries_per_block(const clc_ctx* ctx);
  * (0 = equal shares; round 4, k2nn.hip), [6] queries per workgroup, [7] workgroups aimed at per launch.  The reference has no such
  * entry (its grid is ((num_q - 1) >> 8) + 1 blocks, CUDAK2NN.cu:79); tests and bench.py report the plan with it. */
 int clc_k2nn_plan_query(const clc_ctx* ctx, int nq, int nt, int32_t* info);
+/* What the sweep planner knows about the context's device and which unequal shares it uses (round 5): info[0] XCDs
+ * (hipDeviceAttributeNumberOfXccs), [1] CUs, [2] the formulation's default workgroups per launch (3 per CU: one resident round of the
+ * matrix sweep), [3], [4] share of a slot-0 / slot-1 workgroup in 1/256 of the equal share, [5] where that pair comes from: 0 built-in
+ * default, 1 CLC_K2NN_BIAS, 2 a timed probe of four candidate pairs on this device (once per process and device, at the first matcher
+ * context's creation; CLC_K2NN_PROBE=0 skips it), [6] XCDs the sweep kernel's workgroup map is compiled for, [7] CLC_K2NN_TARGET_BLOCKS
+ * (0: unset).  probe_us (nullable, 4 floats): the 10k x 10k sweep's time under the candidates 295:264, 311:256, 326:249, 326:233. */
+int clc_k2nn_device_info(const clc_ctx* ctx, int32_t* info, float* probe_us);
 
 /* Measurement aid (replaces nothing in the reference): runs ONE sweep of d_q x d_t with the diagnostic build of the
  * matrix-formulation kernel, whose workgroups bracket their tile loop with the shader-clock and the constant 100 MHz

@@ -475,3 +475,39 @@ def test_unequal_shares_with_train_sets_beyond_4096_tiles(oracle, k2nn_formulati
         assert (m[:len(tail)] == tail).all() and m[len(tail)] == -1
     finally:
         ctx.close()
+
+
+def test_planner_takes_its_numbers_from_the_device(oracle):
+    """the sweep planner's XCD / CU / slot counts come from the device (rounds 3-4 had 8 / 32 / 768 written in), and the
+    unequal shares are the device's own: the first matcher context of a process times four candidate pairs (once per device), later
+    contexts take the winner, CLC_K2NN_BIAS / CLC_K2NN_PROBE=0 / CLC_K2NN_TARGET_BLOCKS switch the probe off.  Whatever the shares, the
+    matches are the oracle's."""
+    import os
+    from coloc_amd import Context
+    c1 = Context(device=0, width=160, height=120, maxkp=12000, detector=False)
+    try:
+        d = c1.k2nn_device_info()
+        assert d["xcds"] == d["kernel_xcds"] == 8 and d["cus"] % 8 == 0 and d["default_target_blocks"] == 3 * d["cus"]        # MI355X: 256 CUs
+        assert d["bias_source"] == "probe" and all(10.0 < v < 60.0 for v in d["probe_us"].values()), d
+        assert (d["bias_a"], d["bias_b"]) in ((295, 264), (311, 256), (326, 249), (326, 233))
+        best = min(d["probe_us"], key=d["probe_us"].get)
+        assert "%d:%d" % (d["bias_a"], d["bias_b"]) in (best, "326:249")        # the winner, or the default when the winner is within the noise
+        c2 = Context(device=0, width=160, height=120, maxkp=12000, detector=False)
+        assert c2.k2nn_device_info()["probe_us"] == d["probe_us"] and c2.k2nn_device_info()["bias_a"] == d["bias_a"]     # probed once per device
+        c2.close()
+        Q, T = synth.planted_descriptors(10000, 10000, seed=77)
+        want = oracle.k2nn(Q, T, 40)
+        assert np.array_equal(c1.match_2nn(Q, T, 40), want)
+        for env, src in ((("CLC_K2NN_BIAS", "300,260"), "CLC_K2NN_BIAS"), (("CLC_K2NN_PROBE", "0"), "default"), (("CLC_K2NN_TARGET_BLOCKS", "512"), "default")):
+            os.environ[env[0]] = env[1]
+            try:
+                c3 = Context(device=0, width=160, height=120, maxkp=12000, detector=False)
+            finally:
+                del os.environ[env[0]]
+            try:
+                assert c3.k2nn_device_info()["bias_source"] == src
+                assert np.array_equal(c3.match_2nn(Q, T, 40), want)
+            finally:
+                c3.close()
+    finally:
+        c1.close()
