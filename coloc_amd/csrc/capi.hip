@@ -234,7 +234,7 @@ int cache_mode_default()
 // per CU of the context's device (768 / 2560 on MI355X's 256)
 int default_target_blocks(int formulation, const K2nnDevice& dev = K2nnDevice{}) { return (int)((formulation == K2NN_POPCOUNT ? 10u : 3u) * dev.n_cu); }
 
-int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
+int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st, bool probe = false)
 {
     const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev);
     const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b, ctx->k2dev);
@@ -245,7 +245,7 @@ int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st)
         CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
         ctx->partial_dirty = false;
     }
-    const hipError_t e = launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, &ctx->prof, ctx->formulation);
+    const hipError_t e = launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, probe ? nullptr : &ctx->prof, ctx->formulation, nullptr, probe);
     if (e != hipSuccess) { ctx->partial_dirty = true; return fail(ctx, CLC_ERR_HIP, "launch_k2nn", e); }
     return CLC_OK;
 }
@@ -293,7 +293,7 @@ static void k2nn_probe_bias(clc_ctx* ctx)
                 jobs[0] = K2nnJobDev{};
                 jobs[0].q = (const uint4*)ctx->d_q; jobs[0].t = (const uint4*)ctx->d_t; jobs[0].out = ctx->d_match;
                 jobs[0].nq = (uint32_t)N; jobs[0].nt = (uint32_t)N; jobs[0].thr = 40u;
-                ok = run_jobs(ctx, jobs, ctx->stream) == CLC_OK;
+                ok = run_jobs(ctx, jobs, ctx->stream, true) == CLC_OK;
             }
             ctx->bias_a = sa; ctx->bias_b = sb;
             return ok;

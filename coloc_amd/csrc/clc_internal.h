@@ -156,8 +156,9 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map 
 // the workgroup that completes a query block leaves it that way again (self re-arming workspace).
 // d_stamps (matrix formulation only, nullable): run the diagnostic build whose workgroups record their shader-clock /
 // real-time stamps, 4 uint64 per workgroup of the launch grid
+// probe: the share probe's launches (the default matrix sweep under a symbol of its own, so that kernel traces keep them apart)
 hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream,
-                       Profiler* prof = nullptr, int formulation = K2NN_MATRIX, uint64_t* d_stamps = nullptr);
+                       Profiler* prof = nullptr, int formulation = K2NN_MATRIX, uint64_t* d_stamps = nullptr, bool probe = false);
 int k2nn_queries_per_block(int formulation);
 
 // ---- PnP -------------------------------------------------------------------------------------

@@ -351,7 +351,10 @@ __device__ __forceinline__ uint32_t mx_decode_rel(const uint32_t bits, const uin
 // t covers the top-2 of chain 0 of tile t, chain 0 of tile t + 1 covers the top-2 of chain 1 of tile t -- so the kernel keeps its
 // three waves per SIMD; the price is that every A operand is read from LDS twice.  PIPE = false is round 2's loop (k-step outer,
 // both chains per A read, then all 64 v_med3): kept selectable as CLC_K2NN_MATRIX_PLAIN for A/B runs.
-template <bool STAMP, bool PIPE, bool GLOBAL = false>
+// PROBE: the same code under another symbol, for the launches of the per-device share probe at context creation (capi.hip k2nn_probe_bias):
+// a kernel trace of an application then shows ITS sweeps under k2nn_sweep_mx_kernel<false, true, false> and the probe's -- run from cold
+// clocks, under four different share pairs -- under <..., true>, instead of one average over both.
+template <bool STAMP, bool PIPE, bool GLOBAL = false, bool PROBE = false>
 __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial,
                                                                       uint64_t* __restrict__ stamps)
 {
@@ -849,7 +852,7 @@ K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map,
 }
 
 hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipStream_t stream, Profiler* prof, int formulation,
-                       uint64_t* d_stamps)
+                       uint64_t* d_stamps, bool probe)
 {
     for (int base = 0; base < njobs; base += kK2nnJobsPerLaunch) {
         const int cnt = njobs - base < kK2nnJobsPerLaunch ? njobs - base : kK2nnJobsPerLaunch;
@@ -925,6 +928,9 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
                 hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
             else if (formulation == K2NN_MATRIX_PLAIN)
                 hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, false>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                                   (uint64_t*)nullptr);
+            else if (probe)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true, false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
                                    (uint64_t*)nullptr);
             else
                 hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,

@@ -253,9 +253,28 @@ public:
         return EXIT_SUCCESS;
     }
 
+    // RobustMatcher::filterFundamental (:128-151) and ::filterHomography (:188-230).  NOT on the GPU path, on purpose and by name: the
+    // hot path SURVEY.md section 8 (f-2) scopes is the essential-matrix model, the one `coloc_node.cpp:87` selects ('E'); the other two
+    // need OpenMVG's seven-point / four-point solvers with its point normalisation (ACKernelAdaptor) and, for 'H', OpenCV's
+    // decomposeHomographyMat (RobustMatcher.hpp:106-126) -- none of it in the reference tree.  They keep the reference's signatures so
+    // that code that names them compiles, return EXIT_FAILURE like a failed estimate, and say why: lastStatus() ==
+    // kModelNotOnGpuPath (a caller can fall back to the reference's CPU RobustMatcher for these two models).
+    enum Status { kOk = 0, kEstimateFailed = 1, kModelNotOnGpuPath = 2 };
+    Status lastStatus() const { return last_status_; }
+    bool filterFundamental(const openMVG::cameras::IntrinsicBase*, const openMVG::cameras::IntrinsicBase*, const openMVG::Mat&, const openMVG::Mat&,
+                           openMVG::sfm::RelativePose_Info&, colocParams&, bool)
+    {
+        return not_on_gpu_path('F', "RobustMatcher.hpp:128-151 (SevenPointSolver + EpipolarDistanceError)");
+    }
+    bool filterHomography(const openMVG::cameras::IntrinsicBase*, const openMVG::cameras::IntrinsicBase*, const openMVG::Mat&, const openMVG::Mat&,
+                          openMVG::sfm::RelativePose_Info&, colocParams&, bool)
+    {
+        return not_on_gpu_path('H', "RobustMatcher.hpp:188-230 (FourPointSolver + AsymmetricError, cv::decomposeHomographyMat)");
+    }
+
     // RobustMatcher::computeRelativePose (:372-424): positions of the pair's putative matches, undistorted through each camera's
-    // radial-K3 model, into the filter selected by params->model.  Only the essential-matrix model ('E', the one the reference's
-    // own launch files use) is on this path; 'H' / 'F' report failure.
+    // radial-K3 model, into the filter selected by params->model (:399-405).  Only the essential-matrix model ('E', the one the
+    // reference's own launch code uses) runs on the GPU; 'F' / 'H' report kModelNotOnGpuPath (above).
     bool computeRelativePose(openMVG::sfm::RelativePose_Info& relativePose, openMVG::Pair current_pair, FeatureMap& regions,
                              openMVG::matching::PairWiseMatches& putativeMatches)
     {
@@ -278,9 +297,15 @@ public:
             xR(0, k) = uj[0]; xR(1, k) = uj[1];
         }
         bool status = EXIT_FAILURE;
-        if (params->model == 'E') status = filterEssential(&camL, &camR, xL, xR, relativePose, *params, true);
-        else std::cout << "HIPRobustMatcher: filtering model '" << params->model << "' is not provided (essential matrix only)." << std::endl;
-        if (status == EXIT_FAILURE) std::cerr << "Unable to estimate relative pose." << std::endl;
+        last_status_ = kOk;
+        if (params->model == 'E') {
+            status = filterEssential(&camL, &camR, xL, xR, relativePose, *params, true);
+            if (status == EXIT_FAILURE) last_status_ = kEstimateFailed;
+        }
+        else if (params->model == 'F') status = filterFundamental(&camL, &camR, xL, xR, relativePose, *params, true);
+        else if (params->model == 'H') status = filterHomography(&camL, &camR, xL, xR, relativePose, *params, true);
+        else status = not_on_gpu_path(params->model, "RobustMatcher.hpp:399-405 knows 'E', 'F', 'H'");
+        if (status == EXIT_FAILURE && last_status_ != kModelNotOnGpuPath) std::cerr << "Unable to estimate relative pose." << std::endl;
         return status;
     }
 
@@ -356,6 +381,14 @@ public:
     }
 
 private:
+    bool not_on_gpu_path(const char model, const char* where)
+    {
+        last_status_ = kModelNotOnGpuPath;
+        std::cerr << "HIPRobustMatcher: filtering model '" << model << "' is not on the GPU path (" << where
+                  << "); only the essential-matrix model 'E' is -- use the reference's CPU RobustMatcher for this model." << std::endl;
+        return EXIT_FAILURE;
+    }
+    Status last_status_ = kOk;
     clc_ctx* ctx_ = nullptr;
     colocParams* params;
 };
