@@ -350,8 +350,15 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
     *out_ctx = nullptr;
     if (dopts) {
         if (dopts->scale_levels < 1 || dopts->scale_levels > CLC_MAX_LEVELS || dopts->width < 8 || dopts->height < 8 ||
-            dopts->width > CLC_DETECT_MAX_WIDTH || !(dopts->scale_factor > 1.0f) || dopts->maxkp == 0)
+            !(dopts->scale_factor > 1.0f) || dopts->maxkp == 0)
             return CLC_ERR_BAD_ARG;
+        if (dopts->width > CLC_DETECT_MAX_WIDTH) {
+            // (said here, with its own code: every later clc_detect* call would otherwise fail with a bare hipErrorInvalidValue; there is no
+            // context yet whose clc_last_error_string could carry the text)
+            fprintf(stderr, "coloc_hip: DetectorOptions.width %u exceeds CLC_DETECT_MAX_WIDTH %d (the GPU detector keeps a row's pre-test bits in LDS)\n",
+                    dopts->width, CLC_DETECT_MAX_WIDTH);
+            return CLC_ERR_CAPACITY;
+        }
     }
     if (mopts && mopts->maxkp == 0) return CLC_ERR_BAD_ARG;
     int ndev = 0;

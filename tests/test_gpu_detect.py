@@ -163,3 +163,15 @@ def test_detect_batch_equals_single_camera_calls(oracle, W, H, n):
             assert same_kps(kps, w[:cnt[0]])
             assert np.array_equal(d_desc[b].cpu().numpy()[:cnt[0]], oracle.clatch(pyr, w[:cnt[0]]))
     ctx.close()
+
+
+def test_width_beyond_the_detector_limit_is_refused_at_creation():
+    """CLC_DETECT_MAX_WIDTH (4096) was only enforced inside the detector launch, so a wider context was created and
+    every later clc_detect* call failed with a bare hipErrorInvalidValue.  clc_ctx_create refuses it with CLC_ERR_CAPACITY (2);
+    the widest allowed frame still detects like the oracle."""
+    from coloc_amd import Context, CLCError
+    with pytest.raises(CLCError) as e:
+        Context(device=0, width=4097, height=64, maxkp=1000)
+    assert e.value.status == 2
+    ctx = Context(device=0, width=4096, height=40, maxkp=4000)
+    ctx.close()
