@@ -8,7 +8,7 @@ OUT=gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 run() { # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-seconds 0 --settle-steps 0 --headline-only > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; }
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -o p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-seconds 0 --settle-steps 0 --headline-only --one-stream > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; }
   f=$(find $OUT/$name -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python3 - "$f" "$name" <<'PY'
 import csv, sys, collections
