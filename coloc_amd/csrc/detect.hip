@@ -106,37 +106,6 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
     const int t = (int)a.threshold;
     const uint8_t* __restrict__ img = arena_base + (size_t)cam * a.slot_stride + L.offset;
 
-    // ---- KFAST.h:245 replay: does the walk of row gy land on cols - 35?  (levels of width 6 mod 16, tiles at the right end)
-    // The walk only ever asks two things of a 32-column block at j = 3 + 16 g: is any pre-test bit set, and is its low half empty --
-    // i.e. it needs any(g) = "some pixel of columns 3 + 16 g .. 18 + 16 g passes the pre-test" per 16-column group.  A lane takes four
-    // columns 4 l .. 4 l + 3 of a row as dwords (3 of the centre row, 1 each of the rows 3 above and below: five loads instead
-    // of twenty byte loads), a wave instruction covers 256 columns, and all the loads of the wave's rows (w, w + 4, ..: five at most)
-    // are in flight together -- one load latency per 256 columns of width, where one ballot per 64 columns of one row cost
-    // 18 dependent steps (3.6 us per tile at 214 columns).  Lane 4 g' + r: r = 0 -> its columns 0..2 belong to group g' - 1, column 3 to
-    // g'; r != 0 -> all four to g'.  C = ballot(own group) | ballot(previous group) >> 4 then holds any(g) in nibble g.
-    // Round 5: the loads of the FIRST 256 columns are issued BEFORE the tile is staged, so that the two sets of loads are in flight
-    // together (the 22 tiles of a 640 x 480 frame that replay the walk are the launch's critical path: they paid the two latencies
-    // one after the other).
-    const bool walk = (cols % 16 == 6) && cols >= 38 && (x0 + kTileW + 1 >= cols - 35);
-    const int nunits = (cols + 255) >> 8;                        // 256-column units per row (<= 16)
-    uint32_t ctr0[5], ctr1[5], ctr2[5], top[5], bot[5];
-    auto walk_load = [&](const int c) {
-        const int xl = 256 * c + 4 * (int)lane;                  // first of this lane's four columns
-#pragma unroll
-        for (int ri = 0; ri < 5; ++ri) {
-            const int r = (int)wave + 4 * ri;
-            const int gy = y0 - 1 + r;
-            const bool ok = r < kScRows && gy >= 3 && gy < rows - 3 && xl < pitch;
-            const uint8_t* p = img + (size_t)(ok ? gy : 3) * pitch + (ok ? xl : 0);
-            ctr0[ri] = (ok && xl >= 4) ? *reinterpret_cast<const uint32_t*>(p - 4) : 0u;
-            ctr1[ri] = ok ? *reinterpret_cast<const uint32_t*>(p) : 0u;
-            ctr2[ri] = (ok && xl + 4 < pitch) ? *reinterpret_cast<const uint32_t*>(p + 4) : 0u;
-            top[ri] = ok ? *reinterpret_cast<const uint32_t*>(p - 3 * pitch) : 0u;
-            bot[ri] = ok ? *reinterpret_cast<const uint32_t*>(p + 3 * pitch) : 0u;
-        }
-    };
-    if (walk) walk_load(0);
-
     // ---- stage the tile (+ 4 px halo) and clear the work areas ---------------------------------
     for (uint32_t i = tid; i < (uint32_t)(kImgRows * (kImgStride / 4)); i += 256u) {
         const int r = (int)(i / (kImgStride / 4)), d = (int)(i - (uint32_t)r * (kImgStride / 4));
@@ -149,13 +118,35 @@ __global__ __launch_bounds__(256) void detect_tile_kernel(const DetectArgs a, co
     if (tid < (uint32_t)kTileH * 2u) s_mask[tid >> 1][tid & 1u] = 0u;
     if (tid == 0) s_nkp = 0u;
 
+    // ---- KFAST.h:245 replay: does the walk of row gy land on cols - 35?  (levels of width 6 mod 16, tiles at the right end)
+    const bool walk = (cols % 16 == 6) && cols >= 38 && (x0 + kTileW + 1 >= cols - 35);
     if (!walk) {
         if (tid < (uint32_t)kScRows) s_drop[tid] = 0u;           // (with the replay, every entry is written by the lane that walks its row)
     } else {
+        // The walk only ever asks two things of a 32-column block at j = 3 + 16 g: is any pre-test bit set, and is its low half empty --
+        // i.e. it needs any(g) = "some pixel of columns 3 + 16 g .. 18 + 16 g passes the pre-test" per 16-column group.  A lane takes four
+        // columns 4 l .. 4 l + 3 of a row as dwords (3 of the centre row, 1 each of the rows 3 above and below: five loads instead
+        // of twenty byte loads), a wave instruction covers 256 columns, and all the loads of the wave's rows (w, w + 4, ..: five at most)
+        // are in flight together -- one load latency per 256 columns of width, where one ballot per 64 columns of one row cost
+        // 18 dependent steps (3.6 us per tile at 214 columns).  Lane 4 g' + r: r = 0 -> its columns 0..2 belong to group g' - 1, column 3 to
+        // g'; r != 0 -> all four to g'.  C = ballot(own group) | ballot(previous group) >> 4 then holds any(g) in nibble g.
+        const int nunits = (cols + 255) >> 8;                    // 256-column units per row (<= 16)
         uint64_t row_flags = 0;                                  // nunits == 1: lane ri of a wave holds the group flags of its row w + 4 ri
         for (int c = 0; c < nunits; ++c) {
             const int xl = 256 * c + 4 * (int)lane;              // first of this lane's four columns
-            if (c > 0) walk_load(c);
+            uint32_t ctr0[5], ctr1[5], ctr2[5], top[5], bot[5];
+#pragma unroll
+            for (int ri = 0; ri < 5; ++ri) {
+                const int r = (int)wave + 4 * ri;
+                const int gy = y0 - 1 + r;
+                const bool ok = r < kScRows && gy >= 3 && gy < rows - 3 && xl < pitch;
+                const uint8_t* p = img + (size_t)(ok ? gy : 3) * pitch + (ok ? xl : 0);
+                ctr0[ri] = (ok && xl >= 4) ? *reinterpret_cast<const uint32_t*>(p - 4) : 0u;
+                ctr1[ri] = ok ? *reinterpret_cast<const uint32_t*>(p) : 0u;
+                ctr2[ri] = (ok && xl + 4 < pitch) ? *reinterpret_cast<const uint32_t*>(p + 4) : 0u;
+                top[ri] = ok ? *reinterpret_cast<const uint32_t*>(p - 3 * pitch) : 0u;
+                bot[ri] = ok ? *reinterpret_cast<const uint32_t*>(p + 3 * pitch) : 0u;
+            }
 #pragma unroll
             for (int ri = 0; ri < 5; ++ri) {
                 const int r = (int)wave + 4 * ri;
