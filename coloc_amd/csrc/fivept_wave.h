@@ -391,18 +391,21 @@ __device__ __noinline__ void models_of_sample(const double* __restrict__ x1, con
             A[6] = 0.0; A[7] = 0.0; A[8] = 1.0;
         }
     }
-    if (threadIdx.x != 0) return;
+    // one model slot per lane (round 5: lane 0 used to write all ten, ~1 000 dependent instructions on one lane at the end of every solve)
+    const int k = (int)threadIdx.x;
+    if (k >= 10) return;
     const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    for (int k = 0; k < 10; ++k) {
-        if (k >= n) { for (int e = 0; e < 18; ++e) out[18 * k + e] = qnan; continue; }
-        const double* Ek = E + 9 * k;
-        double T[9];                                   // T = E K1^-1
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) T[3 * r + c] = Ek[3 * r] * A1[c] + Ek[3 * r + 1] * A1[3 + c] + Ek[3 * r + 2] * A1[6 + c];
-        for (int r = 0; r < 3; ++r)                    // F = K2^-T T : F[r][c] = sum_m A2[m][r] T[m][c]
-            for (int c = 0; c < 3; ++c) out[18 * k + 3 * r + c] = A2[r] * T[c] + A2[3 + r] * T[3 + c] + A2[6 + r] * T[6 + c];
-        for (int e = 0; e < 9; ++e) out[18 * k + 9 + e] = Ek[e];
+    if (k >= n) {
+        for (int e = 0; e < 18; ++e) out[18 * k + e] = qnan;
+        return;
     }
+    const double* Ek = E + 9 * k;
+    double T[9];                                   // T = E K1^-1
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) T[3 * r + c] = Ek[3 * r] * A1[c] + Ek[3 * r + 1] * A1[3 + c] + Ek[3 * r + 2] * A1[6 + c];
+    for (int r = 0; r < 3; ++r)                    // F = K2^-T T : F[r][c] = sum_m A2[m][r] T[m][c]
+        for (int c = 0; c < 3; ++c) out[18 * k + 3 * r + c] = A2[r] * T[c] + A2[3 + r] * T[3 + c] + A2[6 + r] * T[6 + c];
+    for (int e = 0; e < 9; ++e) out[18 * k + 9 + e] = Ek[e];
 }
 
 } // namespace fpw

@@ -151,7 +151,7 @@ def test_two_launch_round_equals_the_three_launch_round():
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_two_view_batch as t; from coloc_amd import Context;"
             "c = Context(device=0, detector=False, matcher=False); out = [];\n"
             "for s in (11, 12, 13):\n"
-            "    p = t._pair(400 + s, n=500 + 100 * s % 700)\n"
+            "    p = t._pair(400 + s, n=500 + (100 * s) %% 700)\n"
             "    r = c.essential_acransac(p['x1'], p['x2'], t.K, t.K, t.WH, max_iteration=256, seed=s)\n"
             "    out.append(dict(E=r['E'].tolist(), inl=r['inliers'].tolist(), emax=r['error_max'], nfa=r['min_nfa'], it=r['iterations']))\n"
             "print('RESULT' + json.dumps(out))" % (os.path.dirname(here), here))
