@@ -62,7 +62,7 @@ class TwoViewJob(C.Structure):
 
 class InterPoseJob(C.Structure):
     """clc_inter_pose_job (include/coloc_hip.h)"""
-    _fields_ = [("tv", TwoViewJob), ("map_index", C.c_void_p), ("map_X", C.c_void_p), ("Rt_source", C.c_void_p), ("huber_a", C.c_double),
+    _fields_ = [("tv", TwoViewJob), ("map_index", C.c_void_p), ("map_X", C.c_void_p), ("map_n", C.c_int), ("Rt_source", C.c_void_p), ("huber_a", C.c_double),
                 ("Rt", C.c_double * 12), ("cov", C.c_double * 36), ("rmse", C.c_double), ("scale", C.c_double),
                 ("n_front", C.c_int), ("n_common", C.c_int), ("n_refined", C.c_int), ("stage", C.c_int)]
 
@@ -276,7 +276,7 @@ def inter_pose_batch(ctxs, problems, map_X, max_iteration=256, huber_a=16.0):
         mi = np.ascontiguousarray(p["map_index"], dtype=np.int32)
         rs = np.ascontiguousarray(p["Rt_source"], dtype=np.float64).reshape(12)
         keep.append((mi, rs))
-        j.map_index, j.map_X, j.Rt_source, j.huber_a = mi.ctypes.data, map_X.ctypes.data, rs.ctypes.data, float(huber_a)
+        j.map_index, j.map_X, j.map_n, j.Rt_source, j.huber_a = mi.ctypes.data, map_X.ctypes.data, int(map_X.shape[0]), rs.ctypes.data, float(huber_a)
     hs = (C.c_void_p * n)(*[c.h for c in ctxs])
     rc = lib.clc_inter_pose_batch(hs, jobs, n)
     if rc != CLC_OK:

@@ -2377,7 +2377,8 @@ int inter_geometry(clc_inter_pose_job& jb, std::vector<double>& Xw, std::vector<
         const int i = tv.inliers[k];
         Xt[3 * w] = n1[2 * (size_t)k] * bl1[(size_t)k]; Xt[3 * w + 1] = n1[2 * (size_t)k + 1] * bl1[(size_t)k]; Xt[3 * w + 2] = bl1[(size_t)k];
         x2f[2 * w] = tv.x2[2 * i]; x2f[2 * w + 1] = tv.x2[2 * i + 1];
-        mi[w] = jb.map_index ? jb.map_index[i] : -1;
+        const int32_t gi = jb.map_index ? jb.map_index[i] : -1;
+        mi[w] = (gi >= 0 && gi < jb.map_n) ? gi : -1;
         ++w;
     }
     // scale through the features both maps hold

@@ -530,6 +530,7 @@ typedef struct clc_inter_pose_job {
     /* in */
     const int32_t* map_index; /* tv.n: index of correspondence i's SOURCE feature in the global map, -1 = none (nullable: no scale) */
     const double*  map_X;     /* global map points, 3 doubles each                         */
+    int            map_n;     /* number of map points: an index outside [0, map_n) counts as "not a map feature" */
     const double*  Rt_source; /* 12: [R|t] of the source camera, x_cam = R X + t           */
     double         huber_a;   /* <= 0: 16                                                  */
     /* out */

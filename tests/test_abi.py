@@ -69,3 +69,31 @@ def test_share_grain_is_a_multiple_of_every_sweep_workgroup():
     lib = abi.load_library()
     grain = lib.clc_k2nn_queries_per_block(None)
     assert grain in (128, 256) and multicam.QBLOCK % grain == 0 and multicam.QBLOCK % 128 == 0
+
+
+def test_job_structs_match_the_c_header(tmp_path):
+    """The batch entries take arrays of plain C structs (clc_pose_job, clc_two_view_job, clc_inter_pose_job): the ctypes mirrors in
+    coloc_amd/abi.py must have the C compiler's sizes and field offsets (a gcc probe over include/coloc_hip.h, no GPU needed)."""
+    import subprocess
+    from coloc_amd import abi
+    probes = {"clc_pose_job": (abi.PoseJob, ["X", "n", "seed", "precision", "refine", "huber_a", "Rt", "n_inliers", "error_max", "rmse"]),
+              "clc_two_view_job": (abi.TwoViewJob, ["x1", "K2", "n", "max_iteration", "seed", "precision", "E", "inliers", "n_inliers", "status", "error_max", "min_nfa"]),
+              "clc_inter_pose_job": (abi.InterPoseJob, ["tv", "map_index", "map_X", "map_n", "Rt_source", "huber_a", "Rt", "cov", "rmse", "scale", "n_front", "stage"])}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "coloc_hip.h"', 'int main(void) {']
+    for name, (_, fields) in probes.items():
+        src.append('printf("%s %%zu", sizeof(%s));' % (name, name))
+        for f in fields:
+            src.append('printf(" %%zu", offsetof(%s, %s));' % (name, f))
+        src.append('printf("\\n");')
+    src += ['return 0;', '}']
+    c = tmp_path / "probe.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    for line in out.strip().splitlines():
+        parts = line.split()
+        cls, fields = probes[parts[0]]
+        assert C.sizeof(cls) == int(parts[1]), parts[0]
+        for f, off in zip(fields, parts[2:]):
+            assert getattr(cls, f).offset == int(off), (parts[0], f)

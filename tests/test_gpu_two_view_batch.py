@@ -133,6 +133,9 @@ def test_inter_pose_batch_lands_on_the_destination_pose():
         assert inter_pose_batch([ctxs[0]], [q], world["map_X"])[0]["stage"] == 3
         q = dict(world); q["x1"], q["x2"], q["map_index"] = world["x1"][:9], world["x2"][:9], world["map_index"][:9]
         assert inter_pose_batch([ctxs[0]], [q], world["map_X"])[0]["stage"] == 1
+        # map indices outside the map are "not a map feature", not a read past the array: with every index out of range -> no scale
+        q = dict(world); q["map_index"] = np.where(world["map_index"] >= 0, world["map_index"] + 10 ** 6, -1).astype(np.int32)
+        assert inter_pose_batch([ctxs[0]], [q], world["map_X"])[0]["stage"] == 3
     finally:
         for c in ctxs:
             c.close()
