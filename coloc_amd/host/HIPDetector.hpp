@@ -30,6 +30,8 @@
 #include <opencv2/highgui/highgui.hpp>
 #endif
 
+static_assert(CLC_ABI_VERSION >= 2, "this policy header uses entry points of ABI version 2 (clc_desc_cache_mode)");
+
 namespace coloc {
 
 namespace hip_detail {
@@ -87,6 +89,10 @@ public:
             std::cerr << "HIPDetector: clc_ctx_create failed: " << clc_status_string(rc) << std::endl;
             ctx_ = nullptr;
         }
+        // the library a host was LINKED against and the header it was COMPILED against must agree (the surface grew in
+        // rounds 4 and 5 under one version number); a mismatch is reported, the calls that exist in both still work
+        if (clc_abi_version() != CLC_ABI_VERSION)
+            std::cerr << "HIPDetector: libcoloc_hip reports ABI version " << clc_abi_version() << ", this header was written for " << CLC_ABI_VERSION << std::endl;
         trustPublishedRegions(true);
     }
     HIPDetector(const HIPDetector&) = delete;

@@ -22,6 +22,8 @@
 #include "coloc_hip.h"
 #include "coloc_hip_types.hpp"
 
+static_assert(CLC_ABI_VERSION >= 2, "this policy header uses entry points of ABI version 2 (clc_desc_cache_mode)");
+
 namespace coloc {
 
 template <typename T>
@@ -41,6 +43,10 @@ public:
             std::cerr << "HIPMatcher: clc_ctx_create failed: " << clc_status_string(rc) << std::endl;
             ctx_ = nullptr;
         }
+        // the library a host was LINKED against and the header it was COMPILED against must agree (the surface grew in
+        // rounds 4 and 5 under one version number); a mismatch is reported, the calls that exist in both still work
+        if (clc_abi_version() != CLC_ABI_VERSION)
+            std::cerr << "HIPMatcher: libcoloc_hip reports ABI version " << clc_abi_version() << ", this header was written for " << CLC_ABI_VERSION << std::endl;
         trustPublishedRegions(true);
     }
     HIPMatcher(const HIPMatcher&) = delete;
