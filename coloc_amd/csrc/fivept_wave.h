@@ -378,34 +378,39 @@ __device__ __noinline__ void models_of_sample(const double* __restrict__ x1, con
         normalise_px(K2, x2[2 * i], x2[2 * i + 1], q2[p]);
     }
     const int n = ok ? solve(q1, q2, E, ws) : 0;
-    // F = K2^-T E K1^-1 for upper-triangular K = [fx s cx; 0 fy cy; 0 0 1]: K^-1 = [1/fx, -s/(fx fy), (s cy - cx fy)/(fx fy); 0, 1/fy, -cy/fy; 0 0 1]
-    double A1[9], A2[9];
+    // F = K2^-T E K1^-1 for upper-triangular K = [fx s cx; 0 fy cy; 0 0 1]: K^-1 = [1/fx, -s/(fx fy), (s cy - cx fy)/(fx fy); 0, 1/fy, -cy/fy; 0 0 1].
+    // Plain IEEE operations in source order, NOT contracted (the block below switches the file's `fp contract(fast)` off): the tests restate
+    // this product on the host (tests/test_gpu_acransac.py _f_from_e) to hand the oracle the F the device scores with, bit for bit.
+    // One model slot per lane (round 5: lane 0 used to write all ten, ~1 000 dependent instructions on one lane at the end of every solve).
     {
-        const double* Ks[2] = { K1, K2 };
-        double* As[2] = { A1, A2 };
-        for (int w = 0; w < 2; ++w) {
-            const double fx = Ks[w][0], sk = Ks[w][1], cx = Ks[w][2], fy = Ks[w][4], cy = Ks[w][5];
-            double* A = As[w];
-            A[0] = 1.0 / fx; A[1] = -sk / (fx * fy); A[2] = (sk * cy - cx * fy) / (fx * fy);
-            A[3] = 0.0; A[4] = 1.0 / fy; A[5] = -cy / fy;
-            A[6] = 0.0; A[7] = 0.0; A[8] = 1.0;
+#pragma clang fp contract(off)
+        const int k = (int)threadIdx.x;
+        if (k >= 10) return;
+        const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+        if (k >= n) {
+            for (int e = 0; e < 18; ++e) out[18 * k + e] = qnan;
+            return;
         }
+        double A1[9], A2[9];
+        {
+            const double* Ks[2] = { K1, K2 };
+            double* As[2] = { A1, A2 };
+            for (int w = 0; w < 2; ++w) {
+                const double fx = Ks[w][0], sk = Ks[w][1], cx = Ks[w][2], fy = Ks[w][4], cy = Ks[w][5];
+                double* A = As[w];
+                A[0] = 1.0 / fx; A[1] = -sk / (fx * fy); A[2] = (sk * cy - cx * fy) / (fx * fy);
+                A[3] = 0.0; A[4] = 1.0 / fy; A[5] = -cy / fy;
+                A[6] = 0.0; A[7] = 0.0; A[8] = 1.0;
+            }
+        }
+        const double* Ek = E + 9 * k;
+        double T[9];                                   // T = E K1^-1
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) T[3 * r + c] = Ek[3 * r] * A1[c] + Ek[3 * r + 1] * A1[3 + c] + Ek[3 * r + 2] * A1[6 + c];
+        for (int r = 0; r < 3; ++r)                    // F = K2^-T T : F[r][c] = sum_m A2[m][r] T[m][c]
+            for (int c = 0; c < 3; ++c) out[18 * k + 3 * r + c] = A2[r] * T[c] + A2[3 + r] * T[3 + c] + A2[6 + r] * T[6 + c];
+        for (int e = 0; e < 9; ++e) out[18 * k + 9 + e] = Ek[e];
     }
-    // one model slot per lane (round 5: lane 0 used to write all ten, ~1 000 dependent instructions on one lane at the end of every solve)
-    const int k = (int)threadIdx.x;
-    if (k >= 10) return;
-    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
-    if (k >= n) {
-        for (int e = 0; e < 18; ++e) out[18 * k + e] = qnan;
-        return;
-    }
-    const double* Ek = E + 9 * k;
-    double T[9];                                   // T = E K1^-1
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) T[3 * r + c] = Ek[3 * r] * A1[c] + Ek[3 * r + 1] * A1[3 + c] + Ek[3 * r + 2] * A1[6 + c];
-    for (int r = 0; r < 3; ++r)                    // F = K2^-T T : F[r][c] = sum_m A2[m][r] T[m][c]
-        for (int c = 0; c < 3; ++c) out[18 * k + 3 * r + c] = A2[r] * T[c] + A2[3 + r] * T[3 + c] + A2[6 + r] * T[6 + c];
-    for (int e = 0; e < 9; ++e) out[18 * k + 9 + e] = Ek[e];
 }
 
 } // namespace fpw

@@ -20,6 +20,8 @@ for case in range(n_cases):
     if W / 1.2 ** (levels - 1) < 8 or H / 1.2 ** (levels - 1) < 8:
         levels = 1
     kind = int(rng.integers(0, 4))
+    if kind == 0 and (W < 24 or H < 24):
+        kind = 1                                                     # (synth.rect_image needs room for its rectangles)
     if kind == 0:
         img = synth.rect_image(W, H, n_rect=max(4, W * H // 2500), seed=int(rng.integers(1 << 30)), noise_sigma=float(rng.choice([0.0, 2.0, 8.0])))
     elif kind == 1:
