@@ -965,8 +965,7 @@ int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_
     if ((uintptr_t)d_match & 3u) return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: misaligned device pointer");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    { const int rc = ensure_pair(ctx); if (rc != CLC_OK) return rc; }
-    if (*ctx->h_gate_err) {
+    if (ctx->h_gate_err && *ctx->h_gate_err) {
         *ctx->h_gate_err = 0;
         ctx->partial_dirty = true;
         return fail(ctx, CLC_ERR_HIP, "describe_match_pair: a gate of an earlier step gave up waiting for its describe launch");
@@ -1017,6 +1016,9 @@ int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_
         jobs[0].nq = nq; jobs[0].nt = nt; jobs[0].thr = (uint32_t)(uint8_t)threshold;
         return run_jobs(ctx, jobs, st);
     }
+    // (second stream, events, progress counters, error word: allocated by the first CHUNKED step of a context -- that call synchronises
+    // and cannot be captured; the default form above needs none of it)
+    { const int rc = ensure_pair(ctx); if (rc != CLC_OK) return rc; }
     // every chunk's sweep planned on its own (its launch has the slots the describe launch leaves to itself), rows and counters of
     // the chunks one behind the other in the context's workspace
     const int target = ctx->pair_target_blocks > 0 ? ctx->pair_target_blocks
