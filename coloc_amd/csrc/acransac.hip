@@ -39,12 +39,6 @@ __device__ unsigned long long g_acr_stamp[16];
 #define ACR_STAMP(i) do { } while (0)
 #endif
 
-// where the round that COMPLETES a run leaves the result (round 3: the finish work rides in that round's select launch, and the
-// host returns as soon as the polled word says "done" instead of launching a finish kernel behind the round enqueued ahead)
-struct AcrFinish {
-    uint8_t* d_mask; AcrResult* d_res;                 // device copies (the refinement reads them)
-    uint8_t* h_mask; int32_t* h_inliers; AcrResult* h_res;     // pinned host memory (nullable)
-};
 __device__ __forceinline__ void acr_finish_block(const AcrProblem& pb, const AcrState& s, const uint32_t* __restrict__ best_inliers,
                                                  const AcrFinish& fin, const int tid, const int T)
 {
@@ -545,6 +539,21 @@ __global__ __launch_bounds__(1024) void acr_nfa_kernel(const AcrProblem pb, cons
                     (int)blockDim.x, reinterpret_cast<uint64_t*>(acr_lds));
 }
 
+// the nfa launch of a two-view round for up to kMaxBatch solves at once (blockIdx.y = chain): the copies of launch parity `par`
+template <int E>
+__global__ __launch_bounds__(1024) void acr_nfa_chains_kernel(const AcrChains chains, const int par, const int P)
+{
+    extern __shared__ unsigned char acr_lds[];
+    constexpr int kSlots = kAcrMaxBatch * 10;
+    const AcrChain& ch = chains.c[blockIdx.y];
+    const AcrProblem& pb = ch.pb;
+    const int slot = blockIdx.x;
+    const AcrState* state = ch.states + par;                         // what this round's keeper has just written: cur_batch = this round's batch
+    if (slot >= state->cur_batch * pb.max_models) return;
+    acr_nfa_body<E>(pb, P, ch.models + ((size_t)par * kSlots + slot) * pb.model_doubles, ch.hyps + (size_t)par * kSlots + slot,
+                    ch.sorted + ((size_t)par * kSlots + slot) * pb.n, (int)threadIdx.x, (int)blockDim.x, reinterpret_cast<uint64_t*>(acr_lds));
+}
+
 // ---- select: the sequential semantics over one batch -------------------------------------------------------------
 // The loop being replayed is sequential (strict '<' improvements in iteration / solver order, the first iteration that
 // switches the index set ends the batch), but everything in it is a prefix operation over the <= 1280 model slots: the
@@ -685,8 +694,8 @@ __device__ __forceinline__ AcrPick acr_select_wave(const AcrProblem& pb, AcrCore
     if (B > 0) { s.rounds += 1; s.rounds_eval += 1; }            // a launch that found nothing to replay is not a round
     s.last_batch = consumed;
     // next round: while nothing has happened look further ahead per round; after an event the whole reserve goes in one
-    if (event_it < B || !s.index_all) s.grow = kAcrMaxBatch;
-    else s.grow = s.grow * 2 > kAcrMaxBatch ? kAcrMaxBatch : s.grow * 2;
+    if (event_it < B || !s.index_all) s.grow = pb.batch_cap;
+    else s.grow = s.grow * 2 > pb.batch_cap ? pb.batch_cap : s.grow * 2;
     const int remaining = s.n_iter - s.iter;
     s.cur_batch = remaining < s.grow ? (remaining > 0 ? remaining : 0) : s.grow;
     return pick;
@@ -800,12 +809,12 @@ __global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, co
 // workgroups read the other list (acr_sample_source).  The word of round r therefore comes out of launch r + 1 -- early in it, so
 // the host has launch r + 2 enqueued long before r + 1 ends, and the launch that reports "done" is the last one in the stream.
 template <int E>
-__global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
-                                                         const int par, const int P /* = blockDim.x * E */, const AcrProblem pb,
-                                                         uint32_t* __restrict__ sorted /* [2][slots * n] */,
-                                                         double* __restrict__ models /* [2][slots * 12] */,
-                                                         uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
-                                                         unsigned long long* __restrict__ h_word, const AcrFinish fin)
+__device__ __forceinline__ void acr_round_body(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
+                                               const int par, const int P /* = blockDim.x * E */, const AcrProblem& pb,
+                                               uint32_t* __restrict__ sorted /* [2][slots * n] */,
+                                               double* __restrict__ models /* [2][slots * 12] */,
+                                               uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
+                                               unsigned long long* __restrict__ h_word, const AcrFinish& fin)
 {
     extern __shared__ unsigned char acr_lds[];
     constexpr int kSlots = kAcrMaxBatch * 4;
@@ -872,6 +881,24 @@ __global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ 
                           reinterpret_cast<uint64_t*>(acr_lds), &pre);
 }
 
+template <int E>
+__global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
+                                                         const int par, const int P /* = blockDim.x * E */, const AcrProblem pb,
+                                                         uint32_t* __restrict__ sorted /* [2][slots * n] */,
+                                                         double* __restrict__ models /* [2][slots * 12] */,
+                                                         uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
+                                                         unsigned long long* __restrict__ h_word, const AcrFinish fin)
+{
+    acr_round_body<E>(states, hyps, par, P, pb, sorted, models, best_inliers, index_set, h_word, fin);
+}
+// the same round for up to kMaxBatch solves at once: blockIdx.y = chain (same code, same bits: the file is compiled without contraction)
+template <int E>
+__global__ __launch_bounds__(1024) void acr_round_chains_kernel(const AcrChains chains, const int par, const int P)
+{
+    const AcrChain& ch = chains.c[blockIdx.y];
+    acr_round_body<E>(ch.states, ch.hyps, par, P, ch.pb, ch.sorted, ch.models, ch.best_inliers, ch.index_set, ch.h_word, ch.fin);
+}
+
 // ---- the five-point round in TWO launches (round 5) ---------------------------------------------------------------------------
 // The two-view round was solve -> nfa -> select: three launches, 39 + 11 + 6.5 us of kernels and three launch boundaries of ~4.4 us.
 // The select launch goes the way it went for resection: every solver workgroup replays the previous round for itself (one wave, one
@@ -881,11 +908,11 @@ __global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ 
 // has ended, so the two stay two launches; state, slots, sorted lists and models live in two copies indexed by launch parity exactly
 // as for resection.  The solve is fpw::models_of_sample, the one not-inlined body fivept_kernel runs: same bits as the hypotheses the
 // tests hand to the sequential oracle.
-__global__ __launch_bounds__(64) void acr_solve5_kernel(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
-                                                        const int par, const AcrProblem pb, uint32_t* __restrict__ sorted /* [2][slots * n] */,
-                                                        double* __restrict__ models /* [2][slots * 18] */,
-                                                        uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
-                                                        unsigned long long* __restrict__ h_word, const AcrFinish fin)
+__device__ __forceinline__ void acr_solve5_body(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
+                                                const int par, const AcrProblem& pb, uint32_t* __restrict__ sorted /* [2][slots * n] */,
+                                                double* __restrict__ models /* [2][slots * 18] */,
+                                                uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
+                                                unsigned long long* __restrict__ h_word, const AcrFinish& fin)
 {
     constexpr int kSlots = kAcrMaxBatch * 10;
     __shared__ AcrCore s_core;
@@ -920,6 +947,20 @@ __global__ __launch_bounds__(64) void acr_solve5_kernel(AcrState* __restrict__ s
 #pragma unroll
     for (int j = 0; j < 5; ++j) id[j] = (int)(src ? src[pos[j]] : pos[j]);
     fpw::models_of_sample(pb.a, pb.b, pb.K1, pb.K2, id[0], id[1], id[2], id[3], id[4], pb.n, models + ((size_t)par * kSlots + (size_t)it * 10) * 18);
+}
+
+__global__ __launch_bounds__(64) void acr_solve5_kernel(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
+                                                        const int par, const AcrProblem pb, uint32_t* __restrict__ sorted /* [2][slots * n] */,
+                                                        double* __restrict__ models /* [2][slots * 18] */,
+                                                        uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
+                                                        unsigned long long* __restrict__ h_word, const AcrFinish fin)
+{
+    acr_solve5_body(states, hyps, par, pb, sorted, models, best_inliers, index_set, h_word, fin);
+}
+__global__ __launch_bounds__(64) void acr_solve5_chains_kernel(const AcrChains chains, const int par)
+{
+    const AcrChain& ch = chains.c[blockIdx.y];
+    acr_solve5_body(ch.states, ch.hyps, par, ch.pb, ch.sorted, ch.models, ch.best_inliers, ch.index_set, ch.h_word, ch.fin);
 }
 
 // ---- finish: mask, inlier list and the result record, straight into pinned host memory ---------------------------
@@ -1039,6 +1080,73 @@ hipError_t launch_acr_round_5pt(const AcrProblem& pb, int par, AcrState* d_state
     else if (P == 8192) e = acr_launch_nfa<8>(pb, B, P, mo, hy, so, stp, stream);
     else e = acr_launch_nfa<16>(pb, B, P, mo, hy, so, stp, stream);
     return e;
+}
+
+// ---- the same rounds for several solves in one launch (lockstep; capi.hip drives them) ----------------------------------------------
+template <typename K>
+static hipError_t acr_dyn_lds(K kernel, bool (&attr_set)[64])
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcrMaxLds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    return hipSuccess;
+}
+static int acr_chains_width(const AcrChains& chains, int n_chains)
+{
+    int P = 64;
+    for (int c = 0; c < n_chains; ++c) while (P < chains.c[c].pb.n) P <<= 1;
+    return P;
+}
+template <int E>
+static hipError_t acr_launch_round_p3p_chains(const AcrChains& chains, int n_chains, int B, int P, int par, hipStream_t stream)
+{
+    static bool attr_set[64] = {};
+    const hipError_t e = acr_dyn_lds(acr_round_chains_kernel<E>, attr_set);
+    if (e != hipSuccess) return e;
+    const int T = P / E;
+    const size_t lds = (T > 64 ? (size_t)P * 8 : 0) + (E <= 8 ? (size_t)P * 8 : 0);
+    hipLaunchKernelGGL(acr_round_chains_kernel<E>, dim3(B * 4 + 1 /* the keeper */, n_chains), dim3(T), lds, stream, chains, par, P);
+    return hipGetLastError();
+}
+hipError_t launch_acr_round_p3p_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream)
+{
+    if (n_chains < 1 || n_chains > kMaxBatch) return hipErrorInvalidValue;
+    const int B = batch_bound < 1 ? 1 : (batch_bound > kAcrMaxBatch ? kAcrMaxBatch : batch_bound);
+    const int P = acr_chains_width(chains, n_chains);                // every chain sorts at the widest chain's width: the order of its n real elements is the same
+    if (P <= 1024) return acr_launch_round_p3p_chains<1>(chains, n_chains, B, P, par, stream);
+    if (P == 2048) return acr_launch_round_p3p_chains<2>(chains, n_chains, B, P, par, stream);
+    if (P == 4096) return acr_launch_round_p3p_chains<4>(chains, n_chains, B, P, par, stream);
+    if (P == 8192) return acr_launch_round_p3p_chains<8>(chains, n_chains, B, P, par, stream);
+    return acr_launch_round_p3p_chains<16>(chains, n_chains, B, P, par, stream);
+}
+template <int E>
+static hipError_t acr_launch_nfa_chains(const AcrChains& chains, int n_chains, int B, int P, int par, hipStream_t stream)
+{
+    static bool attr_set[64] = {};
+    const hipError_t e = acr_dyn_lds(acr_nfa_chains_kernel<E>, attr_set);
+    if (e != hipSuccess) return e;
+    const int T = P / E;
+    const size_t lds = (T > 64 ? (size_t)P * 8 : 0) + (E <= 8 ? (size_t)P * 8 : 0);
+    hipLaunchKernelGGL(acr_nfa_chains_kernel<E>, dim3(B * 10, n_chains), dim3(T), lds, stream, chains, par, P);
+    return hipGetLastError();
+}
+hipError_t launch_acr_round_5pt_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream)
+{
+    if (n_chains < 1 || n_chains > kMaxBatch) return hipErrorInvalidValue;
+    const int B = batch_bound < 1 ? 1 : (batch_bound > kAcrMaxBatch ? kAcrMaxBatch : batch_bound);
+    const int P = acr_chains_width(chains, n_chains);
+    hipLaunchKernelGGL(acr_solve5_chains_kernel, dim3(B + 1 /* the keeper */, n_chains), dim3(64), 0, stream, chains, par);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (P <= 1024) return acr_launch_nfa_chains<1>(chains, n_chains, B, P, par, stream);
+    if (P == 2048) return acr_launch_nfa_chains<2>(chains, n_chains, B, P, par, stream);
+    if (P == 4096) return acr_launch_nfa_chains<4>(chains, n_chains, B, P, par, stream);
+    if (P == 8192) return acr_launch_nfa_chains<8>(chains, n_chains, B, P, par, stream);
+    return acr_launch_nfa_chains<16>(chains, n_chains, B, P, par, stream);
 }
 
 // inputs of a solve: pinned host block -> device workspace, by a launch instead of a copy command (a copy command runs on another

@@ -128,6 +128,7 @@ struct clc_ctx {
     // progress counters, the gates' error word (pinned host memory)
     hipStream_t stream2 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_group = nullptr;   // drive_group: the tail of a batch's shared launches, for the other contexts' streams to wait on
     uint32_t* d_progress = nullptr;
     uint32_t* h_gate_err = nullptr;
     int pair_chunks[kClatchMaxChunks] = {};   // default chunk list in groups of 8 query blocks (CLC_PAIR_CHUNKS), 0-terminated
@@ -459,6 +460,7 @@ int clc_ctx_destroy(clc_ctx* ctx)
     if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_group) (void)hipEventDestroy(ctx->ev_group);
     if (ctx->d_progress) (void)hipFree(ctx->d_progress);
     if (ctx->h_gate_err) (void)hipHostFree(ctx->h_gate_err);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1891,6 +1893,12 @@ struct AcrRun {
     bool five_point_three_launches = false;
     uint32_t round = 0, spins = 0;
     std::chrono::steady_clock::time_point wait_start;
+    // lockstep batches (drive_group): the solve's rounds ride in launches shared with the other solves of the batch, on group_stream; the
+    // run only watches its word -- `reported` = the round waited for has come out, `more` = it needs another one (bound: its batch bound)
+    bool grouped = false, reported = false, more = false;
+    hipStream_t group_stream = nullptr, refine_st = nullptr;
+    int first_bound = 0;
+    int batch_cap = kAcrMaxBatch;      // most iterations a round evaluates (CLC_ACR_BATCH_CAP; batches: see acr_batch_cap)
     unsigned long long* h_word = nullptr;
     AcrResult* h_res = nullptr;
     int32_t* p_inl = nullptr;
@@ -1965,6 +1973,8 @@ struct AcrRun {
         // the resection round is ONE launch per round that reads what the launch before it wrote: two copies of state, models, slots
         // and sorted lists, indexed by launch parity (acransac.hip: acr_round_kernel)
         { const char* e = getenv("CLC_ACR_5PT_LAUNCHES"); five_point_three_launches = kind == 1 && e && e[0] == '3'; }
+        if (grouped) batch_cap = 16;                                   // (a shared launch carries every chain's speculative slots: shorter rounds)
+        if (const char* e = getenv("CLC_ACR_BATCH_CAP")) { const int v = atoi(e); if (v >= 1 && v <= kAcrMaxBatch) batch_cap = v; }
         const bool two_copies = kind == 0 || !five_point_three_launches;
         const int copies = two_copies ? 2 : 1;
         const size_t models_d = (size_t)copies * kAcrMaxBatch * M * md;
@@ -2018,8 +2028,8 @@ struct AcrRun {
         h_init->n_iter = max_iteration - h_init->reserve;
         h_init->n_index = N; h_init->index_all = 1;
         h_init->ac_mode = std::isinf(precision) ? 1 : 0;
-        h_init->grow = 32;
-        h_init->cur_batch = h_init->n_iter < 32 ? h_init->n_iter : 32;
+        h_init->grow = batch_cap < 32 ? batch_cap : 32;
+        h_init->cur_batch = h_init->n_iter < h_init->grow ? h_init->n_iter : h_init->grow;
         if (kind == 1 && five_point_three_launches) {      // (the other rounds draw their own samples on the device)
             const int nb = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
             for (int it = 0; it < nb; ++it) {
@@ -2035,7 +2045,7 @@ struct AcrRun {
         __atomic_store_n(h_word, 0ull, __ATOMIC_RELAXED);
 
         pb = AcrProblem{};
-        pb.kind = kind; pb.n = N; pb.m = m; pb.max_models = M; pb.model_doubles = md;
+        pb.kind = kind; pb.n = N; pb.m = m; pb.max_models = M; pb.model_doubles = md; pb.batch_cap = batch_cap;
         pb.a = d_a; pb.b = d_b; pb.K1 = d_K1; pb.K2 = d_K2; pb.logc_n = d_cn; pb.logc_k = d_ck;
         pb.loge0 = clc_acr_log10((double)M * (double)(N - m));
         if (kind == 0) {
@@ -2054,9 +2064,9 @@ struct AcrRun {
         pb.max_threshold = std::isinf(precision) ? INFINITY : precision * (pb.norm * pb.norm);
         pb.seed = seed;
 
-        st = ctx->stream;
+        st = grouped ? group_stream : ctx->stream;
         CLC_HIP(ctx, launch_acr_stage(hp, ctx->d_pnp, (in_d + 1) & ~(size_t)1, st));      // (both blocks are sized past in_d + 1)
-        prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
+        if (!grouped) prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
         // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
         // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
         // select straight into the next round's solve while the host is still polling (a 10 us bubble per round otherwise).
@@ -2065,17 +2075,36 @@ struct AcrRun {
         // device): while the index set has not switched the batch doubles up to kAcrMaxBatch; afterwards it is what is left of the
         // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
         reserve0 = h_init->reserve;
-        bound = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
-        int rc2 = enqueue_round(two_copies ? h_init->cur_batch : bound);     // (a replaying launch takes its first batch as it stands)
-        if (rc2 != CLC_OK) return drained(rc2);
-        rc2 = enqueue_round(bound);                                     // speculative: the round after the one being waited for
-        if (rc2 != CLC_OK) return drained(rc2);
+        bound = h_init->n_iter < batch_cap ? h_init->n_iter : batch_cap;
+        first_bound = two_copies ? h_init->cur_batch : bound;          // (a replaying launch takes its first batch as it stands)
+        if (!grouped) {
+            int rc2 = enqueue_round(first_bound);
+            if (rc2 != CLC_OK) return drained(rc2);
+            rc2 = enqueue_round(bound);                                 // speculative: the round after the one being waited for
+            if (rc2 != CLC_OK) return drained(rc2);
+        }                                                               // (grouped: drive_group enqueues the shared launches)
         round = 1;
         spins = 0;
+        reported = false; more = false;
         wait_start = std::chrono::steady_clock::now();
         phase = ROUNDS;
         status = CLC_OK;
         return CLC_OK;
+    }
+
+    // this solve's part of a shared launch
+    void chain(AcrChain& c) const
+    {
+        c.pb = pb;
+        c.states = d_state; c.hyps = d_hyp; c.sorted = d_sorted; c.models = d_models; c.best_inliers = d_best; c.index_set = d_index;
+        c.h_word = h_word;
+        c.fin = AcrFinish{ d_mask, d_res, nullptr, p_inl, h_res };
+    }
+    // the shared launch of the next round is in the stream: wait for that round's word
+    void advance()
+    {
+        ++round; spins = 0; reported = false; more = false;
+        wait_start = std::chrono::steady_clock::now();
     }
 
     // One look at the progress word / the refinement's ready flag.  Returns the status; phase == DONE when the solve has ended.
@@ -2098,8 +2127,9 @@ struct AcrRun {
             if (iter_k < n_iter_k) {
                 const bool switched = ((w >> 48) & 1u) != 0;
                 const long left = (long)n_iter_k - iter_k + 4 + (switched ? 0 : reserve0);
-                bound = left > kAcrMaxBatch ? kAcrMaxBatch : (int)left;
+                bound = left > batch_cap ? batch_cap : (int)left;
                 if (round > 0x7000u) return drained(fail(ctx, CLC_ERR_STATE, "acransac: too many rounds"));
+                if (grouped) { reported = true; more = true; return CLC_OK; }      // (drive_group enqueues the batch's next launch)
                 const int rc = enqueue_round(bound);                   // speculative: the round after the one being waited for
                 if (rc != CLC_OK) return drained(rc);
                 ++round;
@@ -2108,7 +2138,8 @@ struct AcrRun {
                 return CLC_OK;
             }
             // done: the completing round has left the result in pinned memory
-            prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);
+            reported = true; more = false;
+            if (!grouped) prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, false, st);
             // The result record, mask and inlier list were written by the round that completed the run BEFORE its word (system-scope
             // release / acquire): no finish launch, and without refinement no stream synchronisation either -- the round enqueued ahead is
             // still in the stream, evaluates nothing and touches no host memory; anything enqueued later on this stream is ordered behind it.
@@ -2116,10 +2147,14 @@ struct AcrRun {
             // Behind the launch that completed the run, on the same stream (nothing is queued behind that launch any more: the word of
             // the last round comes out of the last launch).  The refinement writes its record into pinned memory and sets `ready` last;
             // the host polls that instead of synchronising the stream (~5 us), with the synchronisation as the fallback after 5 ms.
+            // (A grouped run refines on its OWN context's stream: the shared stream still carries the other solves' rounds.  What the
+            // refinement reads was written before the word the host has just seen -- system-scope release / acquire -- so the launch
+            // needs no ordering against the shared stream.)
             ready = (int32_t*)((uint8_t*)p_ref + pnp_refine_ready_offset());
             __atomic_store_n(ready, 0, __ATOMIC_RELAXED);
+            refine_st = grouped ? ctx->stream : st;
             const hipError_t e = launch_pnp_refine((const double*)d_res /* AcrResult.model = [R|t] */, d_a, d_b, d_mask, N, d_K1, refine_huber, 50,
-                                                   d_ref, st, &ctx->prof, &d_res->valid, p_ref);
+                                                   d_ref, refine_st, &ctx->prof, &d_res->valid, p_ref);
             if (e != hipSuccess) return drained(fail(ctx, CLC_ERR_HIP, "launch_pnp_refine", e));
             spins = 0;
             wait_start = std::chrono::steady_clock::now();
@@ -2129,8 +2164,8 @@ struct AcrRun {
         if (phase == REFINE) {
             if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) {
                 if ((++spins & 1023u) == 0 && std::chrono::steady_clock::now() - wait_start > std::chrono::milliseconds(5)) {
-                    const hipError_t e = hipStreamSynchronize(st);
-                    if (e != hipSuccess) return drained(fail(ctx, CLC_ERR_HIP, "hipStreamSynchronize(st)", e));
+                    const hipError_t e = hipStreamSynchronize(refine_st);
+                    if (e != hipSuccess) return drained(fail(ctx, CLC_ERR_HIP, "hipStreamSynchronize(refine stream)", e));
                     if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) == 0) return drained(fail(ctx, CLC_ERR_HIP, "acransac: refinement did not complete"));
                 } else return CLC_OK;
             }
@@ -2183,6 +2218,90 @@ void drive_runs(std::vector<AcrRun>& runs)
             (void)r.poll();
             if (r.phase == AcrRun::DONE) --live;
         }
+}
+
+// Lockstep form of the same (round 5, the default of the batched entries): the batch's solves -- one kind, contexts on one device -- share
+// their launches.  Round r of every unfinished solve is ONE launch (resection) or two (two-view) with blockIdx.y = solve
+// (launch_acr_round_*_chains), on the first context's stream, enqueued one ahead as for a single solve; the host waits for the round's
+// words of all unfinished solves and enqueues the next shared launch while any of them needs one.  A finished solve's part of the later
+// launches finds nothing to replay and returns.  Why: eight interleaved poses were ~80 launches from one thread (4-5 us each inside the
+// runtime, and the runtime serialises launching threads), eight two-view filters ~100; in lockstep they are ~10 and ~16.  Same bits per
+// solve: a chain's kernels take its batch from its own device state, the grid and the sort width (the largest chain's) only bound them.
+// Measured (MI355X, N = 1 000, 30 % outliers, tools/time_two_view.py / time_pose_batch2.py; interleaved -> lockstep):
+//     two-view filters   2: 0.417 -> 0.439 ms   4: 0.570 -> 0.574   8: 1.08-1.21 -> 0.79-0.85      (rounds of <= 16 iterations: 0.79)
+//     resection poses    2: 0.200 -> 0.239      4: 0.244 -> 0.327   8: 0.504 -> 0.589 (0.456 with rounds of <= 8 iterations)
+// The two-view round is a 44 us chain of dependent fp64 steps in ONE wave per iteration -- eight chains' solves in one launch cost what one
+// costs --, the resection round is 100+ workgroups of sorting per chain that fill the chip either way.  Default: lockstep for two-view
+// batches of four or more; CLC_ACR_LOCKSTEP=1 / =0 forces it on (any batch of two or more) / off for both kinds.
+bool acr_lockstep(const int kind, const int n_jobs)
+{
+    static const int mode = [] { const char* e = getenv("CLC_ACR_LOCKSTEP"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    if (n_jobs < 2 || mode == 0) return false;
+    if (mode == 1) return true;
+    return kind == 1 && n_jobs >= 4;
+}
+bool acr_three_launch_rounds()
+{
+    const char* e = getenv("CLC_ACR_5PT_LAUNCHES");
+    return e && e[0] == '3';
+}
+void drive_group(std::vector<AcrRun>& runs)
+{
+    std::vector<AcrRun*> live;
+    for (AcrRun& r : runs) if (r.phase == AcrRun::ROUNDS && r.grouped) live.push_back(&r);
+    if (live.empty()) { drive_runs(runs); return; }
+    const int kind = live[0]->kind;
+    hipStream_t st = live[0]->group_stream;
+    clc_ctx* ctx0 = live[0]->ctx;
+    // the chains' launch arguments, kMaxBatch per launch
+    std::vector<AcrChains> packs((live.size() + kMaxBatch - 1) / kMaxBatch);
+    for (size_t i = 0; i < live.size(); ++i) live[i]->chain(packs[i / kMaxBatch].c[i % kMaxBatch]);
+    int launches = 0;
+    auto fail_all = [&](const int code) { for (AcrRun* r : live) if (r->phase != AcrRun::DONE) (void)r->drained(code); };
+    auto enqueue = [&](const int bound) -> bool {
+        if (hipSetDevice(ctx0->device) != hipSuccess) { fail_all(fail(ctx0, CLC_ERR_HIP, "hipSetDevice")); return false; }
+        for (size_t k = 0; k < packs.size(); ++k) {
+            const int n = (int)std::min<size_t>(kMaxBatch, live.size() - k * kMaxBatch);
+            const hipError_t e = kind == 0 ? launch_acr_round_p3p_chains(packs[k], n, launches & 1, bound, st)
+                                           : launch_acr_round_5pt_chains(packs[k], n, launches & 1, bound, st);
+            if (e != hipSuccess) { fail_all(fail(ctx0, CLC_ERR_HIP, "acransac: shared round launch", e)); return false; }
+        }
+        ++launches;
+        return true;
+    };
+    int b0 = 1, b1 = 1;
+    for (AcrRun* r : live) { b0 = std::max(b0, r->first_bound); b1 = std::max(b1, r->bound); }
+    if (!enqueue(b0) || !enqueue(b1)) return;                        // the second: speculative, the round after the one being waited for
+    for (;;) {
+        bool any_live = false, rounds_waiting = false, any_more = false;
+        int bnd = 1;
+        for (AcrRun* r : live) {
+            if (r->phase == AcrRun::DONE) continue;
+            any_live = true;
+            if (!(r->phase == AcrRun::ROUNDS && r->reported)) (void)r->poll();   // ROUNDS: one look at the word; REFINE: one look at the record
+            if (r->phase != AcrRun::ROUNDS) continue;
+            if (!r->reported) rounds_waiting = true;                  // (in its rounds and reported = it needs another round)
+            else { any_more = true; bnd = std::max(bnd, r->bound); }
+        }
+        if (!any_live) break;
+        if (any_more && !rounds_waiting) {
+            // every solve still in its rounds has reported the round waited for: the next shared launch (refinements of finished solves
+            // may still be out on their own streams; they do not hold the rounds up)
+            if (!enqueue(bnd)) return;
+            for (AcrRun* r : live) if (r->phase == AcrRun::ROUNDS) r->advance();
+        }
+    }
+    // The launch enqueued ahead of the last round is still in the shared stream (it finds nothing to replay, but its keepers carry every
+    // chain's state forward inside that chain's workspace): whatever the other contexts enqueue next on THEIR streams -- the staging of
+    // their next solve, a refinement -- has to come behind it.  (Work on the shared stream is ordered by the stream.)
+    bool ordered = false;
+    if (ctx0->ev_group || hipEventCreateWithFlags(&ctx0->ev_group, hipEventDisableTiming) == hipSuccess) {
+        ordered = hipEventRecord(ctx0->ev_group, st) == hipSuccess;
+        for (AcrRun* r : live)
+            if (ordered && r->ctx->stream != st) ordered = hipStreamWaitEvent(r->ctx->stream, ctx0->ev_group, 0) == hipSuccess;
+    }
+    if (!ordered) (void)hipStreamSynchronize(st);
+    // (runs of the batch that were not part of the group -- early outs -- are DONE already)
 }
 
 int acr_impl(clc_ctx* ctx, int kind, const double* h_a, const double* h_b, int N, const double* h_K1, const double* h_K2, int img_w,
@@ -2241,9 +2360,11 @@ int clc_pnp_localize_ac_batch(clc_ctx* const* ctxs, clc_pose_job* jobs, int n_jo
     }
     std::vector<AcrRun> runs((size_t)n_jobs);
     int worst = CLC_OK, live = 0;
+    const bool lockstep = acr_lockstep(0, n_jobs);
     for (int i = 0; i < n_jobs; ++i) {
         clc_pose_job& jb = jobs[i];
         AcrRun& r = runs[(size_t)i];
+        r.grouped = lockstep; r.group_stream = ctxs[0]->stream;
         if (jb.Rt) memset(jb.Rt, 0, sizeof(double) * 12);
         if (jb.cov) memset(jb.cov, 0, sizeof(double) * 36);
         jb.n_inliers = 0; jb.error_max = 0.0; jb.rmse = 0.0; jb.iterations = 0;
@@ -2252,11 +2373,11 @@ int clc_pnp_localize_ac_batch(clc_ctx* const* ctxs, clc_pose_job* jobs, int n_jo
         r.refine_huber = jb.refine ? (jb.huber_a > 0.0 ? jb.huber_a : 16.0) : -1.0;
         r.h_model = jb.Rt; r.h_mask = jb.inlier_mask; r.h_inliers = jb.inliers; r.n_inliers = &jb.n_inliers; r.error_max = &jb.error_max;
         r.iterations = &jb.iterations; r.h_cov = jb.cov; r.rmse = &jb.rmse;
-        jb.status = r.begin();                        // stages this job's inputs and puts its first two rounds into its context's stream
+        jb.status = r.begin();                        // stages this job's inputs (and, on its own, puts its first two rounds into its context's stream)
         if (r.phase != AcrRun::DONE) ++live;
     }
     (void)live;
-    drive_runs(runs);
+    if (lockstep) drive_group(runs); else drive_runs(runs);
     for (int i = 0; i < n_jobs; ++i) {
         AcrRun& r = runs[(size_t)i];
         r.finish();
@@ -2283,8 +2404,9 @@ int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2,
 // ---- several two-view problems at once / the inter-camera step behind the C ABI (round 5) -----------------------------------
 namespace {
 
-void two_view_begin(AcrRun& r, clc_ctx* ctx, clc_two_view_job& jb, double* EF)
+void two_view_begin(AcrRun& r, clc_ctx* ctx, clc_two_view_job& jb, double* EF, const bool lockstep, hipStream_t group_stream)
 {
+    r.grouped = lockstep; r.group_stream = group_stream;
     if (jb.E) memset(jb.E, 0, sizeof(double) * 9);
     if (jb.F) memset(jb.F, 0, sizeof(double) * 9);
     jb.n_inliers = 0; jb.iterations = 0; jb.error_max = 0.0; jb.min_nfa = INFINITY;
@@ -2470,8 +2592,9 @@ int clc_essential_acransac_batch(clc_ctx* const* ctxs, clc_two_view_job* jobs, i
     if (rc0 != CLC_OK) return rc0;
     std::vector<AcrRun> runs((size_t)n_jobs);
     std::vector<double> EF((size_t)18 * n_jobs, 0.0);
-    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i], &EF[(size_t)18 * i]);
-    drive_runs(runs);
+    const bool lockstep = acr_lockstep(1, n_jobs) && !acr_three_launch_rounds();
+    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i], &EF[(size_t)18 * i], lockstep, ctxs[0]->stream);
+    if (lockstep) drive_group(runs); else drive_runs(runs);
     int worst = CLC_OK;
     for (int i = 0; i < n_jobs; ++i) {
         AcrRun& r = runs[(size_t)i];
@@ -2500,8 +2623,9 @@ int clc_inter_pose_batch(clc_ctx* const* ctxs, clc_inter_pose_job* jobs, int n_j
     // 1. the a-contrario five-point filters of all pairs, their chains of launches interleaved
     std::vector<AcrRun> runs((size_t)n_jobs);
     std::vector<double> EF((size_t)18 * n_jobs, 0.0);
-    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i].tv, &EF[(size_t)18 * i]);
-    drive_runs(runs);
+    const bool lockstep = acr_lockstep(1, n_jobs) && !acr_three_launch_rounds();
+    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i].tv, &EF[(size_t)18 * i], lockstep, ctxs[0]->stream);
+    if (lockstep) drive_group(runs); else drive_runs(runs);
     int worst = CLC_OK;
     struct Pending { int job; int32_t* ready; double* rec; };
     std::vector<Pending> pend;

@@ -217,6 +217,7 @@ static constexpr size_t kAcrMaxLds = (size_t)kAcrMaxN * 8;
 struct AcrProblem {        // passed by value to every kernel of a solve
     int kind;              // 0: resection (P3P, [R|t] models of 12 doubles), 1: essential (five-point, {F, E} models of 18)
     int n, m, max_models, model_doubles;
+    int batch_cap;         // most iterations a round evaluates (<= kAcrMaxBatch): the schedule, not the result, depends on it
     const double* a;       // X (3 n)  | x1 (2 n)
     const double* b;       // x (2 n)  | x2 (2 n)
     const double* K1;      // 9 doubles row-major (+ padding)
@@ -250,6 +251,26 @@ struct AcrResult {
 };
 struct AcrHyp;
 size_t acr_hyp_bytes();
+// where the round that COMPLETES a run leaves the result (the finish work rides in that round's launch, and the host returns as soon as
+// the polled word says "done" instead of launching a finish kernel behind the round enqueued ahead)
+struct AcrFinish {
+    uint8_t* d_mask; AcrResult* d_res;                 // device copies (the refinement reads them)
+    uint8_t* h_mask; int32_t* h_inliers; AcrResult* h_res;     // pinned host memory (nullable)
+};
+// Everything the launches of ONE solve work on; up to kMaxBatch solves of one kind share a launch (blockIdx.y = chain): their rounds then
+// advance in lockstep, one launch (resection) or two (two-view) per round for all of them (round 5: the batched entries were bound by the
+// host's launch calls -- 8 poses = ~80 launches from one thread).
+struct AcrChain {
+    AcrProblem pb;
+    AcrState* states; AcrHyp* hyps; uint32_t* sorted; double* models;      // two copies each, indexed by launch parity
+    uint32_t* best_inliers; uint32_t* index_set;
+    unsigned long long* h_word;
+    AcrFinish fin;
+};
+struct AcrChains { AcrChain c[kMaxBatch]; };
+// one round of n_chains solves: P3P (one launch) / five-point (two launches); batch_bound and the sort width cover the largest chain
+hipError_t launch_acr_round_p3p_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream);
+hipError_t launch_acr_round_5pt_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream);
 // nfa + select of one batch (state->cur_batch iterations) whose models are in d_models (max_models slots each)
 // batch_bound: iterations the launch grids cover (>= the batch the device state asks for); d_mask .. h_res: where the round that
 // completes the run leaves mask / inlier list / result record (device copies + pinned host mirrors)

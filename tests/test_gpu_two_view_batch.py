@@ -169,3 +169,52 @@ def test_two_launch_round_equals_the_three_launch_round():
         res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0][6:])
     assert res["2"] == res["3"]
     assert all(len(r["inl"]) > 100 for r in res["2"])
+
+
+def test_lockstep_batches_equal_interleaved_batches_equal_single_solves():
+    """Round 5: the solves of a batch may share their launches (lockstep: one launch per round for all of them, blockIdx.y = solve) instead of
+    interleaving chains of their own -- the default for two-view batches of four or more, CLC_ACR_LOCKSTEP=1 / =0 forces it on / off for
+    both kinds.  A chain's kernels take their batch from the chain's own device state; the shared grid and the shared sort width (the
+    widest chain's) only bound them: every job -- ten two-view filters of 150 .. 2 400 correspondences (two launches per round: more
+    than eight chains), a job below the minimal sample, six resection solves with refinement -- identical in both forms and to the
+    single-solve entries."""
+    import json
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_two_view_batch as t, synth\n"
+            "from coloc_amd import Context\n"
+            "from coloc_amd.abi import essential_acransac_batch, pnp_localize_batch\n"
+            "ctxs = [Context(device=0, detector=False, matcher=False) for _ in range(10)]\n"
+            "ns = [150, 2400, 600, 900, 1100, 300, 1700, 450, 1300, 800]\n"
+            "pairs = [t._pair(500 + i, n=ns[i]) for i in range(10)]\n"
+            "probs = [(p['x1'], p['x2'], t.K, t.K, t.WH, 31 + i) for i, p in enumerate(pairs)]\n"
+            "probs[4] = (pairs[4]['x1'][:5], pairs[4]['x2'][:5], t.K, t.K, t.WH, 1)\n"
+            "out = dict(tv=[], tv1=[], pnp=[], pnp1=[])\n"
+            "def tv(r): return dict(E=None if r['E'] is None else r['E'].tolist(), inl=r['inliers'].tolist(), emax=r['error_max'], nfa=r['min_nfa'], it=r['iterations'])\n"
+            "for rep in range(2):\n"
+            "    got = essential_acransac_batch(ctxs, probs)\n"
+            "out['tv'] = [tv(r) for r in got]\n"
+            "out['tv1'] = [tv(ctxs[0].essential_acransac(x1, x2, t.K, t.K, t.WH, max_iteration=256, seed=s)) for (x1, x2, _, _, _, s) in probs]\n"
+            "scenes = [synth.pnp_scene(400 + 350 * c, seed=900 + c, outlier_frac=0.3) for c in range(6)]\n"
+            "pp = [(s['X'], s['x'], s['K']) for s in scenes]\n"
+            "def pn(r): return dict(Rt=np.asarray(r['Rt']).tolist(), cov=np.asarray(r['cov']).tolist(), inl=np.asarray(r['inliers']).tolist(), it=r['iterations'], rmse=r['rmse'])\n"
+            "for rep in range(2):\n"
+            "    gp = pnp_localize_batch(ctxs[:6], pp, max_iteration=256, seeds=list(range(21, 27)), refine=True)\n"
+            "out['pnp'] = [pn(r) for r in gp]\n"
+            "out['pnp1'] = [pn(pnp_localize_batch([ctxs[7]], [pp[c]], max_iteration=256, seeds=[21 + c], refine=True)[0]) for c in range(6)]\n"
+            "print('RESULT' + json.dumps(out))" % (os.path.dirname(here), here))
+    res = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ)
+        env["CLC_ACR_LOCKSTEP"] = mode
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0][6:])
+    for mode in ("1", "0"):
+        assert res[mode]["tv"] == res[mode]["tv1"], mode
+        assert res[mode]["pnp"] == res[mode]["pnp1"], mode
+    assert res["1"] == res["0"]
+    assert res["1"]["tv"][4]["E"] is None and all(len(r["inl"]) > 60 for i, r in enumerate(res["1"]["tv"]) if i != 4)
+    assert all(len(r["inl"]) > 200 for r in res["1"]["pnp"])

@@ -24,3 +24,15 @@ for it in range(105):
 te = np.sort(te[5:])
 print("essential_acransac p50 %.3f ms  p95 %.3f  iterations median %.0f  rounds median %.0f  inliers %d" % (te[len(te) // 2], te[int(len(te) * .95)], np.median(its), np.median(rounds), len(r["inliers"])))
 ctx.close()
+
+# the same problem as a batch of n pairs (clc_essential_acransac_batch; CLC_ACR_LOCKSTEP=0: the pairs' chains interleaved instead of shared launches)
+from coloc_amd.abi import essential_acransac_batch
+for nb in ([int(sys.argv[1])] if len(sys.argv) > 1 else [2, 4, 8]):
+    ctxs = [Context(device=0, detector=False, matcher=False) for _ in range(nb)]
+    probs = [(p1, p2, Kc, Kc, (1280, 720), 100 + i) for i in range(nb)]
+    tb = []
+    for rep in range(60):
+        t1 = time.perf_counter(); got = essential_acransac_batch(ctxs, probs); tb.append((time.perf_counter() - t1) * 1e3)
+    tb = np.sort(tb[5:])
+    print("batch of %d pairs (CLC_ACR_LOCKSTEP=%s): p50 %.3f ms = %.3f per pair, iterations %s" % (nb, os.environ.get("CLC_ACR_LOCKSTEP", "default"), tb[len(tb) // 2], tb[len(tb) // 2] / nb, [g["iterations"] for g in got]))
+    for c in ctxs: c.close()
