@@ -978,7 +978,8 @@ def main():
                                "p50_ms": float(np.median(te[5:])), "inliers": int(len(r["inliers"])), "iterations": int(r["iterations"]),
                                "fixed_threshold_p50_ms": float(np.median(tf[5:]))}
             # the same filter for 4 / 8 camera pairs in ONE clc_essential_acransac_batch call (what a frame of the streaming loop asks for):
-            # the chains of launches interleave on the device, results job by job those of the single calls
+            # the pairs' rounds share their launches (lockstep, blockIdx.y = pair; CLC_ACR_LOCKSTEP=0: chains of their own, interleaved --
+            # 8 pairs 1.08-1.21 ms against 0.80), results job by job those of the single calls
             from coloc_amd.abi import essential_acransac_batch
             for npair in (4, 8):
                 tcs = [Context(device=dev_index, detector=False, matcher=False) for _ in range(npair)]
@@ -992,7 +993,8 @@ def main():
                     one = ctx.essential_acransac(p1, p2, Kc, Kc, (1280, 720), max_iteration=256, seed=30 + npair - 1)
                     same = bool(np.array_equal(rb[-1]["inliers"], one["inliers"]) and np.array_equal(rb[-1]["E"], one["E"]))
                     out["two_view"]["batch_of_%d" % npair] = {"per_pair_p50_ms": float(np.median(tb[5:])) / npair, "batch_p50_ms": float(np.median(tb[5:])),
-                                                               "identical_to_single_call": same}
+                                                               "identical_to_single_call": same,
+                                                               "launches": os.environ.get("CLC_ACR_LOCKSTEP", "shared by the pairs (lockstep rounds)")}
                     if not same:
                         raise RuntimeError("batched two-view filter differs from the single call")
                 finally:

@@ -364,7 +364,9 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
         for k, (cam, nb) in enumerate(todo):
             c.match_2nn_dev(desc_ptr[nb], est[nb]["n"], desc_ptr[cam], est[cam]["n"], 60, dp[k].data_ptr(), cptr)
         with torch.cuda.stream(torch.cuda.ExternalStream(cptr)):
-            pms = [dp[k, :est[nb]["n"]].cpu().numpy() for k, (cam, nb) in enumerate(todo)]
+            nmax = max(est[nb]["n"] for _, nb in todo)
+            block = dp[:len(todo), :nmax].cpu().numpy()              # ONE copy + synchronisation for all pairs of the frame
+            pms = [block[k, :est[nb]["n"]] for k, (cam, nb) in enumerate(todo)]
         probs, meta = [], []
         for (cam, nb), pm in zip(todo, pms):
             S, D = est[nb], est[cam]
