@@ -249,10 +249,11 @@ def main():
     ap.add_argument("--no-exchange-legs", action="store_true",
                     help="N > 1 only: skip the informational legs that run the same step through clc-rccl and clc-peer and compare the matches")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events; implies --one-stream)")
+    ap.add_argument("--lanes", type=int, default=3, help="lanes of the pipelined N = 1 headline loop (contexts / streams taking consecutive steps in turn; measured 2 / 3 / 4 lanes: 0.0826 / 0.0804-0.0812 / 0.0810 ms per step)")
     ap.add_argument("--one-stream", action="store_true",
                     help="N = 1: every step on ONE stream, a step's sweep waiting for its own describe and the next step's describe for that sweep "
-                         "(rounds 1-4's headline).  Default since round 5: consecutive steps alternate between two contexts / streams / descriptor "
-                         "arenas, so that step i's sweep (matrix pipe) runs beside step i + 1's pyramid + CLATCH -- the only describe / sweep overlap "
+                         "(rounds 1-4's headline).  Default since round 5: consecutive steps are dealt to --lanes contexts / streams / descriptor "
+                         "arenas in turn, so that step i's sweep (matrix pipe) runs beside the next steps' pyramid + CLATCH -- the only describe / sweep overlap "
                          "this machine allows (profiles/r05_step_overlap.txt); the one-stream figure is then reported as `one_stream`.")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the informational side sections (other formulation, shares, config[2], front end, pose, two-view, host path): "
@@ -358,27 +359,29 @@ def main():
         if abi_jobs:
             ctx.match_jobs_dev(arena.data_ptr(), abi_jobs, d_match.data_ptr(), sptr)
 
-    # N = 1 headline loop (round 5): consecutive steps on alternating lanes = (context, stream, descriptor arena, match buffer).  A lane's
+    # N = 1 headline loop (round 5): consecutive steps dealt to the lanes in turn; lane = (context, stream, descriptor arena, match buffer).  A lane's
     # step is the whole step -- pyramid + CLATCH of both cameras, then the pair's sweep, in stream order --; what changes against ONE lane is
     # that the device is not drained between step i's sweep and step i + 1's describe: the sweep, dispatched first, holds 58 KB of a CU's
     # LDS and the matrix pipe, the next step's CLATCH waves fill the rest (profiles/r05_step_overlap.txt: inside one step the same overlap
     # is impossible).  One context per concurrently running stream is the library's rule (include/coloc_hip.h).
     pipelined = world == 1 and not args.one_stream and not args.graph and not args.per_camera_launches
-    ctx_b = None
+    extra_lanes = []                        # (context, torch stream, arena, match buffer) of lanes 1 ..
     if pipelined:
-        ctx_b = Context(device=dev_index, width=W, height=H, maxkp=NKP)
-        stream_b = torch.cuda.Stream(device=dev)
-        arena_b = torch.zeros_like(arena)
-        d_match_b = torch.empty_like(d_match)
-        lanes = [(ctx, sptr, arena, d_match, desc_ptrs),
-                 (ctx_b, stream_b.cuda_stream, arena_b, d_match_b, [arena_b[c].data_ptr() for c in cams])]
+        lanes = [(ctx, sptr, arena, d_match, desc_ptrs)]
+        for _ in range(max(2, min(args.lanes, 6)) - 1):
+            c_x = Context(device=dev_index, width=W, height=H, maxkp=NKP)
+            s_x = torch.cuda.Stream(device=dev)
+            a_x = torch.zeros_like(arena)
+            m_x = torch.empty_like(d_match)
+            extra_lanes.append((c_x, s_x, a_x, m_x))
+            lanes.append((c_x, s_x.cuda_stream, a_x, m_x, [a_x[c].data_ptr() for c in cams]))
     tick = [0]
 
     def step_h():
         """one step of the headline loop"""
         if not pipelined:
             return step()
-        c_, s_, a_, m_, dp_ = lanes[tick[0] & 1]
+        c_, s_, a_, m_, dp_ = lanes[tick[0] % len(lanes)]
         tick[0] += 1
         c_.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP] * len(cams), dp_, s_)
         c_.match_jobs_dev(a_.data_ptr(), abi_jobs, m_.data_ptr(), s_)
@@ -418,12 +421,12 @@ def main():
         fence()
     # timed region: K steps; the sweep kernel is bracketed by HIP events on its stream (both lanes' when the loop is pipelined)
     ctx.profile_reset()
-    if ctx_b is not None:
-        ctx_b.profile_reset()
+    for lx in extra_lanes:
+        lx[0].profile_reset()
     if graph is None:
         ctx.profile_enable(True, only=["k2nn_sweep_kernel"])
-        if ctx_b is not None:
-            ctx_b.profile_enable(True, only=["k2nn_sweep_kernel"])
+        for lx in extra_lanes:
+            lx[0].profile_enable(True, only=["k2nn_sweep_kernel"])
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if graph is not None:
@@ -437,12 +440,15 @@ def main():
     one_stream = None
     pipelined_info = None
     if pipelined:
-        ctx_b.profile_enable(False)
-        pb = ctx_b.profile_read()["k2nn_sweep_kernel"]
-        pa = prof["k2nn_sweep_kernel"]
-        same_lanes = bool(torch.equal(d_match[:n_out], d_match_b[:n_out]))
-        pipelined_info = {"sweep_us_while_overlapped": (pa[0] + pb[0]) / max(pa[1] + pb[1], 1) * 1e3, "sweep_launches": pa[1] + pb[1],
-                          "lanes_identical_results": same_lanes}
+        pa = list(prof["k2nn_sweep_kernel"])
+        same_lanes = True
+        for lx in extra_lanes:
+            lx[0].profile_enable(False)
+            px = lx[0].profile_read()["k2nn_sweep_kernel"]
+            pa[0] += px[0]; pa[1] += px[1]
+            same_lanes = same_lanes and bool(torch.equal(d_match[:n_out], lx[3][:n_out]))
+        pipelined_info = {"sweep_us_while_overlapped": pa[0] / max(pa[1], 1) * 1e3, "sweep_launches": pa[1],
+                          "lanes_identical_results": same_lanes, "lanes": len(lanes)}
         # the same K steps on ONE stream (the device drained between a step's kernels): rounds 1-4's headline, and the region the
         # roofline's per-kernel duration comes from -- a kernel's duration says something about the kernel only while it has the machine
         want_h = d_match[:n_out].clone()
@@ -680,9 +686,9 @@ def main():
             "roofline": roof,
             "k2nn_device": ctx.k2nn_device_info(),        # XCDs / CUs the sweep planner reads from the device, and where its unequal shares come from
             "launch_mode": ("hipGraph replay" if graph is not None else
-                            ("eager launches, consecutive steps on ALTERNATING lanes (two contexts / streams / descriptor arenas): step i's sweep runs beside "
-                             "step i + 1's pyramid + CLATCH; every step does all of its work, results identical to the one-stream loop's; "
-                             "`one_stream` = the same K steps with the device drained between a step's kernels (rounds 1-4's value)") if pipelined
+                            ("eager launches, consecutive steps dealt to %d LANES in turn (a lane = context + stream + descriptor arena): step i's sweep runs "
+                             "beside the next steps' pyramid + CLATCH; every step does all of its work, results identical to the one-stream loop's; "
+                             "`one_stream` = the same K steps with the device drained between a step's kernels (rounds 1-4's value)" % len(lanes)) if pipelined
                             else "eager launches, one stream"),
             "one_stream": one_stream,
             "pipelined": pipelined_info,
@@ -1166,8 +1172,8 @@ def main():
         os._exit(3)
     if mc is not None:
         mc.close()
-    if ctx_b is not None:
-        ctx_b.close()
+    for lx in extra_lanes:
+        lx[0].close()
     ctx.close()
     if world > 1:
         dist.barrier()                  # nobody tears the group down while another rank still uses it

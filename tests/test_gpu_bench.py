@@ -37,9 +37,9 @@ def test_default_line_has_contract_fields():
     assert 1.0 < r["clock_ghz_in_kernel"]["median"] <= 2.5          # the chip's real in-kernel clock, not an assumed 2.4
     assert d["sustained"]["seconds"] >= 1.0 and d["sustained"]["steps"] >= 20 and d["sustained_value"] > 0
     assert d["stages"]["k2nn_other_formulation"]["identical_results"] is True
-    # round 5: the headline loop alternates two lanes (contexts / streams), so that a step's sweep runs beside the next step's describe;
-    # the one-stream loop (rounds 1-4's headline, where `roofline` is measured) is reported beside it: same matches, not faster
-    assert "ALTERNATING" in d["launch_mode"] and d["pipelined"]["lanes_identical_results"] is True
+    # round 5: the headline loop deals consecutive steps to lanes (contexts / streams) in turn, so that a step's sweep runs beside the next
+    # steps' describe; the one-stream loop (rounds 1-4's headline, where `roofline` is measured) is reported beside it: same matches, not faster
+    assert "LANES" in d["launch_mode"] and d["pipelined"]["lanes_identical_results"] is True and d["pipelined"]["lanes"] == 3
     one = d["one_stream"]
     assert one["identical_results"] is True and d["ms_per_step"] < 1.02 * one["ms_per_step"] and one["steps"] == d["steps"]
     assert "one-stream" in r["measured_in"] and d["pipelined"]["sweep_us_while_overlapped"] >= 0.9 * r["avg_launch_us"]
