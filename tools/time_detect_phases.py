@@ -1,4 +1,5 @@
-"""phase timeline of two workgroups of detect_tile_kernel (variant build -DCLC_DET_STAMPS, CLC_DETECT_LAUNCHES=2): block 0 (a tile of the
+"""[needs a build with the stamp instrumentation of profiles/r05_detect_fused_emit.patch (apply it, then tools/build_variant.sh det_stamps -I../../include -DCLC_DET_STAMPS): the shipped library has no stamp symbol]
+phase timeline of two workgroups of detect_tile_kernel (variant build -DCLC_DET_STAMPS, CLC_DETECT_LAUNCHES=2): block 0 (a tile of the
 level that replays the KFAST.h:245 walk) and block 500; s_memrealtime stamps (10 ns) relative to the workgroup's entry."""
 import os, sys, ctypes
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,4 +1,5 @@
-"""timeline of the detector launch's LAST workgroup (variant build with -DCLC_DET_STAMPS: COLOC_HIP_LIB=tools/bin/det_stamps.so);
+"""[needs the one-launch detector of profiles/r05_detect_fused_emit.patch (apply it, then tools/build_variant.sh det_stamps -I../../include -DCLC_DET_STAMPS): the shipped library has no stamp symbol]
+timeline of the detector launch's LAST workgroup (variant build with -DCLC_DET_STAMPS: COLOC_HIP_LIB=tools/bin/det_stamps.so);
 s_memrealtime stamps (10 ns): entry, tile done, stores acknowledged, arrival returned, prefix known, band emitted, done counted, end."""
 import os, sys, ctypes
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
