@@ -1164,6 +1164,29 @@ hipError_t launch_acr_stage(const double* h_pinned, double* d_dst, size_t n_doub
     return hipGetLastError();
 }
 
+// the same for the solves of a lockstep batch in ONE launch (blockIdx.y = solve): eight staging launches on the shared stream were 75 us
+// of a batch's 400
+struct AcrStageJobs { const double2* src[kMaxBatch]; double2* dst[kMaxBatch]; int n2[kMaxBatch]; };
+__global__ __launch_bounds__(256) void acr_stage_chains_kernel(const AcrStageJobs jobs)
+{
+    const int c = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i < jobs.n2[c]) jobs.dst[c][i] = jobs.src[c][i];
+}
+hipError_t launch_acr_stage_chains(const double* const* h_pinned, double* const* d_dst, const size_t* n_doubles /* even */, int n_chains,
+                                   hipStream_t stream)
+{
+    if (n_chains < 1 || n_chains > kMaxBatch) return hipErrorInvalidValue;
+    AcrStageJobs jobs{};
+    int most = 0;
+    for (int c = 0; c < n_chains; ++c) {
+        jobs.src[c] = (const double2*)h_pinned[c]; jobs.dst[c] = (double2*)d_dst[c]; jobs.n2[c] = (int)(n_doubles[c] / 2);
+        most = jobs.n2[c] > most ? jobs.n2[c] : most;
+    }
+    if (most <= 0) return hipSuccess;
+    hipLaunchKernelGGL(acr_stage_chains_kernel, dim3((most + 255) / 256, n_chains), dim3(256), 0, stream, jobs);
+    return hipGetLastError();
+}
+
 hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
                              uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream)
 {

@@ -1898,6 +1898,7 @@ struct AcrRun {
     bool grouped = false, reported = false, more = false;
     hipStream_t group_stream = nullptr, refine_st = nullptr;
     int first_bound = 0;
+    const double* stage_src = nullptr; double* stage_dst = nullptr; size_t stage_n = 0;   // the inputs' way to the device (a launch, not a copy)
     int batch_cap = kAcrMaxBatch;      // most iterations a round evaluates (CLC_ACR_BATCH_CAP; batches: see acr_batch_cap)
     unsigned long long* h_word = nullptr;
     AcrResult* h_res = nullptr;
@@ -1973,7 +1974,7 @@ struct AcrRun {
         // the resection round is ONE launch per round that reads what the launch before it wrote: two copies of state, models, slots
         // and sorted lists, indexed by launch parity (acransac.hip: acr_round_kernel)
         { const char* e = getenv("CLC_ACR_5PT_LAUNCHES"); five_point_three_launches = kind == 1 && e && e[0] == '3'; }
-        if (grouped) batch_cap = 16;                                   // (a shared launch carries every chain's speculative slots: shorter rounds)
+        if (grouped) batch_cap = kind == 0 ? 8 : 12;                   // (a shared launch carries every chain's speculative slots: shorter rounds)
         if (const char* e = getenv("CLC_ACR_BATCH_CAP")) { const int v = atoi(e); if (v >= 1 && v <= kAcrMaxBatch) batch_cap = v; }
         const bool two_copies = kind == 0 || !five_point_three_launches;
         const int copies = two_copies ? 2 : 1;
@@ -2065,7 +2066,8 @@ struct AcrRun {
         pb.seed = seed;
 
         st = grouped ? group_stream : ctx->stream;
-        CLC_HIP(ctx, launch_acr_stage(hp, ctx->d_pnp, (in_d + 1) & ~(size_t)1, st));      // (both blocks are sized past in_d + 1)
+        stage_src = hp; stage_dst = ctx->d_pnp; stage_n = (in_d + 1) & ~(size_t)1;      // (both blocks are sized past in_d + 1)
+        if (!grouped) CLC_HIP(ctx, launch_acr_stage(stage_src, stage_dst, stage_n, st));  // (grouped: one launch for the batch, drive_group)
         if (!grouped) prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
         // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
         // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
@@ -2227,18 +2229,22 @@ void drive_runs(std::vector<AcrRun>& runs)
 // launches finds nothing to replay and returns.  Why: eight interleaved poses were ~80 launches from one thread (4-5 us each inside the
 // runtime, and the runtime serialises launching threads), eight two-view filters ~100; in lockstep they are ~10 and ~16.  Same bits per
 // solve: a chain's kernels take its batch from its own device state, the grid and the sort width (the largest chain's) only bound them.
-// Measured (MI355X, N = 1 000, 30 % outliers, tools/time_two_view.py / time_pose_batch2.py; interleaved -> lockstep):
-//     two-view filters   2: 0.417 -> 0.439 ms   4: 0.570 -> 0.574   8: 1.08-1.21 -> 0.79-0.85      (rounds of <= 16 iterations: 0.79)
-//     resection poses    2: 0.200 -> 0.239      4: 0.244 -> 0.327   8: 0.504 -> 0.589 (0.456 with rounds of <= 8 iterations)
-// The two-view round is a 44 us chain of dependent fp64 steps in ONE wave per iteration -- eight chains' solves in one launch cost what one
-// costs --, the resection round is 100+ workgroups of sorting per chain that fill the chip either way.  Default: lockstep for two-view
-// batches of four or more; CLC_ACR_LOCKSTEP=1 / =0 forces it on (any batch of two or more) / off for both kinds.
+// Measured (MI355X, N = 1 000, 30 % outliers, tools/time_two_view.py / time_pose_batch2.py; interleaved -> lockstep, one staging launch
+// for the batch, a round's launches carrying only the solves still in their rounds):
+//     two-view filters   2: 0.417 -> 0.439 ms   4: 0.570 -> 0.574   8: 1.08-1.21 -> 0.75-0.80      (rounds of <= 12 / 16 iterations)
+//     resection poses    2: 0.190 -> 0.189      4: 0.251 -> 0.271   8: 0.514 -> 0.508; with rounds of <= 8 iterations 0.429 (4: 0.295)
+// The interleaved batch is bound by the host's launch calls (eight poses = ~70 launches of 5-7 us from one thread, two of them in flight on
+// the device at a time); in lockstep eight poses are ~12 launches, but each carries every solve's speculative slots -- 8 x 32 iterations x 4
+// models of 1 024 threads do not fit the chip at once (33 us per round against 17.5) -- hence the cap on a round's iterations, which costs
+// rounds.  The two-view round is a 44 us chain of dependent fp64 steps in ONE wave per iteration: eight chains' solves in one launch cost
+// what one costs.  Default: lockstep for two-view batches of four or more (rounds of <= 12 iterations) and resection batches of eight or
+// more (<= 8); CLC_ACR_LOCKSTEP=1 / =0 forces it on (any batch of two or more) / off for both kinds, CLC_ACR_BATCH_CAP the iterations.
 bool acr_lockstep(const int kind, const int n_jobs)
 {
     static const int mode = [] { const char* e = getenv("CLC_ACR_LOCKSTEP"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
     if (n_jobs < 2 || mode == 0) return false;
     if (mode == 1) return true;
-    return kind == 1 && n_jobs >= 4;
+    return kind == 1 ? n_jobs >= 4 : n_jobs >= 8;
 }
 bool acr_three_launch_rounds()
 {
@@ -2253,19 +2259,36 @@ void drive_group(std::vector<AcrRun>& runs)
     const int kind = live[0]->kind;
     hipStream_t st = live[0]->group_stream;
     clc_ctx* ctx0 = live[0]->ctx;
-    // the chains' launch arguments, kMaxBatch per launch
-    std::vector<AcrChains> packs((live.size() + kMaxBatch - 1) / kMaxBatch);
-    for (size_t i = 0; i < live.size(); ++i) live[i]->chain(packs[i / kMaxBatch].c[i % kMaxBatch]);
     int launches = 0;
     auto fail_all = [&](const int code) { for (AcrRun* r : live) if (r->phase != AcrRun::DONE) (void)r->drained(code); };
+    if (hipSetDevice(ctx0->device) != hipSuccess) { fail_all(fail(ctx0, CLC_ERR_HIP, "hipSetDevice")); return; }
+    // the inputs of all solves: one staging launch per kMaxBatch of them
+    for (size_t k = 0; k < live.size(); k += kMaxBatch) {
+        const int n = (int)std::min<size_t>(kMaxBatch, live.size() - k);
+        const double* src[kMaxBatch]; double* dst[kMaxBatch]; size_t cnt[kMaxBatch];
+        for (int i = 0; i < n; ++i) { src[i] = live[k + i]->stage_src; dst[i] = live[k + i]->stage_dst; cnt[i] = live[k + i]->stage_n; }
+        const hipError_t e = launch_acr_stage_chains(src, dst, cnt, n, st);
+        if (e != hipSuccess) { fail_all(fail(ctx0, CLC_ERR_HIP, "acransac: shared staging launch", e)); return; }
+    }
+    // a round's launches carry the solves that are still in their rounds (what the host knows when it enqueues: a solve that finishes in
+    // the round being waited for rides along once more and finds nothing to replay), kMaxBatch per launch
     auto enqueue = [&](const int bound) -> bool {
-        if (hipSetDevice(ctx0->device) != hipSuccess) { fail_all(fail(ctx0, CLC_ERR_HIP, "hipSetDevice")); return false; }
-        for (size_t k = 0; k < packs.size(); ++k) {
-            const int n = (int)std::min<size_t>(kMaxBatch, live.size() - k * kMaxBatch);
-            const hipError_t e = kind == 0 ? launch_acr_round_p3p_chains(packs[k], n, launches & 1, bound, st)
-                                           : launch_acr_round_5pt_chains(packs[k], n, launches & 1, bound, st);
+        AcrChains pack;
+        int n = 0;
+        auto flush = [&]() -> bool {
+            if (n == 0) return true;
+            const hipError_t e = kind == 0 ? launch_acr_round_p3p_chains(pack, n, launches & 1, bound, st)
+                                           : launch_acr_round_5pt_chains(pack, n, launches & 1, bound, st);
+            n = 0;
             if (e != hipSuccess) { fail_all(fail(ctx0, CLC_ERR_HIP, "acransac: shared round launch", e)); return false; }
+            return true;
+        };
+        for (AcrRun* r : live) {
+            if (r->phase != AcrRun::ROUNDS) continue;
+            r->chain(pack.c[n++]);
+            if (n == kMaxBatch && !flush()) return false;
         }
+        if (!flush()) return false;
         ++launches;
         return true;
     };

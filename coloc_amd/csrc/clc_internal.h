@@ -288,6 +288,8 @@ hipError_t launch_acr_round_5pt(const AcrProblem& pb, int par, AcrState* d_state
                                 uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word, hipStream_t stream,
                                 int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res);
 hipError_t launch_acr_stage(const double* h_pinned, double* d_dst, size_t n_doubles /* even */, hipStream_t stream);
+hipError_t launch_acr_stage_chains(const double* const* h_pinned, double* const* d_dst, const size_t* n_doubles /* even */, int n_chains,
+                                   hipStream_t stream);
 hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
                              uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream);
 
