@@ -177,7 +177,8 @@ def test_lockstep_batches_equal_interleaved_batches_equal_single_solves():
     both kinds.  A chain's kernels take their batch from the chain's own device state; the shared grid and the shared sort width (the
     widest chain's) only bound them: every job -- ten two-view filters of 150 .. 2 400 correspondences (two launches per round: more
     than eight chains), a job below the minimal sample, six resection solves with refinement -- identical in both forms and to the
-    single-solve entries."""
+    single-solve entries; a third run caps a round at five iterations (CLC_ACR_BATCH_CAP: lockstep groups use 8 / 12): the
+    schedule changes, no result does."""
     import json
     import os
     import subprocess
@@ -206,15 +207,18 @@ def test_lockstep_batches_equal_interleaved_batches_equal_single_solves():
             "out['pnp1'] = [pn(pnp_localize_batch([ctxs[7]], [pp[c]], max_iteration=256, seeds=[21 + c], refine=True)[0]) for c in range(6)]\n"
             "print('RESULT' + json.dumps(out))" % (os.path.dirname(here), here))
     res = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "cap5"):
         env = dict(os.environ)
-        env["CLC_ACR_LOCKSTEP"] = mode
+        env.pop("CLC_ACR_BATCH_CAP", None)
+        env["CLC_ACR_LOCKSTEP"] = "1" if mode == "cap5" else mode
+        if mode == "cap5":
+            env["CLC_ACR_BATCH_CAP"] = "5"          # rounds of at most five iterations: another schedule, the same sequential semantics
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0][6:])
-    for mode in ("1", "0"):
+    for mode in ("1", "0", "cap5"):
         assert res[mode]["tv"] == res[mode]["tv1"], mode
         assert res[mode]["pnp"] == res[mode]["pnp1"], mode
-    assert res["1"] == res["0"]
+    assert res["1"] == res["0"] and res["1"] == res["cap5"]
     assert res["1"]["tv"][4]["E"] is None and all(len(r["inl"]) > 60 for i, r in enumerate(res["1"]["tv"]) if i != 4)
     assert all(len(r["inl"]) > 200 for r in res["1"]["pnp"])
