@@ -462,7 +462,11 @@ int clc_pnp_localize_ac(clc_ctx* ctx, const double* h_X, const double* h_x, int 
  * without detector and matcher options are enough).  A solve is a chain of short launches with the host in the loop and leaves the GPU idle
  * most of the time; here ONE host thread drives all the chains, so they interleave on the device.  Every job's result is the one the
  * single-solve entry gives for the same arguments (same model, inliers, threshold, covariance, bit for bit).  jobs[i].status holds the
- * job's own status; the return value is the first failure, CLC_OK if none. */
+ * job's own status; the return value is the first failure, CLC_OK if none.
+ * Since round 5 the solves of a larger batch (eight or more here, four or more two-view filters below) SHARE their launches instead --
+ * round r of every unfinished solve is one launch on ctxs[0]'s stream, blockIdx.y = solve -- which changes the schedule, not a result;
+ * on return the streams of all the contexts are ordered behind whatever of those launches is still in flight (CLC_ACR_LOCKSTEP=0|1
+ * forces the form). */
 typedef struct clc_pose_job {
     /* in */
     const double* X;          /* n x 3 world points                                      */
@@ -496,8 +500,9 @@ int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2,
                            double* error_max, double* min_nfa, int* iterations);
 
 /* Several two-view filters at once (round 5): what RobustMatcher::filterMatches runs pair after pair (RobustMatcher.hpp:455-483 ->
- * filterEssential :153-171).  As clc_pnp_localize_ac_batch: one context per job (all on one device), ONE host thread drives all the chains
- * of launches so that they interleave on the device; every job's result is clc_essential_acransac's for the same arguments. */
+ * filterEssential :153-171).  As clc_pnp_localize_ac_batch: one context per job (all on one device), ONE host thread drives all the solves
+ * (chains of launches of their own that interleave on the device, or -- four or more jobs -- rounds in launches shared by the batch);
+ * every job's result is clc_essential_acransac's for the same arguments. */
 typedef struct clc_two_view_job {
     /* in */
     const double* x1;         /* n x 2 undistorted pixels, image 1                        */
