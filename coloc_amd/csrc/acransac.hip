@@ -18,8 +18,9 @@
 //             the phase-switch rule), stops at the first iteration that changes the index set -- the iterations after it were
 //             sampled speculatively from the old set and are discarded; one workgroup then applies the side effects (device
 //             state, best inlier list, index set, the word the host polls, the result record when the run ends).
-// The resection path runs solve + nfa + the select of the PREVIOUS round as ONE launch per round (acr_round_kernel below); the
-// five-point path keeps the three launches.  The host only polls one packed word per round in pinned memory to learn whether
+// The resection path runs solve + nfa + the select of the PREVIOUS round as ONE launch per round (acr_round_kernel below), the
+// five-point path as two (acr_solve5_kernel: select of the previous round + samples + solve; nfa); several solves of one kind can share
+// those launches (blockIdx.y = solve: the *_chains_kernel forms, driven in lockstep by capi.hip).  The host only polls one packed word per round in pinned memory to learn whether
 // another round is needed: one round to find the first meaningful model, then one per improvement in the reserve.  Results are identical to the
 // sequential oracle: same samples, bit-identical residuals (same operation order, no FMA contraction), a total order on
 // (residual, index), and the same portable log10 in the NFA terms.

@@ -2070,7 +2070,7 @@ struct AcrRun {
         if (!grouped) CLC_HIP(ctx, launch_acr_stage(stage_src, stage_dst, stage_n, st));  // (grouped: one launch for the batch, drive_group)
         if (!grouped) prof_mark(&ctx->prof, CLC_KERNEL_PNP_SCORE, true, st);
         // Rounds are enqueued ONE AHEAD of what the host knows: the solve / nfa / select kernels take the round's batch from the
-        // device state (a round enqueued after the run has finished is three empty launches), so the GPU goes from one round's
+        // device state (a round enqueued after the run has finished finds nothing to do), so the GPU goes from one round's
         // select straight into the next round's solve while the host is still polling (a 10 us bubble per round otherwise).
         launches = 0;
         // Upper bound of the batch a round can ask for, from what the host knows when it enqueues it (one or two rounds behind the
