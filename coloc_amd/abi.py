@@ -49,7 +49,7 @@ class PoseJob(C.Structure):
                 ("n_inliers", C.c_int), ("iterations", C.c_int), ("status", C.c_int), ("error_max", C.c_double), ("rmse", C.c_double)]
 
 
-ABI_VERSION = 2          # CLC_ABI_VERSION of include/coloc_hip.h
+ABI_VERSION = 3          # CLC_ABI_VERSION of include/coloc_hip.h
 DESC_CACHE_OFF, DESC_CACHE_VERIFY, DESC_CACHE_TRUST = 0, 1, 2
 
 class TwoViewJob(C.Structure):
@@ -151,7 +151,7 @@ def load_library():
     lib.clc_desc_cache_mode.argtypes = [vp, ci]
     lib.clc_essential_acransac_batch.argtypes = [vp, vp, ci]
     lib.clc_inter_pose_batch.argtypes = [vp, vp, ci]
-    lib.clc_describe_match_pair_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, ci, vp, ci, vp]
+    lib.clc_describe_match_pair_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, ci, vp, vp]
     lib.clc_pnp_localize_ac_batch.argtypes = [vp, vp, ci]
     lib.clc_keypoints_to_features.argtypes = [vp, ci, vp]
     lib.clc_match_2nn.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, vp]
@@ -548,14 +548,13 @@ class Context:
         out = (C.c_void_p * n)(*d_desc) if d_desc is not None else None
         self._chk(self.lib.clc_detect_batch_dev(self.h, n, imgs, width, height, pitch, kps, cnt, out, stream))
 
-    def describe_match_pair_dev(self, d_imgs, width, height, pitch, d_kps, counts, d_desc, threshold, d_match, chunks=0, stream=None):
-        """clc_describe_match_pair_dev: pyramid + CLATCH of the pair's two cameras and the sweep camera 0 -> camera 1, the sweep of a
-        finished chunk of camera 0 running beside the rest of the describe launch (chunks: 0 default list, 1 no overlap, K chunks)."""
+    def describe_match_pair_dev(self, d_imgs, width, height, pitch, d_kps, counts, d_desc, threshold, d_match, stream=None):
+        """clc_describe_match_pair_dev: pyramid + CLATCH of the pair's two cameras and the sweep camera 0 -> camera 1 as one enqueue."""
         imgs = (C.c_void_p * 2)(*d_imgs)
         kps = (C.c_void_p * 2)(*d_kps)
         cnt = (C.c_int * 2)(*[int(c) for c in counts])
         out = (C.c_void_p * 2)(*d_desc)
-        self._chk(self.lib.clc_describe_match_pair_dev(self.h, imgs, width, height, pitch, kps, cnt, out, int(threshold), d_match, int(chunks), stream))
+        self._chk(self.lib.clc_describe_match_pair_dev(self.h, imgs, width, height, pitch, kps, cnt, out, int(threshold), d_match, stream))
 
     def desc_cache_mode(self, mode):
         """clc_desc_cache_mode: "off" | "verify" (whole-block fold, default) | "trust" (address + count + 18 sampled rows)."""
@@ -589,7 +588,7 @@ class Context:
     # -- match
     def set_k2nn_formulation(self, name):
         """"matrix" (FP4 matrix pipe, default) or "popcount" (xor + popcount on the vector ALU): same results."""
-        self._chk(self.lib.clc_k2nn_set_formulation(self.h, {"matrix": 0, "popcount": 1, "matrix-plain": 2}[name]))
+        self._chk(self.lib.clc_k2nn_set_formulation(self.h, {"matrix": 0, "popcount": 1}[name]))
 
     @property
     def k2nn_queries_per_block(self):

@@ -753,49 +753,6 @@ __device__ __forceinline__ void acr_keep(const AcrProblem& pb, const AcrCore& c,
     }
 }
 
-// select as a launch of its own (the five-point path: fivept_kernel -> acr_nfa_kernel -> this): replay, side effects, and the
-// samples of the next batch for the solver launch that follows
-__global__ __launch_bounds__(256) void acr_select_kernel(const AcrProblem pb, const double* __restrict__ models,
-                                                         const AcrHyp* __restrict__ hyp, const uint32_t* __restrict__ sorted_idx,
-                                                         AcrState* __restrict__ state, uint32_t* __restrict__ best_inliers,
-                                                         uint32_t* __restrict__ index_set, int32_t* __restrict__ samples,
-                                                         unsigned long long* __restrict__ h_word, const AcrFinish fin)
-{
-    constexpr int T = 256;
-    __shared__ AcrCore s_core;
-    __shared__ AcrPick s_pick;
-    __shared__ AcrState s_full;
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        AcrCore c = acr_core_load(state);
-        const AcrPick pick = pb.max_models == 4 ? acr_select_wave<4>(pb, c, hyp, tid) : acr_select_wave<10>(pb, c, hyp, tid);
-        if (tid == 0) { s_core = c; s_pick = pick; }
-    }
-    __syncthreads();
-    const AcrCore s = s_core;
-    const AcrPick pick = s_pick;
-    {
-        const uint32_t* win = pick.best_h >= 0 ? sorted_idx + (size_t)pick.best_h * pb.n : nullptr;
-        const uint32_t* src = acr_sample_source(s, pick, win, best_inliers, index_set);
-        const int remaining = s.n_iter - s.iter;
-        const int nb = remaining < kAcrMaxBatch ? remaining : kAcrMaxBatch;
-        for (int it = tid; it < nb; it += T) {
-            if (pb.m == 3) {                                       // P3P
-                uint32_t pos[3];
-                clc_acr_sample_t<3>(pb.seed, (uint32_t)(s.iter + it), (uint32_t)s.n_index, pos);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) samples[it * 3 + j] = (int32_t)(src ? src[pos[j]] : pos[j]);
-            } else {                                               // five-point
-                uint32_t pos[5];
-                clc_acr_sample_t<5>(pb.seed, (uint32_t)(s.iter + it), (uint32_t)s.n_index, pos);
-#pragma unroll
-                for (int j = 0; j < 5; ++j) samples[it * 5 + j] = (int32_t)(src ? src[pos[j]] : pos[j]);
-            }
-        }
-    }
-    acr_keep(pb, s, pick, models, sorted_idx, state, state, best_inliers, index_set, h_word, fin, s_full, tid, T);
-}
-
 // ---- the resection round in ONE launch ------------------------------------------------------------------------------
 // A P3P round used to be three dependent launches (solve 5.8 us, nfa 15 us, select 7.7 us in the kernel trace) of which ~4.4 us
 // EACH is the launch boundary itself (an empty launch in the same chain measures 4.0-4.5 us): 13 of a round's 28 us.  Here a round
@@ -964,17 +921,6 @@ __global__ __launch_bounds__(64) void acr_solve5_chains_kernel(const AcrChains c
     acr_solve5_body(ch.states, ch.hyps, par, ch.pb, ch.sorted, ch.models, ch.best_inliers, ch.index_set, ch.h_word, ch.fin);
 }
 
-// ---- finish: mask, inlier list and the result record, straight into pinned host memory ---------------------------
-__global__ __launch_bounds__(256) void acr_finish_kernel(const AcrProblem pb, const AcrState* __restrict__ state,
-                                                         const uint32_t* __restrict__ best_inliers, uint8_t* __restrict__ d_mask,
-                                                         AcrResult* __restrict__ d_res, uint8_t* __restrict__ h_mask,
-                                                         int32_t* __restrict__ h_inliers, AcrResult* __restrict__ h_res)
-{
-    const AcrState s = *state;
-    const AcrFinish fin{ d_mask, d_res, h_mask, h_inliers, h_res };
-    acr_finish_block(pb, s, best_inliers, fin, (int)threadIdx.x, (int)blockDim.x);        // launched as ONE workgroup
-}
-
 // ---- host side ----------------------------------------------------------------------------------------------------
 template <int E>
 static hipError_t acr_launch_nfa(const AcrProblem& pb, int B, int P, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted,
@@ -992,32 +938,6 @@ static hipError_t acr_launch_nfa(const AcrProblem& pb, int B, int P, const doubl
     // one word per element for the exchanges that cross waves + (E <= 8) one for the exact residual bits
     const size_t lds = (T > 64 ? (size_t)P * 8 : 0) + (E <= 8 ? (size_t)P * 8 : 0);
     hipLaunchKernelGGL(acr_nfa_kernel<E>, dim3(B * pb.max_models), dim3(T), lds, stream, pb, P, d_models, d_hyp, d_sorted, d_state);
-    return hipGetLastError();
-}
-
-hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
-                            uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, unsigned long long* h_word,
-                            hipStream_t stream, int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers,
-                            AcrResult* h_res)
-{
-    // the grid covers `batch_bound` iterations (an upper bound of the batch the device state will ask for, <= kAcrMaxBatch); the
-    // kernels take the round's real batch from the device state.  A tight bound matters: a slot workgroup that has nothing to do
-    // still costs its dispatch (512 workgroups of 1024 threads for a 25-iteration reserve round was a third of the nfa launch).
-    const int B = batch_bound < 1 ? 1 : (batch_bound > kAcrMaxBatch ? kAcrMaxBatch : batch_bound);
-    int P = 64;
-    while (P < pb.n) P <<= 1;
-        hipError_t e;
-    // up to 1024 threads per slot: one element per thread wins while it fits (measured: p50 0.281 -> 0.253 ms at n = 1000
-    // against four per thread -- the residual / log10 arithmetic is latency-bound with one wave per SIMD)
-    if (P <= 1024) e = acr_launch_nfa<1>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
-    else if (P == 2048) e = acr_launch_nfa<2>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
-    else if (P == 4096) e = acr_launch_nfa<4>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
-    else if (P == 8192) e = acr_launch_nfa<8>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
-    else e = acr_launch_nfa<16>(pb, B, P, d_models, d_hyp, d_sorted, d_state, stream);
-    if (e != hipSuccess) return e;
-    const AcrFinish fin{ d_mask, d_res, h_mask, h_inliers, h_res };
-    hipLaunchKernelGGL(acr_select_kernel, dim3(1), dim3(256), 0, stream, pb, d_models, (const AcrHyp*)d_hyp, (const uint32_t*)d_sorted,
-                       d_state, d_best_inliers, d_index_set, d_samples, h_word, fin);
     return hipGetLastError();
 }
 
@@ -1185,13 +1105,6 @@ hipError_t launch_acr_stage_chains(const double* const* h_pinned, double* const*
     }
     if (most <= 0) return hipSuccess;
     hipLaunchKernelGGL(acr_stage_chains_kernel, dim3((most + 255) / 256, n_chains), dim3(256), 0, stream, jobs);
-    return hipGetLastError();
-}
-
-hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
-                             uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream)
-{
-    hipLaunchKernelGGL(acr_finish_kernel, dim3(1), dim3(256), 0, stream, pb, d_state, d_best_inliers, d_mask, d_res, h_mask, h_inliers, h_res);
     return hipGetLastError();
 }
 

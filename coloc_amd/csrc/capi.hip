@@ -124,15 +124,7 @@ struct clc_ctx {
     K2nnDevice k2dev{};          // XCDs and CUs of this context's device (the sweep planner's balance arguments)
     int bias_source = 0;         // 0: built-in default, 1: CLC_K2NN_BIAS, 2: timed probe on this device (k2nn_probe_bias)
     float bias_probe_us[4] = {}; // the probe's sweep times per candidate (0: not probed)
-    // pair step (clc_describe_match_pair_dev): the second stream the chunk sweeps run on, fork / join events, the describe launch's
-    // progress counters, the gates' error word (pinned host memory)
-    hipStream_t stream2 = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_group = nullptr;   // drive_group: the tail of a batch's shared launches, for the other contexts' streams to wait on
-    uint32_t* d_progress = nullptr;
-    uint32_t* h_gate_err = nullptr;
-    int pair_chunks[kClatchMaxChunks] = {};   // default chunk list in groups of 8 query blocks (CLC_PAIR_CHUNKS), 0-terminated
-    int pair_target_blocks = 0;               // sweep workgroups aimed at per chunk launch (CLC_PAIR_TARGET_BLOCKS; 0 = the context's)
     int cache_mode = CLC_DESC_CACHE_VERIFY;   // how this context's host-pointer match entry points treat published blocks (clc_desc_cache_mode)
     // pnp
     uint8_t* d_pairs = nullptr;   // clc_match_pairs arena: descriptors of all cameras, then results
@@ -389,22 +381,12 @@ int clc_ctx_create(int device_id, const clc_detector_opts* dopts, const clc_matc
     }
     if (const char* e = getenv("CLC_K2NN_XCD_MAP")) ctx->xcd_map = atoi(e) != 0;
     ctx->cache_mode = cache_mode_default();
-    if (const char* e = getenv("CLC_PAIR_CHUNKS")) {
-        int k = 0;
-        for (const char* q = e; *q && k < (int)kClatchMaxChunks - 1;) {
-            const int v = atoi(q);
-            if (v > 0) ctx->pair_chunks[k++] = v;
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
-        }
-    }
-    if (const char* e = getenv("CLC_PAIR_TARGET_BLOCKS")) ctx->pair_target_blocks = atoi(e) > 0 ? atoi(e) : 0;
     if (const char* e = getenv("CLC_K2NN_BIAS")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 0 && b >= 0 && a < 1024 && b < 1024) { ctx->bias_a = a; ctx->bias_b = b; ctx->bias_source = 1; }
     }
     if (const char* e = getenv("CLC_K2NN_FORMULATION"))
-        ctx->formulation = (e[0] == 'p' || e[0] == '1') ? K2NN_POPCOUNT : ((e[0] == '2' || strstr(e, "plain")) ? K2NN_MATRIX_PLAIN : K2NN_MATRIX);
+        ctx->formulation = (e[0] == 'p' || e[0] == '1') ? K2NN_POPCOUNT : K2NN_MATRIX;
     if (dopts) {
         ctx->has_det = true;
         ctx->dopts = *dopts;
@@ -457,12 +439,7 @@ int clc_ctx_destroy(clc_ctx* ctx)
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
-    if (ctx->stream2) { (void)hipStreamSynchronize(ctx->stream2); (void)hipStreamDestroy(ctx->stream2); }
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_group) (void)hipEventDestroy(ctx->ev_group);
-    if (ctx->d_progress) (void)hipFree(ctx->d_progress);
-    if (ctx->h_gate_err) (void)hipHostFree(ctx->h_gate_err);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CLC_OK;
@@ -473,12 +450,6 @@ int clc_sync(clc_ctx* ctx)
     if (!ctx) return CLC_ERR_BAD_ARG;
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->stream2) CLC_HIP(ctx, hipStreamSynchronize(ctx->stream2));
-    if (ctx->h_gate_err && *ctx->h_gate_err) {
-        *ctx->h_gate_err = 0;
-        ctx->partial_dirty = true;
-        return fail(ctx, CLC_ERR_HIP, "pair step: a gate gave up waiting for the describe launch (results of that step are invalid)");
-    }
     return CLC_OK;
 }
 
@@ -818,9 +789,9 @@ int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4)
 
 int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation)
 {
-    if (!ctx || (formulation != CLC_K2NN_MATRIX && formulation != CLC_K2NN_POPCOUNT && formulation != CLC_K2NN_MATRIX_PLAIN))
+    if (!ctx || (formulation != CLC_K2NN_MATRIX && formulation != CLC_K2NN_POPCOUNT))
         return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_set_formulation: bad argument");
-    ctx->formulation = formulation == CLC_K2NN_POPCOUNT ? K2NN_POPCOUNT : (formulation == CLC_K2NN_MATRIX_PLAIN ? K2NN_MATRIX_PLAIN : K2NN_MATRIX);
+    ctx->formulation = formulation == CLC_K2NN_POPCOUNT ? K2NN_POPCOUNT : K2NN_MATRIX;
     return CLC_OK;
 }
 
@@ -921,43 +892,18 @@ int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, in
     return run_jobs(ctx, jobs, pick(ctx, stream));
 }
 
-/* ---- describe both cameras of a pair and match them, as ONE step (round 5) -------------------------------------------------
+/* ---- describe both cameras of a pair and match them, as ONE step ------------------------------------------------------------
  * The reference's call pattern for a pair is detectAndDescribe of each camera (GPUDetector.hpp:216-291) and then
- * computeMatchesPair (GPUMatcher.hpp:165-172, :180-226): the sweep starts when both describes have ended.  CLATCH keeps the LDS
- * and the vector-memory path busy, the sweep the matrix pipe: here the sweep over a CHUNK of the query camera's rows starts as
- * soon as that chunk (and the whole train camera) has been described, while the same describe launch is still working on the
- * later chunks.  One describe launch (train camera dispatched first, its waves count themselves into per-chunk progress
- * counters after an agent-scope store of their descriptor), and on a second stream per chunk a one-wave gate (waits for the
- * chunk's counters, bounded) followed by the chunk's sweep launch; the caller's stream joins at the end.  Results are those of
- * the two calls it replaces: the fold over train splits is order-free and chunks own disjoint query blocks. */
-static int ensure_pair(clc_ctx* ctx)
-{
-    if (ctx->stream2) return CLC_OK;
-    // the chunk sweeps' queue takes precedence over the describe launch's: a sweep workgroup (19.5 KB of LDS, 4 x 152 VGPRs) fits a CU
-    // only in the moment one of its twelve CLATCH waves (12.7 KB each, 152 of the 160 KB) has retired -- at equal priority the next
-    // CLATCH wave takes that room every time and the sweeps start when the describe launch has drained (measured: no overlap at all)
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    const char* pe = getenv("CLC_PAIR_PRIORITY");
-    if (pe && pe[0] == '0') CLC_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    else CLC_HIP(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_hi));
-    CLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    CLC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    const size_t bytes = (size_t)(1 + kClatchMaxChunks * 4) * kClatchProgressWays * kClatchProgressStride * sizeof(uint32_t);
-    CLC_HIP(ctx, hipMalloc((void**)&ctx->d_progress, bytes));
-    CLC_HIP(ctx, hipMemsetAsync(ctx->d_progress, 0, bytes, ctx->stream));
-    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    CLC_HIP(ctx, hipHostMalloc((void**)&ctx->h_gate_err, sizeof(uint32_t), hipHostMallocDefault));
-    *ctx->h_gate_err = 0;
-    return CLC_OK;
-}
-
+ * computeMatchesPair (GPUMatcher.hpp:165-172, :180-226).  Here: one pyramid launch and one CLATCH launch for both cameras, one sweep
+ * launch, on the caller's stream.  (Round 5 also shipped a chunked form -- sweeps over finished chunks of the query camera on a
+ * second stream behind one-wave gates that polled the describe launch's progress counters; it measured slower at every chunking
+ * on MI355X and is gone: profiles/r05_step_overlap.txt, profiles/r06_removed_variants.patch.) */
 int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_t width, uint32_t height, size_t pitch,
                                 const clc_keypoint* const* d_kps, const int* counts, void* const* d_desc, int threshold,
-                                int32_t* d_match, int chunks, void* stream)
+                                int32_t* d_match, void* stream)
 {
     if (!ctx || !d_imgs || !d_kps || !counts || !d_desc || !d_imgs[0] || !d_imgs[1] || counts[0] < 0 || counts[1] < 0 ||
-        (counts[0] > 0 && (!d_kps[0] || !d_desc[0] || !d_match)) || (counts[1] > 0 && (!d_kps[1] || !d_desc[1])) || chunks < 0)
+        (counts[0] > 0 && (!d_kps[0] || !d_desc[0] || !d_match)) || (counts[1] > 0 && (!d_kps[1] || !d_desc[1])))
         return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: bad argument");
     if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "describe_match_pair: context created without detector options");
     if (width != ctx->dopts.width || height != ctx->dopts.height || pitch < width || pitch > 0xFFFFFFFFull)
@@ -967,11 +913,6 @@ int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_
     if ((uintptr_t)d_match & 3u) return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: misaligned device pointer");
     CLC_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    if (ctx->h_gate_err && *ctx->h_gate_err) {
-        *ctx->h_gate_err = 0;
-        ctx->partial_dirty = true;
-        return fail(ctx, CLC_ERR_HIP, "describe_match_pair: a gate of an earlier step gave up waiting for its describe launch");
-    }
     { const int rc = ensure_slots(ctx, 2, st); if (rc != CLC_OK) return rc; }
     // pyramid slot 0 = the TRAIN camera (camera 1 of the pair), slot 1 = the query camera: the describe launch dispatches slot 0 first
     const uint8_t* srcs[2] = { (const uint8_t*)d_imgs[1], (const uint8_t*)d_imgs[0] };
@@ -981,88 +922,13 @@ int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_
     ctx->pyramid_valid = false;
     CLC_HIP(ctx, launch_pyramid_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, srcs, 2, (uint32_t)pitch, st, &ctx->prof));
     ctx->pyramid_valid = true;
-    const uint32_t nq = (uint32_t)counts[0], nt = (uint32_t)counts[1];
-    const uint32_t group_rows = (uint32_t)k2nn_queries_per_block(ctx->formulation) * 8u;       // eight query blocks: one per XCD
-    const uint32_t ngroups = (nq + group_rows - 1u) / group_rows;
-    // the chunk list in groups: the caller's count (equal parts), or the context's default
-    uint32_t csz[kClatchMaxChunks] = {};
-    uint32_t nchunks = 0;
-    if (chunks == 0 && ctx->pair_chunks[0] == 0) {
-        // default: NO chunking.  Measured on MI355X (profiles/r05_step_overlap.txt): twelve CLATCH waves hold 152 of a CU's 160 KB of LDS,
-        // a sweep workgroup needs 19.5 KB, so the chunk sweeps only get onto the CUs when the describe launch drains -- 2 / 3 / 5 chunks
-        // took 124 / 138 / 175 us per step against 95 without (stream priority changes nothing).  The chunked path stays for A/B runs.
-        nchunks = 0;
-    } else if (chunks == 0) {
-        for (uint32_t k = 0; k < kClatchMaxChunks && ctx->pair_chunks[k] > 0; ++k) csz[nchunks++] = (uint32_t)ctx->pair_chunks[k];
-    } else {
-        const uint32_t K = std::min<uint32_t>((uint32_t)chunks, kClatchMaxChunks);
-        for (uint32_t k = 0; k < K; ++k) csz[nchunks++] = (ngroups * (k + 1u)) / K - (ngroups * k) / K;
-    }
-    // clip to the groups there are; what the list leaves over goes to the last chunk
-    uint32_t used = 0, kept = 0;
-    for (uint32_t k = 0; k < nchunks && used < ngroups; ++k) {
-        if (csz[k] == 0u) continue;
-        csz[kept] = std::min(csz[k], ngroups - used);
-        used += csz[kept++];
-    }
-    nchunks = kept;
-    if (nchunks && used < ngroups) csz[nchunks - 1u] += ngroups - used;
-    const bool overlap = nchunks >= 2u && nt > 0u && nt <= (1u << 22) && ngroups <= kClatchMaxChunks * 4u;
-    if (!overlap) {
-        // one stream, one describe launch, one sweep launch: the two calls this entry replaces
-        CLC_HIP(ctx, launch_clatch_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, 2, st, &ctx->prof));
-        if (nq == 0u) return CLC_OK;
-        std::vector<K2nnJobDev> jobs(1);
-        jobs[0] = K2nnJobDev{};
-        jobs[0].q = (const uint4*)d_desc[0]; jobs[0].t = (const uint4*)d_desc[1]; jobs[0].out = d_match;
-        jobs[0].nq = nq; jobs[0].nt = nt; jobs[0].thr = (uint32_t)(uint8_t)threshold;
-        return run_jobs(ctx, jobs, st);
-    }
-    // (second stream, events, progress counters, error word: allocated by the first CHUNKED step of a context -- that call synchronises
-    // and cannot be captured; the default form above needs none of it)
-    { const int rc = ensure_pair(ctx); if (rc != CLC_OK) return rc; }
-    // every chunk's sweep planned on its own (its launch has the slots the describe launch leaves to itself), rows and counters of
-    // the chunks one behind the other in the context's workspace
-    const int target = ctx->pair_target_blocks > 0 ? ctx->pair_target_blocks
-                                                   : (ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev));
-    std::vector<K2nnJobDev> jobs(nchunks);
-    size_t base = 0;
-    uint32_t g0 = 0;
-    for (uint32_t k = 0; k < nchunks; ++k) {
-        const uint32_t r0 = g0 * group_rows, r1 = std::min(nq, (g0 + csz[k]) * group_rows);
-        K2nnJobDev& jb = jobs[k];
-        jb = K2nnJobDev{};
-        jb.q = (const uint4*)((const uint8_t*)d_desc[0] + (size_t)r0 * CLC_DESC_BYTES);
-        jb.t = (const uint4*)d_desc[1];
-        jb.out = d_match + r0;
-        jb.nq = r1 - r0; jb.nt = nt; jb.thr = (uint32_t)(uint8_t)threshold;
-        const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, 0, 0, ctx->k2dev);
-        if (!plan.atomic_merge) return fail(ctx, CLC_ERR_STATE, "describe_match_pair: chunk plan without the atomic fold");
-        jb.partial_off += (uint32_t)base;
-        jb.cnt_off += (uint32_t)(2u * base);
-        base += plan.partial_elems;
-        g0 += csz[k];
-    }
-    { const int rc = ensure_partial(ctx, base); if (rc != CLC_OK) return rc; }
-    if (ctx->partial_dirty) {
-        CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
-        ctx->partial_dirty = false;
-    }
-    CLC_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
-    CLC_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    CLC_HIP(ctx, launch_clatch_progress(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, ctx->d_progress, group_rows, st, &ctx->prof));
-    g0 = 0;
-    for (uint32_t k = 0; k < nchunks; ++k) {
-        // chunk 0 also waits for the train camera (group 0); query groups are numbered from 1
-        const uint32_t first = k == 0u ? 0u : 1u + g0, groups = k == 0u ? 1u + csz[k] : csz[k];
-        CLC_HIP(ctx, launch_clatch_gate(ctx->d_progress, first, groups, nt, nq, group_rows, ctx->h_gate_err, ctx->stream2));
-        const hipError_t e = launch_k2nn(&jobs[k], 1, ctx->d_partial, ctx->stream2, &ctx->prof, ctx->formulation);
-        if (e != hipSuccess) { ctx->partial_dirty = true; return fail(ctx, CLC_ERR_HIP, "describe_match_pair: launch_k2nn", e); }
-        g0 += csz[k];
-    }
-    CLC_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-    CLC_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
-    return CLC_OK;
+    CLC_HIP(ctx, launch_clatch_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, 2, st, &ctx->prof));
+    if (counts[0] == 0) return CLC_OK;
+    std::vector<K2nnJobDev> jobs(1);
+    jobs[0] = K2nnJobDev{};
+    jobs[0].q = (const uint4*)d_desc[0]; jobs[0].t = (const uint4*)d_desc[1]; jobs[0].out = d_match;
+    jobs[0].nq = (uint32_t)counts[0]; jobs[0].nt = (uint32_t)counts[1]; jobs[0].thr = (uint32_t)(uint8_t)threshold;
+    return run_jobs(ctx, jobs, st);
 }
 
 int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs, int njobs,
@@ -1890,7 +1756,6 @@ struct AcrRun {
     AcrProblem pb{};
     hipStream_t st = nullptr;
     int launches = 0, bound = 0, reserve0 = 0;
-    bool five_point_three_launches = false;
     uint32_t round = 0, spins = 0;
     std::chrono::steady_clock::time_point wait_start;
     // lockstep batches (drive_group): the solve's rounds ride in launches shared with the other solves of the batch, on group_stream; the
@@ -1906,7 +1771,7 @@ struct AcrRun {
     double* p_ref = nullptr;
     int32_t* ready = nullptr;
     double *d_a = nullptr, *d_b = nullptr, *d_K1 = nullptr, *d_K2 = nullptr, *d_models = nullptr, *d_ref = nullptr;
-    AcrState* d_state = nullptr; int32_t* d_samples = nullptr; AcrHyp* d_hyp = nullptr;
+    AcrState* d_state = nullptr; AcrHyp* d_hyp = nullptr;
     uint32_t *d_sorted = nullptr, *d_best = nullptr, *d_index = nullptr;
     AcrResult* d_res = nullptr; uint8_t* d_mask = nullptr;
 
@@ -1917,18 +1782,12 @@ struct AcrRun {
 
     int enqueue_round(const int bnd)
     {
-        const int32_t* d_cnt = &d_state->cur_batch;
         const int S = bnd < 1 ? 1 : (bnd > kAcrMaxBatch ? kAcrMaxBatch : bnd);
         if (kind == 0) {
             // one launch: replay of the previous round, this round's samples, P3P, residuals / sort / NFA; the word of round r comes
             // out of launch r + 1
             CLC_HIP(ctx, launch_acr_round_p3p(pb, launches & 1, d_state, d_hyp, d_sorted, d_models, d_best, d_index, h_word, st, S, d_mask,
                                               d_res, nullptr, p_inl, h_res));
-        } else if (five_point_three_launches) {
-            // rounds 2-4's form (CLC_ACR_5PT_LAUNCHES=3, A/B runs): solve, nfa, select as three launches on ONE copy of the state
-            CLC_HIP(ctx, launch_fivept(d_a, d_b, N, d_K1, d_K2, d_samples, S, d_models, st, d_cnt));
-            CLC_HIP(ctx, launch_acr_round(pb, d_models, d_hyp, d_sorted, d_state, d_best, d_index, d_samples, h_word, st, S, d_mask, d_res,
-                                          nullptr, p_inl, h_res));
         } else {
             // two launches: replay of the previous round + this round's samples + five-point solve, then nfa; the word of round r
             // comes out of round r + 1's first launch
@@ -1966,18 +1825,15 @@ struct AcrRun {
     {
         CLC_HIP(ctx, hipSetDevice(ctx->device));
         refine = kind == 0 && refine_huber > 0.0;
-        // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k | initial state | first batch's samples ] uploaded
-        // in one copy, then scratch
-        const size_t samples_d = dbl(sizeof(int32_t) * kAcrMaxBatch * 5);
+        // device workspace (doubles): [ a | b | K1 16 | K2 16 | logc_n | logc_k | initial state ] staged by
+        // one launch, then scratch
         const size_t state_d = 2 * dbl(sizeof(AcrState));                      // [ copy 0 | copy 1 = the state a run starts from ]
-        const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d + samples_d;
-        // the resection round is ONE launch per round that reads what the launch before it wrote: two copies of state, models, slots
-        // and sorted lists, indexed by launch parity (acransac.hip: acr_round_kernel)
-        { const char* e = getenv("CLC_ACR_5PT_LAUNCHES"); five_point_three_launches = kind == 1 && e && e[0] == '3'; }
+        const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d;
+        // a round's launches read what the round before them wrote: two copies of state, models, slots and sorted lists, indexed by
+        // launch parity (acransac.hip: acr_round_kernel, acr_solve5_kernel)
         if (grouped) batch_cap = kind == 0 ? 8 : 12;                   // (a shared launch carries every chain's speculative slots: shorter rounds)
         if (const char* e = getenv("CLC_ACR_BATCH_CAP")) { const int v = atoi(e); if (v >= 1 && v <= kAcrMaxBatch) batch_cap = v; }
-        const bool two_copies = kind == 0 || !five_point_three_launches;
-        const int copies = two_copies ? 2 : 1;
+        const int copies = 2;
         const size_t models_d = (size_t)copies * kAcrMaxBatch * M * md;
         const size_t hyp_d = dbl(acr_hyp_bytes() * copies * kAcrMaxBatch * M);
         const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)copies * kAcrMaxBatch * M * N);
@@ -1998,7 +1854,6 @@ struct AcrRun {
         float* d_cn = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
         float* d_ck = (float*)d;               d += dbl(sizeof(float) * ((size_t)N + 1));
         d_state = (AcrState*)d;                d += state_d;
-        d_samples = (int32_t*)d;               d += samples_d;
         d_models = d;                          d += models_d;
         d_hyp = (AcrHyp*)d;                    d += hyp_d;
         d_sorted = (uint32_t*)d;               d += sorted_d;
@@ -2017,12 +1872,11 @@ struct AcrRun {
         float* h_cn = (float*)(hK + 32);
         float* h_ck = (float*)(hK + 32 + dbl(sizeof(float) * ((size_t)N + 1)));
         acr_tables(N, m, h_cn, h_ck, ctx->acr_lg);
-        // the state ACRANSAC starts from and the first batch's samples (drawn from all data) are part of the upload
+        // the state ACRANSAC starts from is part of the upload (every round draws its own samples on the device)
         AcrState* h_states = (AcrState*)(hK + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)));
-        int32_t* h_samples = (int32_t*)((double*)h_states + state_d);
         memset(h_states, 0, 2 * sizeof(AcrState));
-        // resection: launch 0 (parity 0) reads copy 1; the five-point path keeps its single state in copy 0
-        AcrState* h_init = h_states + (two_copies ? 1 : 0);
+        // launch 0 (parity 0) reads copy 1
+        AcrState* h_init = h_states + 1;
         h_init->min_nfa = INFINITY; h_init->error_max = INFINITY;
         h_init->best_iter = -1;
         h_init->reserve = max_iteration / 10;
@@ -2031,14 +1885,6 @@ struct AcrRun {
         h_init->ac_mode = std::isinf(precision) ? 1 : 0;
         h_init->grow = batch_cap < 32 ? batch_cap : 32;
         h_init->cur_batch = h_init->n_iter < h_init->grow ? h_init->n_iter : h_init->grow;
-        if (kind == 1 && five_point_three_launches) {      // (the other rounds draw their own samples on the device)
-            const int nb = h_init->n_iter < kAcrMaxBatch ? h_init->n_iter : kAcrMaxBatch;
-            for (int it = 0; it < nb; ++it) {
-                uint32_t pos[8];
-                clc_acr_sample(seed, (uint32_t)it, (uint32_t)N, m, pos);
-                for (int j = 0; j < m; ++j) h_samples[it * m + j] = (int32_t)pos[j];
-            }
-        }
         h_word = (unsigned long long*)(hp + in_d + state_d);
         h_res = (AcrResult*)(hp + in_d + state_d + 1);
         p_inl = (int32_t*)(hp + in_d + state_d + 1 + res_d + mask_d);
@@ -2078,7 +1924,7 @@ struct AcrRun {
         // reserve, remaining = n_iter - iter (+ a margin for the "no inliers: n_iter++" rule, once per round).
         reserve0 = h_init->reserve;
         bound = h_init->n_iter < batch_cap ? h_init->n_iter : batch_cap;
-        first_bound = two_copies ? h_init->cur_batch : bound;          // (a replaying launch takes its first batch as it stands)
+        first_bound = h_init->cur_batch;                               // (a replaying launch takes its first batch as it stands)
         if (!grouped) {
             int rc2 = enqueue_round(first_bound);
             if (rc2 != CLC_OK) return drained(rc2);
@@ -2245,11 +2091,6 @@ bool acr_lockstep(const int kind, const int n_jobs)
     if (n_jobs < 2 || mode == 0) return false;
     if (mode == 1) return true;
     return kind == 1 ? n_jobs >= 4 : n_jobs >= 8;
-}
-bool acr_three_launch_rounds()
-{
-    const char* e = getenv("CLC_ACR_5PT_LAUNCHES");
-    return e && e[0] == '3';
 }
 void drive_group(std::vector<AcrRun>& runs)
 {
@@ -2615,7 +2456,7 @@ int clc_essential_acransac_batch(clc_ctx* const* ctxs, clc_two_view_job* jobs, i
     if (rc0 != CLC_OK) return rc0;
     std::vector<AcrRun> runs((size_t)n_jobs);
     std::vector<double> EF((size_t)18 * n_jobs, 0.0);
-    const bool lockstep = acr_lockstep(1, n_jobs) && !acr_three_launch_rounds();
+    const bool lockstep = acr_lockstep(1, n_jobs);
     for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i], &EF[(size_t)18 * i], lockstep, ctxs[0]->stream);
     if (lockstep) drive_group(runs); else drive_runs(runs);
     int worst = CLC_OK;
@@ -2646,7 +2487,7 @@ int clc_inter_pose_batch(clc_ctx* const* ctxs, clc_inter_pose_job* jobs, int n_j
     // 1. the a-contrario five-point filters of all pairs, their chains of launches interleaved
     std::vector<AcrRun> runs((size_t)n_jobs);
     std::vector<double> EF((size_t)18 * n_jobs, 0.0);
-    const bool lockstep = acr_lockstep(1, n_jobs) && !acr_three_launch_rounds();
+    const bool lockstep = acr_lockstep(1, n_jobs);
     for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], jobs[i].tv, &EF[(size_t)18 * i], lockstep, ctxs[0]->stream);
     if (lockstep) drive_group(runs); else drive_runs(runs);
     int worst = CLC_OK;

@@ -33,13 +33,6 @@
 #include "clc_sincos.h"
 #include "latch_layout.inc"
 #include "latch_layout_swap.inc"
-#include "latch_layout8.inc"
-#include <cstdlib>
-#include <type_traits>
-
-#ifndef CLC_CLATCH_DEFAULT_COPIES
-#define CLC_CLATCH_DEFAULT_COPIES 4
-#endif
 
 namespace clc {
 
@@ -109,12 +102,6 @@ struct ClatchArgs {
     uint32_t slot_stride;                 // bytes between the pyramids of consecutive cameras (blockIdx.y = camera)
     const uint32_t* n_dev[kMaxBatch];     // after the GPU detector: a camera's keypoint count in device memory (nullable per camera)
     ClatchBatch cam;
-    // PROGRESS instantiation only (the pair step, capi.hip): a wave that has stored its descriptor counts itself in on
-    // progress[group * kClatchProgressWays + (keypoint & (kClatchProgressWays - 1))], group = 0 for camera 0 (the train side, dispatched
-    // first) and 1 + keypoint / chunk_rows for camera 1 -- so that a sweep over a finished chunk of camera 1 can start while the rest
-    // of this launch is still running
-    uint32_t* progress;
-    uint32_t chunk_rows;
 };
 
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c)
@@ -128,7 +115,6 @@ __device__ __forceinline__ int clamp_i32(int v, int hi)   // min(max(v, 0), hi) 
     return r;
 }
 
-template <bool PROGRESS>
 __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
 {
     // One keypoint per wave, no loop (the grid is the keypoint count).  Round 3 (tools/clatch_lab.hip, in-kernel stamps): a wave
@@ -269,277 +255,11 @@ __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const
         asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
             : "+v"(word) : "s"((uint32_t)bits), "s"((uint32_t)(bits >> 32)), "n"(2 * j), "n"(2 * j + 1));
     }
-    if (!PROGRESS) {
-        if (lane < 16u) reinterpret_cast<uint32_t*>(desc)[(size_t)kp * 16u + lane] = word;
-        return;
-    }
-    // The descriptor leaves with AGENT scope (written through this XCD's L2: a sweep workgroup on another XCD, in a launch that starts
-    // while this one is still running, must find it in memory -- coarse-grained memory is otherwise only coherent at launch boundaries),
-    // the wave waits until the store has been performed, then one lane counts the keypoint in.  No fence: a release fence writes the
-    // whole L2 back, once per wave (k2nn.hip measured +50 % for the same pattern).
-    if (lane < 16u) __hip_atomic_store(reinterpret_cast<uint32_t*>(desc) + (size_t)kp * 16u + lane, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0u) {
-        const uint32_t group = cam == 0u ? 0u : 1u + (uint32_t)kp / args.chunk_rows;
-        __hip_atomic_fetch_add(args.progress + (group * kClatchProgressWays + ((uint32_t)kp & (kClatchProgressWays - 1u))) * kClatchProgressStride, 1u,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// The gate of the pair step: ONE wave that waits -- polling with agent scope, asleep in between -- until the counters of `groups` progress
-// groups (first, first + 1, ...) add up to their targets, re-arms them (they are complete: nobody adds to them any more) and ends; the
-// sweep launch enqueued behind it on the same stream then starts.  Bounded: after ~0.5 s it raises *gate_error and ends anyway, so
-// that a describe launch that never ran (or a wrong target) cannot leave a wave spinning -- the step's results are then wrong and the
-// error word says so (clc_sync / the next pair step report it).
-__global__ __launch_bounds__(64) void clatch_gate_kernel(uint32_t* progress, const uint32_t first, const uint32_t groups, const uint32_t n_train,
-                                                          const uint32_t n_query, const uint32_t chunk_rows, uint32_t* gate_error)
-{
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t g = 0; g < groups; ++g) {
-        uint32_t* p = progress + (size_t)(first + g) * kClatchProgressWays * kClatchProgressStride;
-        // group 0: every keypoint of the train camera; group k >= 1: rows [(k - 1) chunk_rows, k chunk_rows) of the query camera
-        const uint32_t row0 = first + g ? (first + g - 1u) * chunk_rows : 0u;
-        const uint32_t target = first + g == 0u ? n_train : (row0 >= n_query ? 0u : min(chunk_rows, n_query - row0));
-        bool done = false;
-        for (uint32_t spin = 0; spin < 400000u && !done; ++spin) {
-            uint32_t v = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < kClatchProgressWays; w += 64u)
-                v += __hip_atomic_load(p + (w + lane) * kClatchProgressStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            done = v >= target;
-            if (!done) __builtin_amdgcn_s_sleep(32);
-        }
-        if (!done && lane == 0u) __hip_atomic_store(gate_error, 1u + first + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#pragma unroll
-        for (uint32_t w = 0; w < kClatchProgressWays; w += 64u)
-            __hip_atomic_store(p + (w + lane) * kClatchProgressStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// ---- round 5: two waves per keypoint, EIGHT byte-shifted copies -----------------------------------------------------------------
-// clatch_kernel above reads every 8-pixel patch row as a dword-aligned ds_read2_b32 (128 B/clk per CU) out of four shifted copies, and
-// its LDS pipe (1 570 cycles per keypoint and CU, a quarter of them bank conflicts) is the longer of its two saturated pipes (the window
-// gather: 1 100).  With eight copies every patch row is an 8-byte ALIGNED ds_read_b64 -- 256 B/clk, 64 banks --, but eight copies are
-// 26 KB: one wave per keypoint would halve the waves per CU (r03 measured 91 us that way).  Here TWO waves share one keypoint's window:
-// 26.6 KB per workgroup, six workgroups = the same twelve waves per CU; each wave gathers half the tiles, makes half the shifted copies
-// and evaluates 256 of the 512 tests; the result bits change waves through 512 bytes of LDS.  Same bits as clatch_kernel (same fp32
-// sample coordinates in source order, same integer tests); which kernel runs is CLC_CLATCH_COPIES=4|8.
-static constexpr int kCopy8[8] = LATCH8_COPY_BASES;
-static constexpr int kWin8Bytes = LATCH8_WINDOW_BYTES;
-static constexpr int kWinBytes = LATCH_NROWS * LATCH_STRIDE;       // 3136: one copy's payload
-static constexpr int kWinQwords = kWinBytes / 8;
-static constexpr uint16_t k_slot_triplet8[512] = LATCH8_SLOT_TRIPLET;
-static_assert(kWinBytes % 8 == 0 && kWin8Bytes <= 0x8000, "LDS addresses of the eight-copy window must leave bit 15 for the role-exchange flag");
-
-static constexpr bool copies8_fit()
-{
-    for (int k = 0; k < 8; ++k) {
-        if (kCopy8[k] % 8 != 0) return false;
-        // copy 0 is read 8 bytes past its payload by the copy phase (garbage that only lands beyond what any patch row reads)
-        const int end = kCopy8[k] + kWinBytes + 8;
-        if (end > (k < 7 ? kCopy8[k + 1] : kWin8Bytes)) return false;
-    }
-    return true;
-}
-static_assert(copies8_fit(), "the eight shifted copies must be 8-byte aligned and must not overlap");
-
-static constexpr uint16_t patch_lds_addr8(int row, int col)
-{
-    const int p = (row - kRow0) * kStride + (col - kCol0);
-    return (uint16_t)(kCopy8[p & 7] + (p & ~7));
-}
-static constexpr SlotTable make_slot_table8()
-{
-    // slot = wave * 256 + round * 64 + lane.  rec[slot] = {a, b, c, src}: a / b / c as in make_slot_table; src -- for OUTPUT bit
-    // n = slot (thread (wave, lane), output round j writes descriptor bit 256 wave + 64 j + lane) -- says where that bit was computed:
-    // bits 0..8 = byte offset of the computing thread's word in s_bits, bits 12..13 = its round
-    SlotTable t{};
-    for (int slot = 0; slot < 512; ++slot) {
-        const int n = k_slot_triplet8[slot] & 511;
-        const bool sw = (k_slot_triplet8[slot] >> 10) & 1;
-        const uint16_t a = patch_lds_addr8(k_pattern[n].v[0], k_pattern[n].v[1]), c = patch_lds_addr8(k_pattern[n].v[4], k_pattern[n].v[5]);
-        t.rec[slot][0] = (uint16_t)((sw ? c : a) | (sw ? 0x8000u : 0u));
-        t.rec[slot][1] = patch_lds_addr8(k_pattern[n].v[2], k_pattern[n].v[3]);
-        t.rec[slot][2] = sw ? a : c;
-        const int wave = slot >> 8, round = (slot >> 6) & 3, lane = slot & 63;
-        t.rec[n][3] = (uint16_t)(((wave * 64 + lane) << 2) | (round << 12));
-    }
-    return t;
-}
-__device__ __attribute__((aligned(16))) const SlotTable k_slots8 = make_slot_table8();
-
-typedef uint32_t u32x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
-typedef const volatile u32x2_a8 __attribute__((address_space(3)))* lds_cv8_ptr;
-
-template <bool PROGRESS>
-__global__ __launch_bounds__(128) void clatch8_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
-{
-    const uint32_t cam = blockIdx.y;
-    const int n_arg = args.cam.n[cam];
-    const uint32_t* __restrict__ n_dev = args.n_dev[cam];
-    const int n = n_dev ? min((int)*n_dev, n_arg) : n_arg;
-    const int kp = (int)blockIdx.x;
-    if (kp >= n) return;
-    __shared__ __attribute__((aligned(16))) uint8_t roi[kWin8Bytes];
-    __shared__ uint32_t s_bits[128];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-
-    // this thread's 4 slot records {a, b, c, src}: in flight during the whole fill
-    uint2 rec[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rec[j] = *reinterpret_cast<const uint2*>(k_slots8.rec[wave * 256u + (uint32_t)j * 64u + lane]);
-
-    const uint32_t* __restrict__ kw = reinterpret_cast<const uint32_t*>(args.cam.kps[cam]) + (size_t)kp * 5u;
-    const int px = (int)__builtin_amdgcn_readfirstlane(kw[0]);
-    const int py = (int)__builtin_amdgcn_readfirstlane(kw[1]);
-    const float angle = __uint_as_float(__builtin_amdgcn_readfirstlane(kw[3]));
-    const int scale = (int)(__builtin_amdgcn_readfirstlane(kw[4]) & 0xFFu);
-    uint64_t* __restrict__ desc = args.cam.desc[cam];
-    const uint8_t* __restrict__ arena = arena_base + (size_t)cam * args.slot_stride;
-    const int lv = min(scale, args.pd.levels - 1);
-    const LevelDesc L = args.pd.lv[lv];
-    const uint8_t* __restrict__ img = arena + L.offset;
-    float s, c;
-    clc_sincosf(angle, &s, &c);
-    const float fpx = (float)px, fpy = (float)py;
-    const int wmax = (int)L.w - 1, hmax = (int)L.h - 1;
-    const int dx = (int)(lane & 7u), dy = (int)(lane >> 3);
-
-    // ---- window fill into copy 0: the 49 tiles of 8 x 8 pixels are dealt to the two waves like the squares of a chess board
-    f32x2 XT[kTiles], YT[kTiles];
-#pragma unroll
-    for (int b = 0; b < kTiles; ++b) {
-        const float xo = (float)(kTile0 + b * 8 + dx - 32);
-        const float yo = (float)(kTile0 + b * 8 + dy - 32);
-        XT[b] = f32x2{ xo * c, xo * s };
-        YT[b] = f32x2{ -(yo * s), yo * c };
-    }
-    const f32x2 fp = { fpx, fpy }, half2 = { 0.5f, 0.5f };
-    uint8_t* const win = roi + kCopy8[0];
-    auto fill = [&](auto parity) {
-        constexpr int P = decltype(parity)::value;
-#pragma unroll
-        for (int by = 0; by < kTiles; ++by) {
-#pragma unroll
-            for (int bx = 0; bx < kTiles; ++bx) {
-                if (((by + bx) & 1) != P) continue;
-                const f32x2 f = (fp + (XT[bx] + YT[by])) + half2;     // CLATCH.cu:166
-                const float fx = f.x, fy = f.y;
-                const int sx = clamp_i32((int)fx, wmax);
-                const int sy = clamp_i32((int)fy, hmax);
-                const uint32_t off = __umul24((uint32_t)sy, L.pitch) + (uint32_t)sx;
-                win[(kTile0 - kRow0 + by * 8 + dy) * kStride + (kTile0 - kCol0 + bx * 8 + dx)] = img[off];
-            }
-        }
-    };
-    if (wave == 0u) fill(std::integral_constant<int, 0>{});
-    else fill(std::integral_constant<int, 1>{});
-    __syncthreads();
-
-    // ---- shifted copies 1..7: copy_k[i] = win[i + k], eight bytes at a time (all reads first, then the stores)
-    {
-        constexpr int kIters = (kWinQwords + 127) / 128;
-        u32x2_a8 q0[kIters], q1[kIters];
-#pragma unroll
-        for (int k = 0; k < kIters; ++k) {
-            const int i = (int)tid + 128 * k;
-            if (k < kIters - 1 || i < kWinQwords) {
-                q0[k] = *reinterpret_cast<const u32x2_a8*>(win + 8 * i);
-                q1[k] = *reinterpret_cast<const u32x2_a8*>(win + 8 * i + 8);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kIters; ++k) {
-            const int i = (int)tid + 128 * k;
-            if (k < kIters - 1 || i < kWinQwords) {
-                const uint32_t w0 = q0[k].x, w1 = q0[k].y, w2 = q1[k].x, w3 = q1[k].y;
-#pragma unroll
-                for (int sh = 1; sh < 8; ++sh) {
-                    u32x2_a8 o;
-                    if (sh < 4) { o.x = __builtin_amdgcn_alignbyte(w1, w0, sh); o.y = __builtin_amdgcn_alignbyte(w2, w1, sh); }
-                    else if (sh == 4) { o.x = w1; o.y = w2; }
-                    else { o.x = __builtin_amdgcn_alignbyte(w2, w1, sh - 4); o.y = __builtin_amdgcn_alignbyte(w3, w2, sh - 4); }
-                    *reinterpret_cast<u32x2_a8*>(roi + kCopy8[sh] + 8 * i) = o;
-                }
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- 256 tests per wave, 4 per lane: every patch row one aligned ds_read_b64
-    // The reads are volatile (through an LDS-typed pointer: address-space inference leaves volatile accesses of a generic pointer as flat
-    // loads): the compiler otherwise pairs the reads of two rows into one ds_read2_b64, which the LDS serves at HALF the rate of two
-    // ds_read_b64 (MI355X guide, LDS table: 8 cycles per wave-instruction against 2 + 2).  Volatile reads keep their program order, so the
-    // pipelining is spelled out: the 24 reads of the NEXT round are issued before the 64 dot products of the current one.
-    uint32_t bits4 = 0;
-    u32x2_a8 A[2][8], B[2][8], C[2][8];
-    auto load_round = [&](const int j, const int buf) {
-        const uint32_t pa = rec[j].x & 0x7FFFu, pb = rec[j].x >> 16, pc = rec[j].y & 0xFFFFu;
-#pragma unroll
-        for (int row = 0; row < 8; ++row) {
-            A[buf][row] = *(lds_cv8_ptr)(roi + pa + row * kStride);
-            B[buf][row] = *(lds_cv8_ptr)(roi + pb + row * kStride);
-            C[buf][row] = *(lds_cv8_ptr)(roi + pc + row * kStride);
-        }
-    };
-    load_round(0, 0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (j < 3) load_round(j + 1, (j + 1) & 1);
-        const int buf = j & 1;
-        uint32_t aa = 0, cc = 0, ab = 0, cb = 0;
-#pragma unroll
-        for (int row = 0; row < 8; ++row) {
-            aa = udot4(A[buf][row].x, A[buf][row].x, aa); aa = udot4(A[buf][row].y, A[buf][row].y, aa);
-            cc = udot4(C[buf][row].x, C[buf][row].x, cc); cc = udot4(C[buf][row].y, C[buf][row].y, cc);
-            ab = udot4(A[buf][row].x, B[buf][row].x, ab); ab = udot4(A[buf][row].y, B[buf][row].y, ab);
-            cb = udot4(C[buf][row].x, B[buf][row].x, cb); cb = udot4(C[buf][row].y, B[buf][row].y, cb);
-        }
-        const int32_t S = ((int32_t)aa - (int32_t)cc) - 2 * ((int32_t)ab - (int32_t)cb);
-        const int32_t Se = (rec[j].x & 0x8000u) ? -S : S;
-        bits4 |= (Se < 0 ? 1u : 0u) << j;
-    }
-    s_bits[tid] = bits4;
-    __syncthreads();
-    // ---- descriptor order: thread (wave, lane), output round j <- the bit of triplet 256 wave + 64 j + lane, wherever it was computed
-    uint32_t got[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) got[j] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(s_bits) + ((rec[j].y >> 16) & 0x1FFu));
-    uint32_t word = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint64_t bits = __ballot((got[j] >> (rec[j].y >> 28)) & 1u);
-        asm("s_nop 1\n\tv_writelane_b32 %0, %1, %3\n\tv_writelane_b32 %0, %2, %4"
-            : "+v"(word) : "s"((uint32_t)bits), "s"((uint32_t)(bits >> 32)), "n"(2 * j), "n"(2 * j + 1));
-    }
-    uint32_t* const out = reinterpret_cast<uint32_t*>(desc) + (size_t)kp * 16u + 8u * wave + lane;
-    if (!PROGRESS) {
-        if (lane < 8u) *out = word;
-        return;
-    }
-    if (lane < 8u) __hip_atomic_store(out, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0u) {
-        const uint32_t group = cam == 0u ? 0u : 1u + (uint32_t)kp / args.chunk_rows;
-        __hip_atomic_fetch_add(args.progress + (group * kClatchProgressWays + ((uint32_t)kp & (kClatchProgressWays - 1u))) * kClatchProgressStride, 1u,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// which CLATCH kernel the library launches: CLC_CLATCH_COPIES=4 (one wave per keypoint, four copies) | 8 (two waves, eight copies)
-static int clatch_copies()
-{
-    static const int v = [] { const char* e = getenv("CLC_CLATCH_COPIES"); return (e && atoi(e) == 4) ? 4 : ((e && atoi(e) == 8) ? 8 : CLC_CLATCH_DEFAULT_COPIES); }();
-    return v;
+    if (lane < 16u) reinterpret_cast<uint32_t*>(desc)[(size_t)kp * 16u + lane] = word;
 }
 
 static hipError_t launch_clatch_impl(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
-                                     int n_img, const uint32_t* const* d_count, hipStream_t stream, Profiler* prof,
-                                     uint32_t* progress = nullptr, uint32_t chunk_rows = 0)
+                                     int n_img, const uint32_t* const* d_count, hipStream_t stream, Profiler* prof)
 {
     if (n_img <= 0) return hipSuccess;
     if (n_img > kMaxBatch || slot_stride > 0xFFFFFFFFull) return hipErrorInvalidValue;
@@ -556,31 +276,9 @@ static hipError_t launch_clatch_impl(const PyramidDesc& pd, const uint8_t* arena
     }
     if (max_n <= 0) return hipSuccess;
     const int blocks = max_n;                           // one wave per keypoint (gridDim.x reaches 2^31 - 1)
-    a.progress = progress;
-    a.chunk_rows = chunk_rows ? chunk_rows : 1u;
     prof_mark(prof, CLC_KERNEL_CLATCH, true, stream);
-    if (clatch_copies() == 8) {
-        if (progress) hipLaunchKernelGGL(clatch8_kernel<true>, dim3(blocks, (uint32_t)n_img), dim3(128), 0, stream, a, arena);
-        else hipLaunchKernelGGL(clatch8_kernel<false>, dim3(blocks, (uint32_t)n_img), dim3(128), 0, stream, a, arena);
-    } else {
-        if (progress) hipLaunchKernelGGL(clatch_kernel<true>, dim3(blocks, (uint32_t)n_img), dim3(64), 0, stream, a, arena);
-        else hipLaunchKernelGGL(clatch_kernel<false>, dim3(blocks, (uint32_t)n_img), dim3(64), 0, stream, a, arena);
-    }
+    hipLaunchKernelGGL(clatch_kernel, dim3(blocks, (uint32_t)n_img), dim3(64), 0, stream, a, arena);
     prof_mark(prof, CLC_KERNEL_CLATCH, false, stream);
-    return hipGetLastError();
-}
-
-hipError_t launch_clatch_progress(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
-                                  uint32_t* progress, uint32_t chunk_rows, hipStream_t stream, Profiler* prof)
-{
-    if (!progress || chunk_rows == 0u) return hipErrorInvalidValue;
-    return launch_clatch_impl(pd, arena, slot_stride, batch, 2, nullptr, stream, prof, progress, chunk_rows);
-}
-
-hipError_t launch_clatch_gate(uint32_t* progress, uint32_t first, uint32_t groups, uint32_t n_train, uint32_t n_query, uint32_t chunk_rows,
-                              uint32_t* gate_error, hipStream_t stream)
-{
-    hipLaunchKernelGGL(clatch_gate_kernel, dim3(1), dim3(64), 0, stream, progress, first, groups, n_train, n_query, chunk_rows, gate_error);
     return hipGetLastError();
 }
 

@@ -49,20 +49,6 @@ struct ClatchBatch {
 hipError_t launch_clatch_batch(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
                                int n_img, hipStream_t stream, Profiler* prof = nullptr);
 
-// The pair step (capi.hip clc_describe_match_pair_dev): CLATCH of camera 0 (train side, dispatched first) and camera 1 (query side) in one
-// launch whose waves count themselves into progress groups -- group 0 = camera 0, group 1 + k = rows [k chunk_rows, (k + 1) chunk_rows)
-// of camera 1, kClatchProgressWays counters each -- and the one-wave gate that waits for groups to fill (and re-arms them).
-// (ways: atomics of agent scope are performed at the memory side, and those to ONE address one after the other -- measured round 5: 10 000
-// keypoints counted into 16 addresses made the describe launch 2.3 x longer; 128 addresses in cache lines of their own)
-static constexpr uint32_t kClatchProgressWays = 128;       // a multiple of 64
-static constexpr uint32_t kClatchProgressStride = 16;      // uint32 words between two counters
-static constexpr uint32_t kClatchMaxChunks = 16;
-hipError_t launch_clatch_progress(const PyramidDesc& pd, const uint8_t* arena, size_t slot_stride, const ClatchBatch& batch,
-                                  uint32_t* progress, uint32_t chunk_rows, hipStream_t stream, Profiler* prof = nullptr);
-// waits for groups first .. first + groups - 1 (group 0 = the n_train keypoints of camera 0; group k = rows of camera 1, n_query in all)
-hipError_t launch_clatch_gate(uint32_t* progress, uint32_t first, uint32_t groups, uint32_t n_train, uint32_t n_query, uint32_t chunk_rows,
-                              uint32_t* gate_error, hipStream_t stream);
-
 // ---- detector (FAST-9 + NMS + orientation) ---------------------------------------------------
 // Two launches for the pyramids of n_img cameras (pyramid b at arena + b * slot_stride, score map b at score + b * slot_stride):
 // d_mask: n_img x detect_total_tiles() x 16 keypoint-mask words, d_tcount: n_img x detect_total_tiles() tile counts (both rewritten
@@ -146,7 +132,7 @@ struct K2nnPlan {
     bool     atomic_merge; // every job fits the 22-bit global train index -> atomic top-2 merge
 };
 // The two formulations of the sweep (k2nn.hip): FP4 matrix pipe (default) and round 1's xor + popcount VALU kernel.
-enum { K2NN_MATRIX = 0, K2NN_POPCOUNT = 1, K2NN_MATRIX_PLAIN = 2 };   // PLAIN: round 2's tile loop (no MFMA / top-2 interleave)
+enum { K2NN_MATRIX = 0, K2NN_POPCOUNT = 1 };
 // Fill the derived fields of jobs[] (qblocks/splits/t_per_split/partial_off/nq_pad).
 // bias_a / bias_b: train share of a workgroup on wave slot 0 / 1 in 1/256 of the equal share (0: equal shares); used by single-job one-round plans only
 K2nnPlan k2nn_plan(K2nnJobDev* jobs, int njobs, int target_blocks, bool xcd_map = true, int formulation = K2NN_MATRIX, int bias_a = 0, int bias_b = 0,
@@ -202,13 +188,6 @@ hipError_t launch_pnp_refine(const double* d_Rt_in, const double* d_X, const dou
 size_t pnp_result_valid_offset();   // byte offset of the int32 "winning hypothesis" (< 0: none) in the ransac result record
 size_t pnp_refine_out_bytes();
 size_t pnp_refine_ready_offset();   // int32 written last by the refinement launch (1), for a host polling a pinned record
-
-// the minimal solvers alone (pnp.hip), for the a-contrario rounds: S samples -> 4 S pose slots / 10 S {F, E} slots
-// d_count (nullable): the number of samples actually solved is min(S, *d_count), read on the device
-hipError_t launch_p3p(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples, int S, double* d_Rt,
-                      hipStream_t stream, const int32_t* d_count = nullptr);
-hipError_t launch_fivept(const double* d_x1, const double* d_x2, int N, const double* d_K1, const double* d_K2, const int32_t* d_samples,
-                         int S, double* d_FE, hipStream_t stream, const int32_t* d_count = nullptr);
 
 // ---- a-contrario RANSAC (acransac.hip) -----------------------------------------------------------------------
 static constexpr int kAcrMaxBatch = 128;           // iterations evaluated per round
@@ -271,13 +250,8 @@ struct AcrChains { AcrChain c[kMaxBatch]; };
 // one round of n_chains solves: P3P (one launch) / five-point (two launches); batch_bound and the sort width cover the largest chain
 hipError_t launch_acr_round_p3p_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream);
 hipError_t launch_acr_round_5pt_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream);
-// nfa + select of one batch (state->cur_batch iterations) whose models are in d_models (max_models slots each)
 // batch_bound: iterations the launch grids cover (>= the batch the device state asks for); d_mask .. h_res: where the round that
 // completes the run leaves mask / inlier list / result record (device copies + pinned host mirrors)
-hipError_t launch_acr_round(const AcrProblem& pb, const double* d_models, AcrHyp* d_hyp, uint32_t* d_sorted, AcrState* d_state,
-                            uint32_t* d_best_inliers, uint32_t* d_index_set, int32_t* d_samples, unsigned long long* h_word,
-                            hipStream_t stream, int batch_bound, uint8_t* d_mask, AcrResult* d_res, uint8_t* h_mask, int32_t* h_inliers,
-                            AcrResult* h_res);
 // the resection round as ONE launch (replay of the previous round + P3P + nfa; acransac.hip): d_states / d_hyps / d_sorted / d_models
 // hold two copies, this launch reads copy par ^ 1 and writes copy par; the initial state goes into copy 1 and the first launch has par 0
 hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted, double* d_models,
@@ -290,8 +264,6 @@ hipError_t launch_acr_round_5pt(const AcrProblem& pb, int par, AcrState* d_state
 hipError_t launch_acr_stage(const double* h_pinned, double* d_dst, size_t n_doubles /* even */, hipStream_t stream);
 hipError_t launch_acr_stage_chains(const double* const* h_pinned, double* const* d_dst, const size_t* n_doubles /* even */, int n_chains,
                                    hipStream_t stream);
-hipError_t launch_acr_finish(const AcrProblem& pb, const AcrState* d_state, const uint32_t* d_best_inliers, uint8_t* d_mask, AcrResult* d_res,
-                             uint8_t* h_mask, int32_t* h_inliers, AcrResult* h_res, hipStream_t stream);
 
 } // namespace clc
 #endif

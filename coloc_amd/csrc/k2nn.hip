@@ -345,16 +345,16 @@ __device__ __forceinline__ uint32_t mx_decode_rel(const uint32_t bits, const uin
 // with s_memtime (shader clock) / s_memrealtime (constant 100 MHz) and stores them, with its entry / folded-in times and its
 // XCC id (tools/k2nn_timeline.py), in a buffer nothing else reads.  The product kernel (STAMP = false) contains no stamp.
 //
-// PIPE (round 3, the default): the two 32-query tiles of a wave are swept as two MFMA chains of eight, one after the other, and the
+// The loop (round 3): the two 32-query tiles of a wave are swept as two MFMA chains of eight, one after the other, and the
 // running top-2 of a chain's accumulators is updated in the shadow of the NEXT chain's MFMAs (sched_group_barrier spells the
 // interleave out: one MFMA, one A-operand read, five vector instructions).  No second accumulator set is needed -- chain 1 of tile
 // t covers the top-2 of chain 0 of tile t, chain 0 of tile t + 1 covers the top-2 of chain 1 of tile t -- so the kernel keeps its
-// three waves per SIMD; the price is that every A operand is read from LDS twice.  PIPE = false is round 2's loop (k-step outer,
-// both chains per A read, then all 64 v_med3): kept selectable as CLC_K2NN_MATRIX_PLAIN for A/B runs.
+// three waves per SIMD; the price is that every A operand is read from LDS twice.  (Round 2's loop -- k-step outer, both chains per
+// A read, then all 64 v_med3 -- was kept as an A/B formulation through round 5: profiles/r06_removed_variants.patch.)
 // PROBE: the same code under another symbol, for the launches of the per-device share probe at context creation (capi.hip k2nn_probe_bias):
-// a kernel trace of an application then shows ITS sweeps under k2nn_sweep_mx_kernel<false, true, false> and the probe's -- run from cold
+// a kernel trace of an application then shows ITS sweeps under k2nn_sweep_mx_kernel<false, false, false> and the probe's -- run from cold
 // clocks, under four different share pairs -- under <..., true>, instead of one average over both.
-template <bool STAMP, bool PIPE, bool GLOBAL = false, bool PROBE = false>
+template <bool STAMP, bool GLOBAL = false, bool PROBE = false>
 __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nnJobList jobs, uint2* __restrict__ partial,
                                                                       uint64_t* __restrict__ stamps)
 {
@@ -495,77 +495,48 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
             for (int i = 0; i < 16; ++i)
                 if ((uint32_t)(8 * (i >> 2) + 4 * (int)(lane >> 5) + (i & 3)) >= valid) cinit[i] += 4194304.0f + 8192.0f;
         }
-        if (!PIPE) {
-            mx_v16f acc[QT];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const u32x4 av = s_a[buf][j * kStride + lane];
-                const mx_v8i a8 = { (int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0 };
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    const mx_v8i b8 = { b[qt][j].x, b[qt][j].y, b[qt][j].z, b[qt][j].w, 0, 0, 0, 0 };
-                    mx_v16f c;
-                    if (j == 0) {
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) c[i] = cinit[i];
-                    } else c = acc[qt];
-                    acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c, 4 /* A: fp4 */, 4 /* B: fp4 */, 0, scale_a, 0, scale_b);
-                }
-            }
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    second[qt] = mx_med3(best[qt], second[qt], acc[qt][i]);
-                    best[qt] = mx_med3(best[qt], acc[qt][i], 0.0f);       // = min: every key is > 0
-                }
-            }
-            // next tile: instead of advancing the index part of the sixteen C registers, the running pair steps BACK by one tile --
-            // its index field is then relative to the tile about to be processed (negative for the tiles behind; the integer stays
-            // exact in fp32, order and tie rule unchanged: a lower global index is a lower value).  4 VALU instead of 16 per tile.
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) { best[qt] -= 32.0f; second[qt] -= 32.0f; }
-        } else {
-            static_assert(QT == 2, "the pipelined loop is written for two chains");
-            // chain c of this tile (8 MFMAs) with the top-2 update of `prev` (the accumulators of the chain before it) in its shadow
-            // sixteen steps: step s = MFMA j = s & 7 of chain s >> 3; the A operand of step s + kAhead is requested at step s (an LDS
-            // read takes longer than one MFMA: with the next step's operand only, every MFMA waited for its read)
+        static_assert(QT == 2, "the pipelined loop is written for two chains");
+        // chain c of this tile (8 MFMAs) with the top-2 update of `prev` (the accumulators of the chain before it) in its shadow
+        // sixteen steps: step s = MFMA j = s & 7 of chain s >> 3; the A operand of step s + kAhead is requested at step s (an LDS
+        // read takes longer than one MFMA: with the next step's operand only, every MFMA waited for its read)
 #ifndef CLC_K2NN_AHEAD
 #define CLC_K2NN_AHEAD 3
 #endif
-            constexpr int kAhead = CLC_K2NN_AHEAD;
-            u32x4 ring[kAhead];
+        constexpr int kAhead = CLC_K2NN_AHEAD;
+        u32x4 ring[kAhead];
 #pragma unroll
-            for (int k = 0; k < kAhead; ++k) ring[k] = s_a[buf][k * kStride + lane];
+        for (int k = 0; k < kAhead; ++k) ring[k] = s_a[buf][k * kStride + lane];
 #pragma unroll
-            for (int st = 0; st < 16; ++st) {
-                const int c = st >> 3, j = st & 7;
-                const u32x4 av = ring[st % kAhead];
-                const mx_v8i a8 = { (int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0 };
-                const mx_v8i b8 = { b[c][j].x, b[c][j].y, b[c][j].z, b[c][j].w, 0, 0, 0, 0 };
-                if (st + kAhead < 16) ring[st % kAhead] = s_a[buf][((st + kAhead) & 7) * kStride + lane];
-                mx_v16f& acc = c ? acc1 : acc0;
-                const mx_v16f& prev = c ? acc0 : acc1;       // chain 0 folds in chain 1 of the tile before, chain 1 folds in chain 0
-                const int pq = c ? 0 : 1;
-                mx_v16f ci;
-                if (j == 0) {
+        for (int st = 0; st < 16; ++st) {
+            const int c = st >> 3, j = st & 7;
+            const u32x4 av = ring[st % kAhead];
+            const mx_v8i a8 = { (int)av.x, (int)av.y, (int)av.z, (int)av.w, 0, 0, 0, 0 };
+            const mx_v8i b8 = { b[c][j].x, b[c][j].y, b[c][j].z, b[c][j].w, 0, 0, 0, 0 };
+            if (st + kAhead < 16) ring[st % kAhead] = s_a[buf][((st + kAhead) & 7) * kStride + lane];
+            mx_v16f& acc = c ? acc1 : acc0;
+            const mx_v16f& prev = c ? acc0 : acc1;       // chain 0 folds in chain 1 of the tile before, chain 1 folds in chain 0
+            const int pq = c ? 0 : 1;
+            mx_v16f ci;
+            if (j == 0) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) ci[i] = cinit[i];
-                } else ci = acc;
-                acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, ci, 4, 4, 0, scale_a, 0, scale_b);
-                // two of the sixteen keys of the chain before, in this MFMA's shadow (32 cycles of matrix pipe, 8 of them holding the
-                // vector issue: four v_med3 fit)
+                for (int i = 0; i < 16; ++i) ci[i] = cinit[i];
+            } else ci = acc;
+            acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, ci, 4, 4, 0, scale_a, 0, scale_b);
+            // two of the sixteen keys of the chain before, in this MFMA's shadow (32 cycles of matrix pipe, 8 of them holding the
+            // vector issue: four v_med3 fit)
 #pragma unroll
-                for (int i = 2 * j; i < 2 * j + 2; ++i) {
-                    second[pq] = mx_med3(best[pq], second[pq], prev[i]);
-                    best[pq] = mx_med3(best[pq], prev[i], 0.0f);
-                }
-                if (j == 7) { best[pq] -= 32.0f; second[pq] -= 32.0f; }     // the step back of the chain just folded in (see the plain loop)
-                __builtin_amdgcn_sched_barrier(0);                           // keep the groups in this order
+            for (int i = 2 * j; i < 2 * j + 2; ++i) {
+                second[pq] = mx_med3(best[pq], second[pq], prev[i]);
+                best[pq] = mx_med3(best[pq], prev[i], 0.0f);
             }
+            // the step back of the chain just folded in: instead of advancing the index part of the sixteen C registers per tile, the
+            // running pair steps BACK by one tile -- its index field is then relative to the tile about to be processed (negative for
+            // the tiles behind; the integer stays exact in fp32, order and tie rule unchanged: a lower global index is a lower value)
+            if (j == 7) { best[pq] -= 32.0f; second[pq] -= 32.0f; }
+            __builtin_amdgcn_sched_barrier(0);                           // keep the groups in this order
         }
     }
-    if (PIPE) {        // the last tile's second chain is still to be folded in
+    {                  // the last tile's second chain is still to be folded in
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             second[1] = mx_med3(best[1], second[1], acc1[i]);
@@ -912,28 +883,18 @@ hipError_t launch_k2nn(const K2nnJobDev* jobs, int njobs, uint2* d_partial, hipS
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, true, stream);
             if (formulation == K2NN_POPCOUNT)
                 hipLaunchKernelGGL(k2nn_sweep_kernel<kR>, dim3(grid_x, cnt), dim3(64 * kWaves), 0, stream, list, d_partial);
-            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u && d_stamps && formulation == K2NN_MATRIX_PLAIN)
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
             else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u && d_stamps)
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
-            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u && formulation == K2NN_MATRIX_PLAIN)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
+            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                                   (uint64_t*)nullptr);
+            else if (d_stamps)
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
+            else if (probe)
                 hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
                                    (uint64_t*)nullptr);
-            else if (cnt == 1 && list.j[0].bias_a != 0u && list.j[0].bias_magic != 0u)
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
-                                   (uint64_t*)nullptr);
-            else if (d_stamps && formulation == K2NN_MATRIX_PLAIN)
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, false>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
-            else if (d_stamps)
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<true, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial, d_stamps);
-            else if (formulation == K2NN_MATRIX_PLAIN)
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, false>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
-                                   (uint64_t*)nullptr);
-            else if (probe)
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true, false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
-                                   (uint64_t*)nullptr);
             else
-                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false, true>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
+                hipLaunchKernelGGL((k2nn_sweep_mx_kernel<false>), dim3(grid_x, cnt), dim3(64 * kMxWaves), 0, stream, list, d_partial,
                                    (uint64_t*)nullptr);
             prof_mark(prof, CLC_KERNEL_K2NN_SWEEP, false, stream);
         }

@@ -761,22 +761,4 @@ hipError_t launch_pnp_score(const double* d_Rt, int H, const double* d_X, const 
     return hipGetLastError();
 }
 
-hipError_t launch_p3p(const double* d_X, const double* d_x, int N, const double* d_K, const int32_t* d_samples, int S, double* d_Rt,
-                      hipStream_t stream, const int32_t* d_count)
-{
-    if (S <= 0 || N <= 0) return hipSuccess;
-    const int solve_blocks = (4 * S + 63) / 64;
-    hipLaunchKernelGGL(p3p_kernel, dim3(solve_blocks), dim3(64), 0, stream, d_X, d_x, d_K, d_samples, S, N, d_Rt, solve_blocks,
-                       (const double*)nullptr, (double*)nullptr, 0, d_count);
-    return hipGetLastError();
-}
-
-hipError_t launch_fivept(const double* d_x1, const double* d_x2, int N, const double* d_K1, const double* d_K2, const int32_t* d_samples,
-                         int S, double* d_FE, hipStream_t stream, const int32_t* d_count)
-{
-    if (S <= 0 || N <= 0) return hipSuccess;
-    hipLaunchKernelGGL(fivept_kernel, dim3(S), dim3(64), 0, stream, d_x1, d_x2, d_K1, d_K2, d_samples, S, N, d_FE, d_count);
-    return hipGetLastError();
-}
-
 } // namespace clc

@@ -22,7 +22,7 @@
 #include "coloc_hip.h"
 #include "coloc_hip_types.hpp"
 
-static_assert(CLC_ABI_VERSION >= 2, "this policy header uses entry points of ABI version 2 (clc_desc_cache_mode)");
+static_assert(CLC_ABI_VERSION >= 3, "this policy header uses entry points of ABI version 3 (clc_detect_and_describe_view, clc_desc_handle)");
 
 namespace coloc {
 

@@ -37,9 +37,11 @@ extern "C" {
 #endif
 
 /* 1: rounds 1-3.  2: round 4's additions (clc_detect_batch_dev, clc_desc_cache_*, clc_k2nn_plan_query, clc_mc_open_peers,
- * clc_pnp_localize_ac_batch / clc_pose_job, one-rank communicators in clc_mc_create) + round 5's (clc_desc_cache_mode, ...).
- * Bindings check clc_abi_version() BEFORE resolving symbols an older library does not export. */
-#define CLC_ABI_VERSION 2
+ * clc_pnp_localize_ac_batch / clc_pose_job, one-rank communicators in clc_mc_create).  3: round 5's additions (clc_desc_cache_mode,
+ * clc_describe_match_pair_dev, clc_essential_acransac_batch, clc_inter_pose_batch, clc_k2nn_device_info) and round 6's changes
+ * (clc_describe_match_pair_dev lost its `chunks` argument, CLC_K2NN_MATRIX_PLAIN is gone, the descriptor hand-over is by ownership:
+ * clc_desc_cache_publish returns a handle).  Bindings check clc_abi_version() BEFORE resolving symbols an older library does not export. */
+#define CLC_ABI_VERSION 3
 #define CLC_DESC_BYTES 64
 #define CLC_MAX_LEVELS 8
 #define CLC_MAX_BATCH 8    /* cameras per clc_describe_batch_dev / clc_detect_batch_dev call */
@@ -230,17 +232,12 @@ int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, in
 /* Describe both cameras of a pair and match them as ONE step: replaces detectAndDescribe of each camera (GPUDetector.hpp:216-291)
  * followed by computeMatchesPair (GPUMatcher.hpp:165-172 -> :180-226).  Camera 0 is the query side (regions[pair.first]), camera 1 the
  * train side; d_desc[b] receives counts[b] x 64 B, d_match counts[0] indices into camera 1 (or -1), exactly what clc_describe_batch_dev +
- * clc_match_2nn_dev give.  The sweep over a chunk of camera 0's rows starts while the describe launch is still working on the later
- * chunks (second stream inside the context, one-wave gates on the describe launch's progress counters; the caller's stream joins before
- * the call's work is complete from its point of view).  chunks: 0 = the context's default: no chunking, unless CLC_PAIR_CHUNKS=a,b,..
- * (groups of eight query blocks) is set; 1 = no overlap (one describe launch, then one sweep launch, on the caller's stream); K = K
- * about equal chunks.  On MI355X the chunked form is SLOWER (CLATCH leaves a CU's LDS no room for a sweep workgroup until its launch
- * drains: profiles/r05_step_overlap.txt) -- it is kept for A/B runs; what does overlap describe and sweep is two contexts on two
- * streams taking alternate steps (bench.py's headline loop).
- * Enqueue only; capturable.  16-byte aligned descriptor pointers. */
+ * clc_match_2nn_dev give: one pyramid launch, one CLATCH launch (train camera dispatched first), one sweep launch on the caller's stream.
+ * What overlaps describe and sweep on MI355X is two contexts on two streams taking alternate steps (bench.py's headline loop), not a
+ * split inside one step (profiles/r05_step_overlap.txt).  Enqueue only; capturable.  16-byte aligned descriptor pointers. */
 int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_t width, uint32_t height, size_t pitch,
                                 const clc_keypoint* const* d_kps, const int* counts, void* const* d_desc, int threshold,
-                                int32_t* d_match, int chunks, void* stream);
+                                int32_t* d_match, void* stream);
 /* Many (query-slice, train-set) jobs over one descriptor arena in ONE sweep launch: the
  * all-pairs loop of GPUMatcher::computeMatches (GPUMatcher.hpp:143-155) and the per-rank share
  * of it after the multi-GPU all-gather.  h_jobs is host memory. */
@@ -258,8 +255,7 @@ int clc_match_jobs_counted_dev(clc_ctx* ctx, const void* d_desc_base, const clc_
  * CLC_K2NN_MATRIX (default): bits as +-1 FP4 values on the matrix pipe, exact distances in the fp32 accumulator;
  * CLC_K2NN_POPCOUNT: xor + popcount on the vector ALU, the literal form of CUDAK2NN.cu:58-66 (kept for A/B timing).
  * Also settable at context creation through the environment, CLC_K2NN_FORMULATION=matrix|popcount. */
-enum { CLC_K2NN_MATRIX = 0, CLC_K2NN_POPCOUNT = 1,
-       CLC_K2NN_MATRIX_PLAIN = 2 /* the matrix sweep without its MFMA / top-2 interleave (round 2's loop), for A/B timing */ };
+enum { CLC_K2NN_MATRIX = 0, CLC_K2NN_POPCOUNT = 1 };
 int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation);
 /* Queries per sweep workgroup of the context's formulation: the grain on which a caller that deals query slices out
  * to several GPUs (clc_match_job.q_offset / nq) should cut them, so that no workgroup is split between two jobs. */

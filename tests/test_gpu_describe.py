@@ -194,36 +194,3 @@ def test_batched_cameras_equal_per_image_calls(oracle):
     with pytest.raises(Exception):
         ctx.describe_batch_dev([0] * 9, W, H, pitch, [0] * 9, [0] * 9, [0] * 9)
     ctx.close(); single.close()
-
-
-def test_eight_copy_kernel_same_bits(oracle):
-    """clatch8_kernel (round 5: two waves per keypoint, eight byte-shifted window copies, every patch row an aligned ds_read_b64) is the
-    measured A/B variant of the shipped four-copy kernel (profiles/r05_clatch_notes.txt): selected per PROCESS by CLC_CLATCH_COPIES=8, it
-    must give the oracle's descriptors -- keypoints at the borders, all scales, special angles included."""
-    import subprocess
-    import sys
-    import tempfile
-    W, H, n = 640, 480, 6000
-    img = synth.rect_image(W, H, seed=4711, noise_sigma=2.0)
-    kps = synth.random_keypoints(n, W, H, seed=4712)
-    ws, hs, _ = oracle.pyramid_dims(W, H)
-    for i, ang in enumerate((0.0, math.pi / 2, -math.pi / 2, math.pi, 1e-7, -3.1415925)):
-        kps["angle"][i] = np.float32(ang)
-    for i in range(8):                                   # window reaching over every border of every level
-        lw, lh = ws[i], hs[i]
-        for j, (x, y) in enumerate(((3, 3), (lw - 4, 3), (3, lh - 4), (lw - 4, lh - 4))):
-            k = 10 + 4 * i + j
-            kps["x"][k], kps["y"][k], kps["scale"][k] = x, y, i
-    want = oracle.clatch(oracle.pyramid(img), kps)
-    with tempfile.TemporaryDirectory() as d:
-        np.save(os.path.join(d, "img.npy"), img)
-        np.save(os.path.join(d, "kps.npy"), kps.view(np.uint8))
-        code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import synth; from coloc_amd import Context;"
-                "img = np.load(%r); kps = np.load(%r).view(synth.KP_DTYPE).reshape(-1);"
-                "c = Context(device=0, width=%d, height=%d, maxkp=%d); c.pyramid_build(img); np.save(%r, c.describe(kps)); c.close()"
-                % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
-                   os.path.join(d, "img.npy"), os.path.join(d, "kps.npy"), W, H, n, os.path.join(d, "out.npy")))
-        for copies in ("8", "4"):
-            out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CLC_CLATCH_COPIES=copies), capture_output=True, text=True, timeout=300)
-            assert out.returncode == 0, out.stderr[-2000:]
-            assert np.array_equal(np.load(os.path.join(d, "out.npy")), want), "CLC_CLATCH_COPIES=" + copies

@@ -9,11 +9,11 @@ import synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["matrix", "popcount", "matrix-plain"])
+@pytest.fixture(autouse=True, params=["matrix", "popcount"])
 def k2nn_formulation(request, gpu_ctx):
-    """Every test of this file runs under every formulation of the sweep (coloc_amd/csrc/k2nn.hip): the FP4 matrix-pipe
-    kernel (default: MFMA chains with the top-2 update in their shadow), the xor + popcount kernel, and the matrix kernel
-    with round 2's plain tile loop; all must equal the oracle bit for bit."""
+    """Every test of this file runs under both formulations of the sweep (coloc_amd/csrc/k2nn.hip): the FP4 matrix-pipe
+    kernel (default: MFMA chains with the top-2 update in their shadow) and the xor + popcount kernel; both must equal the
+    oracle bit for bit."""
     gpu_ctx.set_k2nn_formulation(request.param)
     yield request.param
     gpu_ctx.set_k2nn_formulation("matrix")

@@ -1,8 +1,8 @@
-"""The pair step (clc_describe_match_pair_dev, round 5): describe both cameras of a pair and match them as one unit, the sweep over a
-finished chunk of the query camera running beside the rest of the describe launch.  It replaces detectAndDescribe x 2
-(GPUDetector.hpp:216-291) + computeMatchesPair (GPUMatcher.hpp:165-172): descriptors must equal the oracle's CLATCH bit for bit, the match
-indices the oracle's K2NN on those descriptors -- for every chunking, ragged counts, empty sides, repeated steps (the progress counters,
-top-2 rows and arrival counters re-arm themselves) and both formulations of the sweep."""
+"""The pair step (clc_describe_match_pair_dev): describe both cameras of a pair and match them as one enqueue.  It replaces
+detectAndDescribe x 2 (GPUDetector.hpp:216-291) + computeMatchesPair (GPUMatcher.hpp:165-172): descriptors must equal the oracle's CLATCH
+bit for bit, the match indices the oracle's K2NN on those descriptors -- for ragged counts, empty sides, repeated steps (the top-2 rows
+and arrival counters re-arm themselves) and both formulations of the sweep.  (Round 5's chunked form with its device-side gates is gone
+from the library: profiles/r06_removed_variants.patch.)"""
 import numpy as np
 import pytest
 
@@ -24,7 +24,7 @@ def _inputs(torch, nq, nt, seed):
 
 @pytest.mark.parametrize("formulation", ["matrix", "popcount"])
 @pytest.mark.parametrize("nq,nt", [(10000, 10000), (9000, 10000), (4097, 3000), (777, 5000), (2048, 2048), (6200, 1), (0, 100), (100, 0)])
-def test_pair_step_equals_oracle_for_every_chunking(oracle, formulation, nq, nt):
+def test_pair_step_equals_oracle(oracle, formulation, nq, nt):
     import torch
     from coloc_amd import Context
     ctx = Context(device=0, width=W, height=H, maxkp=10000)
@@ -35,24 +35,23 @@ def test_pair_step_equals_oracle_for_every_chunking(oracle, formulation, nq, nt)
         want_d = [oracle.clatch(pyr[c], kps[c]) if len(kps[c]) else np.zeros((0, 64), np.uint8) for c in range(2)]
         want_m = oracle.k2nn(want_d[0], want_d[1], 40) if nq and nt else np.full(nq, -1, np.int32)
         assert nq < 3000 or nt < 3000 or (want_m >= 0).sum() > nq // 4              # the cameras see the same scene: the accept branch is exercised
-        for chunks in (0, 1, 2, 3, 5, 16):
-            desc = [torch.full((max(n, 1), 64), 0xA5, dtype=torch.uint8, device="cuda") for n in (nq, nt)]
-            match = torch.full((max(nq, 1),), -7, dtype=torch.int32, device="cuda")
-            torch.cuda.synchronize()
-            for rep in range(3):                                                    # counters, rows and arrival words re-arm
-                ctx.describe_match_pair_dev([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [nq, nt],
-                                            [t.data_ptr() for t in desc], 40, match.data_ptr(), chunks=chunks)
-            ctx.sync()
-            for c, n in enumerate((nq, nt)):
-                assert np.array_equal(desc[c].cpu().numpy()[:n], want_d[c]), (chunks, c)
-            assert np.array_equal(match.cpu().numpy()[:nq], want_m), chunks
+        desc = [torch.full((max(n, 1), 64), 0xA5, dtype=torch.uint8, device="cuda") for n in (nq, nt)]
+        match = torch.full((max(nq, 1),), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for rep in range(3):                                                        # rows and arrival words re-arm
+            ctx.describe_match_pair_dev([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [nq, nt],
+                                        [t.data_ptr() for t in desc], 40, match.data_ptr())
+        ctx.sync()
+        for c, n in enumerate((nq, nt)):
+            assert np.array_equal(desc[c].cpu().numpy()[:n], want_d[c]), c
+        assert np.array_equal(match.cpu().numpy()[:nq], want_m)
     finally:
         ctx.close()
 
 
 def test_pair_step_back_to_back_with_changing_inputs(oracle):
     """40 steps enqueued without a host synchronisation in between, the keypoint order and the counts changing from step to step (each
-    step writes its own output buffers): the join at the end of a step orders the next one behind it, no step sees another's counters."""
+    step writes its own output buffers): stream order alone keeps the steps apart."""
     import torch
     from coloc_amd import Context
     ctx = Context(device=0, width=W, height=H, maxkp=10000)
@@ -67,7 +66,7 @@ def test_pair_step_back_to_back_with_changing_inputs(oracle):
             desc = [torch.zeros((10000, 64), dtype=torch.uint8, device="cuda") for _ in range(2)]
             match = torch.full((10000,), -7, dtype=torch.int32, device="cuda")
             ctx.describe_match_pair_dev([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [nq, nt],
-                                        [t.data_ptr() for t in desc], 40, match.data_ptr(), chunks=(0, 4, 2)[it % 3])
+                                        [t.data_ptr() for t in desc], 40, match.data_ptr())
             outs.append((nq, nt, desc, match))
         ctx.sync()
         cache = {}
@@ -81,8 +80,8 @@ def test_pair_step_back_to_back_with_changing_inputs(oracle):
 
 
 def test_pair_step_is_capturable(oracle):
-    """Enqueue only, no allocation after the first call: the step (fork to the context's second stream, gates, chunk sweeps, join) is
-    captured into a hipGraph and replayed with new images in the same buffers."""
+    """Enqueue only, no allocation after the first call: the step is captured into a hipGraph and replayed with new images in the same
+    buffers."""
     import torch
     from coloc_amd import Context
     ctx = Context(device=0, width=W, height=H, maxkp=6000)
@@ -94,11 +93,11 @@ def test_pair_step_is_capturable(oracle):
         st = torch.cuda.Stream()
         args = ([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [n, n], [t.data_ptr() for t in desc], 40, match.data_ptr())
         with torch.cuda.stream(st):
-            ctx.describe_match_pair_dev(*args, chunks=0, stream=st.cuda_stream)          # warm: second stream, workspace
+            ctx.describe_match_pair_dev(*args, stream=st.cuda_stream)          # warm: workspace
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
-                ctx.describe_match_pair_dev(*args, chunks=0, stream=st.cuda_stream)
+                ctx.describe_match_pair_dev(*args, stream=st.cuda_stream)
             for rep in range(3):
                 img2 = [np.roll(i, 3 * rep + 1, axis=1).copy() for i in imgs]
                 for t, i in zip(d_imgs, img2):

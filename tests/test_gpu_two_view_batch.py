@@ -141,36 +141,6 @@ def test_inter_pose_batch_lands_on_the_destination_pose():
             c.close()
 
 
-def test_two_launch_round_equals_the_three_launch_round():
-    """The a-contrario five-point round is two launches since round 5 (replay of the previous round + samples + solve; nfa); rounds 2-4's
-    three-launch form (solve, nfa, select on one copy of the state) stays selectable per process (CLC_ACR_5PT_LAUNCHES=3) for A/B runs.
-    Both replay the same sequential semantics on the same minimal solutions: E, inliers, threshold, NFA and iteration count identical."""
-    import json
-    import os
-    import subprocess
-    import sys
-    from coloc_amd import Context
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_two_view_batch as t; from coloc_amd import Context;"
-            "c = Context(device=0, detector=False, matcher=False); out = [];\n"
-            "for s in (11, 12, 13):\n"
-            "    p = t._pair(400 + s, n=500 + (100 * s) %% 700)\n"
-            "    r = c.essential_acransac(p['x1'], p['x2'], t.K, t.K, t.WH, max_iteration=256, seed=s)\n"
-            "    out.append(dict(E=r['E'].tolist(), inl=r['inliers'].tolist(), emax=r['error_max'], nfa=r['min_nfa'], it=r['iterations']))\n"
-            "print('RESULT' + json.dumps(out))" % (os.path.dirname(here), here))
-    res = {}
-    for mode in ("3", "2"):
-        env = dict(os.environ)
-        env.pop("CLC_ACR_5PT_LAUNCHES", None)
-        if mode == "3":
-            env["CLC_ACR_5PT_LAUNCHES"] = "3"
-        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr[-2000:]
-        res[mode] = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0][6:])
-    assert res["2"] == res["3"]
-    assert all(len(r["inl"]) > 100 for r in res["2"])
-
-
 def test_lockstep_batches_equal_interleaved_batches_equal_single_solves():
     """Round 5: the solves of a batch may share their launches (lockstep: one launch per round for all of them, blockIdx.y = solve) instead of
     interleaving chains of their own -- the default for two-view batches of four or more, CLC_ACR_LOCKSTEP=1 / =0 forces it on / off for

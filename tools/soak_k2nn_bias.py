@@ -31,7 +31,7 @@ def main():
             mo, bo, so = orc.k2nn_omp(Q, T, rule=0, threshold=thr, kernel=0)[0], None, None
         else:
             mo, bo, so = orc.k2nn(Q, T, thr, want_dist=True)
-        form = ("matrix", "matrix-plain")[it & 1]
+        form = ("matrix", "popcount")[it & 1]
         ctx.set_k2nn_formulation(form)
         p = ctx.k2nn_plan_query(nq, nt)
         took["equal" if not p["bias_a_tiles"] else ("per-XCD" if p["qblocks"] % 8 == 0 else "all ids")] += 1
