@@ -122,9 +122,11 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
                                   collective_fallback="an exchange leg of the product's clc_mc_* path did not return within %s s: the torch "
                                                       "exchange's measurement stands" % os.environ.get("BENCH_LEG_LIMIT", "90"),
                                   section_errors=["exchange_legs"])), flush=True)
-        # every rank's watchdog fires (each is stuck in, or waiting for, the same leg): the line above is complete and valid, the failure
-        # is IN it (section_errors, collective_fallback) -- leaving with 0 keeps a launcher from discarding it; BENCH_LEG_HANG_RC overrides
-        os._exit(int(os.environ.get("BENCH_LEG_HANG_RC", "0")))
+        # every rank's watchdog fires (each is stuck in, or waiting for, the same leg).  The line above is complete -- the failure is IN it
+        # (section_errors, collective_fallback) -- but a leg that hangs in a process that has touched the GPU (an RCCL or peer-copy
+        # deadlock, a wedged device) is a FAILURE of the run and leaves as one: exit code 4 (BENCH_LEG_HANG_RC overrides; a launcher that
+        # wants the line parses it separately from the code)
+        os._exit(int(os.environ.get("BENCH_LEG_HANG_RC", "4")))
 
     # the reference result: one more step of the headline exchange
     step()
@@ -1132,6 +1134,79 @@ def main():
                                                       "lookup folds the whole 640 KB host block (two of them per call) and compares with the fold taken at publish time",
                                     "pyramid_plus_describe_10k_us": td * 1e6, "Mdesc_per_s_incl_transfers": NKP / td / 1e6}
 
+        def sec_policy_path():
+            # The DROP-IN path timed from C++: tests/host/bench_policy.cpp drives HIPDetector -> HIPMatcher ->
+            # HIPLocalizer in ColoC::mainThread's order (reference include/coloc/coloc.hpp:111-148) on rendered frames of one scene and
+            # prints p50 / p95 of the spans the reference prints (:129-136 detection, :161-164 pair matching, :217-221 map tracking,
+            # :222-225 PnP).  Host buffers in, OpenMVG-shaped regions / matches / pose out, every copy and synchronisation of the policy
+            # classes included.  Never `value`.
+            import subprocess
+            import tempfile
+            from coloc_amd import Context, keypoints_to_features
+            K = np.array([[520.0, 0, 320.0], [0, 520.0, 240.0], [0, 0, 1.0]])
+            relief = synth.smooth_relief()
+            Ra, ta = synth.look_at_plane_pose((7.0, 7.0), 5.0, yaw=0.0, tilt=(0.10, -0.06))
+            Rb, tb = synth.look_at_plane_pose((7.6, 6.7), 5.2, yaw=0.12, tilt=(-0.08, 0.09))
+            det = Context(device=dev_index, width=W, height=H, maxkp=12000, matcher=False)
+            try:
+                frames = None
+                for n_rect in (900, 2500, 6000):          # a texture dense enough for ~5 k keypoints at 640 x 480
+                    tex = synth.plane_texture(n_rect=n_rect)
+                    frames = [synth.render_plane(tex, 100.0, K, R, t, W, H, relief=relief) for R, t in ((Ra, ta), (Rb, tb))]
+                    kps0, desc0, _ = det.detect_and_describe(frames[0])
+                    if len(kps0) >= 4500:
+                        break
+                # the same frame through the device-pointer path: what the policy path's regions must hold
+                d_img = torch.from_numpy(frames[0]).to(dev)
+                det.pyramid_build_dev(d_img.data_ptr(), W, H, W, None)
+                kp_dev, _ = det.detect(capacity=12000)
+                tmp = torch.zeros((max(len(kp_dev), 1), 64), dtype=torch.uint8, device=dev)
+                det.describe_detected_dev(tmp.data_ptr(), None)
+                det.sync()
+                desc_dev = tmp.cpu().numpy()[:len(kp_dev)]
+            finally:
+                det.close()
+            with tempfile.TemporaryDirectory() as d:
+                for c, img in enumerate(frames):
+                    with open(os.path.join(d, "cam%d.pgm" % c), "wb") as f:
+                        f.write(b"P5\n# rendered\n%d %d\n255\n" % (W, H))
+                        f.write(img.tobytes())
+                feat0 = keypoints_to_features(kps0)
+                synth.backproject_to_plane(feat0[:, :2].astype(np.float64), K, Ra, ta, relief=relief).astype(np.float64).tofile(os.path.join(d, "map_xyz.bin"))
+                exe = os.path.join(d, "bench_policy")
+                libdir = os.path.join(ROOT, "coloc_amd", "lib")
+                subprocess.check_call(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "coloc_amd", "host"),
+                                       os.path.join(ROOT, "tests", "host", "bench_policy.cpp"), "-o", exe, "-L", libdir, "-lcoloc_hip", "-Wl,-rpath," + libdir])
+                res = {}
+                for name, env_publish in (("default", None), ("upload_every_call", "0"), ("trusting", "t")):
+                    env = dict(os.environ)
+                    if env_publish is not None:
+                        env["BENCH_POLICY_PUBLISH"] = env_publish
+                    r = subprocess.run([exe, d, str(W), str(H), str(K[0, 0]), str(K[0, 2]), str(K[1, 2]), "300", "60", "12000"], capture_output=True, text=True,
+                                       cwd=d, env=env, timeout=240)
+                    line = [l for l in r.stdout.splitlines() if l.startswith("POLICY ")]
+                    if r.returncode != 0 or not line:
+                        raise RuntimeError("bench_policy (%s) failed: rc %d %s" % (name, r.returncode, r.stderr[-500:]))
+                    res[name] = json.loads(line[0][7:])
+                got = np.fromfile(os.path.join(d, "policy_desc0.bin"), dtype=np.uint8).reshape(-1, 64)
+                same = got.shape == desc_dev.shape and bool(np.array_equal(got, desc_dev)) and got.shape == desc0.shape and bool(np.array_equal(got, desc0))
+            if not same:
+                raise RuntimeError("the policy path's descriptors differ from the device-pointer path's")
+            r0 = res["default"]
+            out["policy_path"] = {
+                "what": "tests/host/bench_policy.cpp: HIPDetector::detectFeaturesImage -> HIPMatcher::matchSceneWithMap -> HIPLocalizer::localizeImage per camera "
+                        "frame (ColoC::mainThread's order, coloc.hpp:111-148), p50 over 300 frames behind 60 untimed ones, host buffers in / regions, matches, "
+                        "pose + covariance out; pair_match_us = HIPMatcher::computeMatches of the two cameras (initMap, :161-164)",
+                "frame": "%dx%d rendered scene" % (W, H), "keypoints": r0["keypoints"], "map_points": r0["map_points"], "map_matches": r0["map_matches"],
+                "pose_inliers": r0["pose_inliers"],
+                "detect_us": r0["detect_us"], "match_us": r0["match_us"], "pose_us": r0["pose_us"], "frame_us": r0["frame_us"], "pair_match_us": r0["pair_match_us"],
+                "p95": {k: r0[k + "_p95"] for k in ("detect_us", "match_us", "pose_us", "frame_us", "pair_match_us")},
+                "identical_to_device_pointer_path": same, "same_results_every_frame": r0["same_results_every_frame"],
+                "descriptor_hand_over": {"default (published, verified behind the sweep)": {k: r0[k] for k in ("match_us", "pair_match_us")},
+                                         "upload every call (reference behaviour)": {k: res["upload_every_call"][k] for k in ("match_us", "pair_match_us")},
+                                         "trusting (opt-in)": {k: res["trusting"][k] for k in ("match_us", "pair_match_us")}},
+            }
+
         def sec_cpu_baseline():
             if not args.no_cpu_baseline and world == 1:
                 dq = arena[0].cpu().numpy()
@@ -1148,6 +1223,7 @@ def main():
             # the side sections belong to the one-GPU line; at N > 1 the other ranks would sit in the teardown barrier below while
             # rank 0 alone ran them for tens of seconds
             guarded("host_path", sec_host_path)
+            guarded("policy_path", sec_policy_path)
             guarded("k2nn_ab", sec_k2nn_ab)
             guarded("two_streams", sec_two_streams)
             guarded("shares", sec_shares)
@@ -1159,7 +1235,7 @@ def main():
         if world > 1:
             # the side sections belong to the one-GPU line (cpu_baseline: rank 0 at N = 1 only, by the bench contract); their keys are
             # present and null here so that lines of different N can be compared field by field
-            for k in ("cpu_baseline", "gpu_over_cpu", "front_end", "pose_solve", "pose_solve_p50_ms", "pose_batch", "pose_batch_per_pose_p50_ms", "two_view", "host_path",
+            for k in ("cpu_baseline", "gpu_over_cpu", "front_end", "pose_solve", "pose_solve_p50_ms", "pose_batch", "pose_batch_per_pose_p50_ms", "two_view", "host_path", "policy_path",
                       "accepted_matches_per_step"):
                 out.setdefault(k, None)
         if errors:

@@ -52,6 +52,11 @@ class PoseJob(C.Structure):
 ABI_VERSION = 3          # CLC_ABI_VERSION of include/coloc_hip.h
 DESC_CACHE_OFF, DESC_CACHE_VERIFY, DESC_CACHE_TRUST = 0, 1, 2
 
+class DescHandle(C.Structure):
+    """clc_desc_handle (include/coloc_hip.h): what a publication hands out"""
+    _fields_ = [("host", C.c_void_p), ("generation", C.c_uint64), ("count", C.c_uint32), ("slot", C.c_uint32)]
+
+
 class TwoViewJob(C.Structure):
     """clc_two_view_job (include/coloc_hip.h)"""
     _fields_ = [("x1", C.c_void_p), ("x2", C.c_void_p), ("K1", C.c_void_p), ("K2", C.c_void_p), ("n", C.c_int), ("img_w", C.c_int), ("img_h", C.c_int),
@@ -74,7 +79,7 @@ EXPORTS = [
     "clc_match_2nn", "clc_match_2nn_dev", "clc_match_jobs_dev", "clc_set_map", "clc_match_map",
     "clc_pnp_residuals", "clc_pnp_score", "clc_profile_enable", "clc_profile_reset", "clc_profile_read",
     "clc_kernel_name", "clc_detect", "clc_detect_dev", "clc_detect_buffers", "clc_describe_detected_dev",
-    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_describe_match_pair_dev", "clc_essential_acransac_batch", "clc_inter_pose_batch", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
+    "clc_detect_and_describe", "clc_detect_batch_dev", "clc_desc_cache_publish", "clc_desc_cache_clear", "clc_desc_cache_stats", "clc_desc_cache_mode", "clc_desc_handle_live", "clc_detect_and_describe_view", "clc_detect_store_descriptors", "clc_describe_match_pair_dev", "clc_essential_acransac_batch", "clc_inter_pose_batch", "clc_pnp_localize_ac_batch", "clc_match_pairs", "clc_pnp_ransac", "clc_pnp_p3p", "clc_pnp_refine", "clc_pnp_localize", "clc_epipolar_residuals", "clc_epipolar_score", "clc_cov_intersection", "clc_essential_ransac",
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_k2nn_device_info", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
@@ -145,7 +150,10 @@ def load_library():
     lib.clc_describe_dev.argtypes = [vp, vp, ci, vp, vp]
     lib.clc_describe_batch_dev.argtypes = [vp, ci, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, vp]
     lib.clc_detect_batch_dev.argtypes = [vp, ci, vp, C.c_uint32, C.c_uint32, C.c_size_t, vp, vp, vp, vp]
-    lib.clc_desc_cache_publish.argtypes = [vp, vp, vp, ci]
+    lib.clc_desc_cache_publish.argtypes = [vp, vp, vp, ci, vp]
+    lib.clc_desc_handle_live.argtypes = [vp]
+    lib.clc_detect_and_describe_view.argtypes = [vp, vp, u32, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci), C.POINTER(ci)]
+    lib.clc_detect_store_descriptors.argtypes = [vp, vp, ci, vp]
     lib.clc_desc_cache_clear.argtypes = []
     lib.clc_desc_cache_stats.argtypes = [vp, vp]
     lib.clc_desc_cache_mode.argtypes = [vp, ci]
@@ -410,6 +418,11 @@ def pnp_localize_batch(ctxs, problems, max_iteration=256, seeds=None, precision=
     return out
 
 
+def desc_handle_live(handle):
+    """1 while the publication the handle came from still stands (same host address, count and generation)."""
+    return bool(load_library().clc_desc_handle_live(C.byref(handle)))
+
+
 def desc_cache_stats():
     """(hits, misses) of the descriptor cache behind the host-pointer match entry points."""
     lib = load_library()
@@ -538,6 +551,21 @@ class Context:
                                                    C.byref(n), C.byref(found)))
         return kps[:n.value], desc[:n.value], found.value
 
+    def detect_and_describe_published(self, img):
+        """The policy classes' front end: clc_detect_and_describe_view (one enqueue sequence, one synchronisation, results in the
+        context's pinned block) + clc_detect_store_descriptors (the frame's one copy into the caller's block, published on the way).
+        Returns (keypoints, descriptors, found, DescHandle)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        pk, pd, n, found = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        self._chk(self.lib.clc_detect_and_describe_view(self.h, _p(img), img.shape[1], img.shape[0], C.byref(pk), C.byref(pd), C.byref(n), C.byref(found)))
+        kps = np.zeros(n.value, dtype=KP_DTYPE)
+        if n.value:
+            C.memmove(_p(kps), pk, n.value * 20)
+        desc = np.zeros((n.value, 64), dtype=np.uint8)
+        handle = DescHandle()
+        self._chk(self.lib.clc_detect_store_descriptors(self.h, _p(desc) if n.value else None, n.value, C.byref(handle)))
+        return kps, desc, found.value, handle
+
     def detect_batch_dev(self, d_imgs, width, height, pitch, d_kps, d_counts, d_desc=None, stream=None):
         """Frames of several cameras (lists of device pointers): one pyramid launch, two detector launches and (with d_desc) one
         CLATCH launch; d_kps[b] holds maxkp keypoints, d_counts[b] a uint32 pair {written, found}, d_desc[b] maxkp x 64 B."""
@@ -557,14 +585,16 @@ class Context:
         self._chk(self.lib.clc_describe_match_pair_dev(self.h, imgs, width, height, pitch, kps, cnt, out, int(threshold), d_match, stream))
 
     def desc_cache_mode(self, mode):
-        """clc_desc_cache_mode: "off" | "verify" (whole-block fold, default) | "trust" (address + count + 18 sampled rows)."""
+        """clc_desc_cache_mode: "off" | "verify" (default: sweep at once, whole-block fold behind it, edited blocks uploaded) | "trust"."""
         self._chk(self.lib.clc_desc_cache_mode(self.h, {"off": DESC_CACHE_OFF, "verify": DESC_CACHE_VERIFY, "trust": DESC_CACHE_TRUST}[mode]))
 
     def desc_cache_publish(self, h_desc, d_src=None):
         """The rows of numpy block h_desc (n x 64) are on this device at d_src (None: the context's own descriptor array, what
         detect_and_describe filled): later host-pointer match calls given this very block skip its upload."""
         assert h_desc.dtype == np.uint8 and h_desc.flags["C_CONTIGUOUS"]
-        self._chk(self.lib.clc_desc_cache_publish(self.h, d_src, _p(h_desc), int(h_desc.shape[0])))
+        handle = DescHandle()
+        self._chk(self.lib.clc_desc_cache_publish(self.h, d_src, _p(h_desc), int(h_desc.shape[0]), C.byref(handle)))
+        return handle
 
     # -- describe
     def describe(self, kps):

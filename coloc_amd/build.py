@@ -11,8 +11,9 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libcoloc_hip.so")
-SOURCES = ["capi.hip", "k2nn.hip", "clatch.hip", "lerp.hip", "pnp.hip", "detect.hip", "acransac.hip", "multicam.hip"]
-HEADERS = ["clc_internal.h", "clc_sincos.h", "clc_acr.h", "p3p.h", "fivept.h", "fivept_wave.h", "latch_pattern.inc", "latch_layout.inc", "latch_layout_swap.inc", os.path.join("..", "host", "HIPCovIntersection.hpp"), os.path.join("..", "host", "HIPRobustMatcher.hpp"), os.path.join("..", "host", "coloc_hip_geometry.hpp"), os.path.join("..", "..", "include", "coloc_hip.h")]
+SOURCES = ["capi_core.hip", "capi_match.hip", "desc_cache.hip", "capi_pose.hip", "pose_batch.hip", "inter_pose.hip", "inter_geometry.cpp",
+           "k2nn.hip", "clatch.hip", "lerp.hip", "pnp.hip", "detect.hip", "acransac.hip", "multicam.hip"]
+HEADERS = ["clc_internal.h", "clc_ctx.h", "desc_cache.h", "inter_geometry.h", "clc_sincos.h", "clc_acr.h", "p3p.h", "fivept.h", "fivept_wave.h", "latch_pattern.inc", "latch_layout.inc", "latch_layout_swap.inc", os.path.join("..", "host", "HIPCovIntersection.hpp"), os.path.join("..", "host", "HIPRobustMatcher.hpp"), os.path.join("..", "host", "coloc_hip_geometry.hpp"), os.path.join("..", "..", "include", "coloc_hip.h")]
 # -ffp-contract=off: the fp32 sample-coordinate / bilinear expressions and the fp64 residuals must
 # evaluate in source order without fused multiply-add.
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in plain VGPRs (gfx950's register file is unified), so the K2NN top-2 reads
@@ -56,10 +57,12 @@ def build(force=False, verbose=False):
     hdr_time = max(hdr_time, os.path.getmtime(os.path.abspath(__file__)))
     jobs = []
     for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         stale = force or extra or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(os.path.join(CSRC, src)), hdr_time)
         if stale:
-            jobs.append([hipcc] + CFLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj])
+            # (.cpp: host arithmetic only, compiled as plain C++ by the same driver)
+            flags = [f for f in CFLAGS if not f.startswith("--offload-arch") and f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")] if src.endswith(".cpp") else CFLAGS
+            jobs.append([hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj])
     if verbose:
         for j in jobs:
             print(" ".join(j))
@@ -67,7 +70,7 @@ def build(force=False, verbose=False):
     failed = [j for j, p in zip(jobs, procs) if p.wait() != 0]
     if failed:
         raise subprocess.CalledProcessError(1, failed[0])
-    link = [hipcc] + LDFLAGS + ["-o", LIB] + [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    link = [hipcc] + LDFLAGS + ["-o", LIB] + [os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link, cwd=CSRC)

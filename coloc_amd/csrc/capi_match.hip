@@ -1,0 +1,550 @@
+// capi_match.hip -- the matcher half of the C ABI (include/coloc_hip.h): planning and launching K2NN sweeps, the device-pointer and the
+// host-pointer match entry points.
+//
+// Host-side replacement for the CUDA-runtime plumbing of the reference's include/coloc/GPUMatcher.hpp (ctor :70-95, setMapData
+// :110-117, computeMatches :180-226, matchFeaturesWithMap :252-271): no texture object per call (:198-201), no +8-vector over-read
+// (:183-186), every HIP status checked.
+#include "clc_ctx.h"
+#include "desc_cache.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+using namespace clc;
+
+namespace clc {
+
+// matrix: 3 workgroups of 4 waves per CU (152 VGPRs) = ONE resident round; popcount: 10 workgroups of 8 waves per CU (measured optima);
+// per CU of the context's device (768 / 2560 on MI355X's 256)
+int default_target_blocks(int formulation, const K2nnDevice& dev) { return (int)((formulation == K2NN_POPCOUNT ? 10u : 3u) * dev.n_cu); }
+
+int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st, bool probe)
+{
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), (int)jobs.size(), target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b, ctx->k2dev);
+    const int rc = ensure_partial(ctx, plan.partial_elems);
+    if (rc != CLC_OK) return rc;
+    if (!plan.atomic_merge) ctx->partial_dirty = true;           // slab mode scribbles over the armed rows
+    else if (ctx->partial_dirty) {
+        CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
+        ctx->partial_dirty = false;
+    }
+    const hipError_t e = launch_k2nn(jobs.data(), (int)jobs.size(), ctx->d_partial, st, probe ? nullptr : &ctx->prof, ctx->formulation, nullptr, probe);
+    if (e != hipSuccess) { ctx->partial_dirty = true; return fail(ctx, CLC_ERR_HIP, "launch_k2nn", e); }
+    return CLC_OK;
+}
+
+
+// ---- which unequal shares suit THIS device (round 5) ---------------------------------------------------------------------------------
+// The share a slot-0 / slot-1 workgroup takes of a one-round sweep has an optimum that moves from device to device (19 : 17 ... 21 : 15
+// tiles of a 313-tile train set across the MI355X boxes of rounds 4-5: the chips hold different clocks under the sweep's load).  The first
+// matcher context a process creates on a device times the 10k x 10k sweep under four candidate pairs -- behind 4 ms of the same sweep, so
+// that the clocks are up -- and every later context on that device takes the winner.  ~15 ms once per process and device; results do not
+// depend on it (the fold is order-free).  CLC_K2NN_BIAS=a,b or CLC_K2NN_PROBE=0 skip it.
+__global__ void k2nn_probe_fill_kernel(uint32_t* p, const size_t n, const uint32_t salt)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i * 2654435761u + salt;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = x;
+}
+struct K2nnProbeCache { std::mutex mu; bool done[64] = {}; int a[64] = {}, b[64] = {}; float us[64][4] = {}; };
+static K2nnProbeCache& probe_cache() { static K2nnProbeCache c; return c; }
+static constexpr int kProbeCand[4][2] = { { 295, 264 }, { 311, 256 }, { 326, 249 }, { 326, 233 } };     // 19:17, 20:16.5, 21:16 (rounds 4's default), 21:15
+
+void k2nn_probe_bias(clc_ctx* ctx)
+{
+    const int N = 10000;
+    if (!ctx->has_mat || ctx->mopts.maxkp < (uint32_t)N || ctx->formulation == K2NN_POPCOUNT || ctx->device < 0 || ctx->device >= 64) return;
+    if (ctx->k2dev.n_xcd != kK2nnXcds || ctx->target_blocks > 0) return;
+    if (const char* e = getenv("CLC_K2NN_PROBE")) if (e[0] == '0') return;
+    K2nnProbeCache& pc = probe_cache();
+    std::lock_guard<std::mutex> lk(pc.mu);
+    const int d = ctx->device;
+    if (!pc.done[d]) {
+        pc.done[d] = true; pc.a[d] = ctx->bias_a; pc.b[d] = ctx->bias_b;             // whatever happens below: probe once
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { if (e0) (void)hipEventDestroy(e0); return; }
+        const size_t words = (size_t)N * CLC_DESC_BYTES / 4;
+        hipLaunchKernelGGL(k2nn_probe_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->d_q, words, 1u);
+        hipLaunchKernelGGL(k2nn_probe_fill_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)ctx->d_t, words, 2u);
+        std::vector<K2nnJobDev> jobs(1);
+        auto sweep = [&](const int a, const int b, const int reps) -> bool {
+            const int sa = ctx->bias_a, sb = ctx->bias_b;
+            ctx->bias_a = a; ctx->bias_b = b;
+            bool ok = true;
+            for (int r = 0; r < reps && ok; ++r) {
+                jobs[0] = K2nnJobDev{};
+                jobs[0].q = (const uint4*)ctx->d_q; jobs[0].t = (const uint4*)ctx->d_t; jobs[0].out = ctx->d_match;
+                jobs[0].nq = (uint32_t)N; jobs[0].nt = (uint32_t)N; jobs[0].thr = 40u;
+                ok = run_jobs(ctx, jobs, ctx->stream, true) == CLC_OK;
+            }
+            ctx->bias_a = sa; ctx->bias_b = sb;
+            return ok;
+        };
+        bool ok = sweep(ctx->bias_a, ctx->bias_b, 160);                                  // ~4 ms: clocks up
+        float best = 0.f; int best_i = -1;
+        for (int pass = 0; pass < 2 && ok; ++pass)                                        // two interleaved passes, the smaller time counts
+            for (int c = 0; c < 4 && ok; ++c) {
+                ok = hipEventRecord(e0, ctx->stream) == hipSuccess && sweep(kProbeCand[c][0], kProbeCand[c][1], 40) && hipEventRecord(e1, ctx->stream) == hipSuccess &&
+                     hipEventSynchronize(e1) == hipSuccess;
+                float ms = 0.f;
+                if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) {
+                    const float us = ms * 1000.f / 40.f;
+                    if (pc.us[d][c] == 0.f || us < pc.us[d][c]) pc.us[d][c] = us;
+                }
+            }
+        if (ok)
+            for (int c = 0; c < 4; ++c) if (pc.us[d][c] > 0.f && (best_i < 0 || pc.us[d][c] < best)) { best = pc.us[d][c]; best_i = c; }
+        // the winner must beat rounds 4's default by more than the noise of such a short measurement (1 %), else the default stays
+        if (ok && best_i >= 0 && pc.us[d][2] > 0.f && best < 0.99f * pc.us[d][2]) { pc.a[d] = kProbeCand[best_i][0]; pc.b[d] = kProbeCand[best_i][1]; }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (!ok) { ctx->partial_dirty = true; for (int c = 0; c < 4; ++c) pc.us[d][c] = 0.f; }
+    }
+    ctx->bias_a = pc.a[d]; ctx->bias_b = pc.b[d];
+    for (int c = 0; c < 4; ++c) ctx->bias_probe_us[c] = pc.us[d][c];
+    if (pc.us[d][0] > 0.f) ctx->bias_source = 2;
+}
+
+
+} // namespace clc
+
+extern "C" {
+
+int clc_k2nn_set_formulation(clc_ctx* ctx, int formulation)
+{
+    if (!ctx || (formulation != CLC_K2NN_MATRIX && formulation != CLC_K2NN_POPCOUNT))
+        return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_set_formulation: bad argument");
+    ctx->formulation = formulation == CLC_K2NN_POPCOUNT ? K2NN_POPCOUNT : K2NN_MATRIX;
+    return CLC_OK;
+}
+
+int clc_k2nn_queries_per_block(const clc_ctx* ctx)
+{
+    return k2nn_queries_per_block(ctx ? ctx->formulation : K2NN_MATRIX);
+}
+
+int clc_k2nn_plan_query(const clc_ctx* ctx, int nq, int nt, int32_t* info)
+{
+    if (!ctx || nq < 0 || nt < 0 || !info) return CLC_ERR_BAD_ARG;
+    K2nnJobDev jb{};
+    jb.nq = (uint32_t)nq; jb.nt = (uint32_t)nt;
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev);
+    const K2nnPlan plan = k2nn_plan(&jb, 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b, ctx->k2dev);
+    info[0] = (int32_t)jb.qblocks; info[1] = (int32_t)jb.splits; info[2] = (int32_t)jb.t_per_split; info[3] = plan.atomic_merge ? 1 : 0;
+    info[4] = (int32_t)jb.bias_a; info[5] = (int32_t)jb.bias_b; info[6] = k2nn_queries_per_block(ctx->formulation); info[7] = target;
+    return CLC_OK;
+}
+
+int clc_k2nn_device_info(const clc_ctx* ctx, int32_t* info, float* probe_us)
+{
+    if (!ctx || !info) return CLC_ERR_BAD_ARG;
+    info[0] = (int32_t)ctx->k2dev.n_xcd; info[1] = (int32_t)ctx->k2dev.n_cu; info[2] = default_target_blocks(ctx->formulation, ctx->k2dev);
+    info[3] = ctx->bias_a; info[4] = ctx->bias_b; info[5] = ctx->bias_source; info[6] = (int32_t)kK2nnXcds; info[7] = ctx->target_blocks;
+    if (probe_us) for (int c = 0; c < 4; ++c) probe_us[c] = ctx->bias_probe_us[c];
+    return CLC_OK;
+}
+
+int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int32_t* d_match, void* stream,
+                         double* ghz_median, double* ghz_min, double* ghz_max, int* workgroups)
+{
+    if (!ctx || nq <= 0 || nt <= 0 || !d_q || !d_t || !d_match) return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_clock_check: bad argument");
+    if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 15u)) return fail(ctx, CLC_ERR_BAD_ARG, "k2nn_clock_check: misaligned device pointer");
+    if (ctx->formulation == K2NN_POPCOUNT) return fail(ctx, CLC_ERR_STATE, "k2nn_clock_check: matrix formulation only");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    std::vector<K2nnJobDev> jobs(1);
+    jobs[0] = K2nnJobDev{};
+    jobs[0].q = (const uint4*)d_q; jobs[0].t = (const uint4*)d_t; jobs[0].out = d_match;
+    jobs[0].nq = (uint32_t)nq; jobs[0].nt = (uint32_t)nt; jobs[0].thr = 40u;
+    const int target = ctx->target_blocks > 0 ? ctx->target_blocks : default_target_blocks(ctx->formulation, ctx->k2dev);
+    const K2nnPlan plan = k2nn_plan(jobs.data(), 1, target, ctx->xcd_map, ctx->formulation, ctx->bias_a, ctx->bias_b, ctx->k2dev);
+    if (!plan.atomic_merge) return fail(ctx, CLC_ERR_CAPACITY, "k2nn_clock_check: train set too large");
+    int rc = ensure_partial(ctx, plan.partial_elems);
+    if (rc != CLC_OK) return rc;
+    if (ctx->partial_dirty) {
+        CLC_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0xFF, ctx->partial_cap * sizeof(uint2), st));
+        ctx->partial_dirty = false;
+    }
+    // the launch grid pads the query blocks to a multiple of 8 (XCD-dealt order, k2nn.hip) and a stamped workgroup
+    // writes row blockIdx.y * gridDim.x + blockIdx.x: size the buffer for the PADDED grid (rows of padding workgroups
+    // stay zero and are skipped below)
+    const size_t nwg = (size_t)((jobs[0].qblocks + 7u) & ~7u) * jobs[0].splits;
+    uint64_t* d_stamps = nullptr;
+    CLC_HIP(ctx, hipMalloc((void**)&d_stamps, nwg * 8 * sizeof(uint64_t)));
+    std::vector<uint64_t> h(nwg * 8);
+    hipError_t e = hipMemsetAsync(d_stamps, 0, nwg * 8 * sizeof(uint64_t), st);
+    if (e == hipSuccess) e = launch_k2nn(jobs.data(), 1, ctx->d_partial, st, nullptr, ctx->formulation, d_stamps);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_stamps, nwg * 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_stamps);
+    if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "k2nn_clock_check", e);
+    if (const char* dump = getenv("CLC_K2NN_STAMP_DUMP")) {            // diagnostic: raw per-workgroup stamps for tools/k2nn_timeline.py
+        if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), sizeof(uint64_t), h.size(), f); fclose(f); }
+    }
+    std::vector<double> ghz;
+    for (size_t w = 0; w < nwg; ++w) {
+        const uint64_t dc = h[8 * w + 2] - h[8 * w], dr = h[8 * w + 3] - h[8 * w + 1];
+        if (dr > 20) ghz.push_back((double)dc / (double)dr * 0.1);       // s_memrealtime ticks at 100 MHz
+    }
+    if (ghz.empty()) return fail(ctx, CLC_ERR_STATE, "k2nn_clock_check: sweep too short to stamp");
+    std::sort(ghz.begin(), ghz.end());
+    if (ghz_median) *ghz_median = ghz[ghz.size() / 2];
+    if (ghz_min) *ghz_min = ghz.front();
+    if (ghz_max) *ghz_max = ghz.back();
+    if (workgroups) *workgroups = (int)ghz.size();
+    return CLC_OK;
+}
+
+int clc_match_2nn_dev(clc_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int threshold,
+                      int32_t* d_match, void* stream)
+{
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!d_q || !d_match)) || (nt > 0 && !d_t))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_2nn: bad argument");
+    if (((uintptr_t)d_q & 15u) || ((uintptr_t)d_t & 15u) || ((uintptr_t)d_match & 3u))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_2nn: device pointers must be 16-byte aligned");
+    if (nq == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<K2nnJobDev> jobs(1);
+    jobs[0] = K2nnJobDev{};
+    jobs[0].q = (const uint4*)d_q;
+    jobs[0].t = (const uint4*)d_t;
+    jobs[0].out = d_match;
+    jobs[0].nq = (uint32_t)nq;
+    jobs[0].nt = (uint32_t)nt;
+    jobs[0].thr = (uint32_t)(uint8_t)threshold;   // CUDAK2NN.cu:46: the kernel parameter is uint8_t
+    return run_jobs(ctx, jobs, pick(ctx, stream));
+}
+
+/* ---- describe both cameras of a pair and match them, as ONE step ------------------------------------------------------------
+ * The reference's call pattern for a pair is detectAndDescribe of each camera (GPUDetector.hpp:216-291) and then
+ * computeMatchesPair (GPUMatcher.hpp:165-172, :180-226).  Here: one pyramid launch and one CLATCH launch for both cameras, one sweep
+ * launch, on the caller's stream.  (Round 5 also shipped a chunked form -- sweeps over finished chunks of the query camera on a
+ * second stream behind one-wave gates that polled the describe launch's progress counters; it measured slower at every chunking
+ * on MI355X and is gone: profiles/r05_step_overlap.txt, profiles/r06_removed_variants.patch.) */
+int clc_describe_match_pair_dev(clc_ctx* ctx, const void* const* d_imgs, uint32_t width, uint32_t height, size_t pitch,
+                                const clc_keypoint* const* d_kps, const int* counts, void* const* d_desc, int threshold,
+                                int32_t* d_match, void* stream)
+{
+    if (!ctx || !d_imgs || !d_kps || !counts || !d_desc || !d_imgs[0] || !d_imgs[1] || counts[0] < 0 || counts[1] < 0 ||
+        (counts[0] > 0 && (!d_kps[0] || !d_desc[0] || !d_match)) || (counts[1] > 0 && (!d_kps[1] || !d_desc[1])))
+        return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: bad argument");
+    if (!ctx->has_det) return fail(ctx, CLC_ERR_STATE, "describe_match_pair: context created without detector options");
+    if (width != ctx->dopts.width || height != ctx->dopts.height || pitch < width || pitch > 0xFFFFFFFFull)
+        return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: image size differs from DetectorOptions width/height");
+    for (int b = 0; b < 2; ++b)
+        if (((uintptr_t)d_desc[b] & 15u) || ((uintptr_t)d_kps[b] & 3u)) return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: misaligned device pointer");
+    if ((uintptr_t)d_match & 3u) return fail(ctx, CLC_ERR_BAD_ARG, "describe_match_pair: misaligned device pointer");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    { const int rc = ensure_slots(ctx, 2, st); if (rc != CLC_OK) return rc; }
+    // pyramid slot 0 = the TRAIN camera (camera 1 of the pair), slot 1 = the query camera: the describe launch dispatches slot 0 first
+    const uint8_t* srcs[2] = { (const uint8_t*)d_imgs[1], (const uint8_t*)d_imgs[0] };
+    ClatchBatch batch{};
+    batch.kps[0] = d_kps[1]; batch.desc[0] = (uint64_t*)d_desc[1]; batch.n[0] = counts[1];
+    batch.kps[1] = d_kps[0]; batch.desc[1] = (uint64_t*)d_desc[0]; batch.n[1] = counts[0];
+    ctx->pyramid_valid = false;
+    CLC_HIP(ctx, launch_pyramid_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, srcs, 2, (uint32_t)pitch, st, &ctx->prof));
+    ctx->pyramid_valid = true;
+    CLC_HIP(ctx, launch_clatch_batch(ctx->pd, ctx->d_arena, ctx->arena_bytes, batch, 2, st, &ctx->prof));
+    if (counts[0] == 0) return CLC_OK;
+    std::vector<K2nnJobDev> jobs(1);
+    jobs[0] = K2nnJobDev{};
+    jobs[0].q = (const uint4*)d_desc[0]; jobs[0].t = (const uint4*)d_desc[1]; jobs[0].out = d_match;
+    jobs[0].nq = (uint32_t)counts[0]; jobs[0].nt = (uint32_t)counts[1]; jobs[0].thr = (uint32_t)(uint8_t)threshold;
+    return run_jobs(ctx, jobs, st);
+}
+
+int clc_match_jobs_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs, int njobs,
+                       int32_t* d_match, void* stream)
+{
+    if (!ctx || njobs < 0 || (njobs > 0 && (!d_desc_base || !h_jobs || !d_match)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs: bad argument");
+    if (((uintptr_t)d_desc_base & 15u) || ((uintptr_t)d_match & 3u))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs: device pointers must be 16-byte aligned");
+    if (njobs == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<K2nnJobDev> jobs;
+    jobs.reserve(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        if (h_jobs[j].nq == 0) continue;
+        K2nnJobDev jb{};
+        jb.q = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].q_offset * CLC_DESC_BYTES);
+        jb.t = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].t_offset * CLC_DESC_BYTES);
+        jb.out = d_match + h_jobs[j].out_offset;
+        jb.nq = h_jobs[j].nq;
+        jb.nt = h_jobs[j].nt;
+        jb.thr = (uint32_t)(uint8_t)h_jobs[j].threshold;
+        jobs.push_back(jb);
+    }
+    if (jobs.empty()) return CLC_OK;
+    return run_jobs(ctx, jobs, pick(ctx, stream));
+}
+
+int clc_match_jobs_counted_dev(clc_ctx* ctx, const void* d_desc_base, const clc_match_job* h_jobs, int njobs,
+                               const int32_t* const* d_cnt_q, const int32_t* const* d_cnt_t, const uint32_t* q_row0,
+                               int32_t* d_match, void* stream)
+{
+    if (!ctx || njobs < 0 || (njobs > 0 && (!d_desc_base || !h_jobs || !d_match || !d_cnt_q || !d_cnt_t || !q_row0)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs_counted: bad argument");
+    if (((uintptr_t)d_desc_base & 15u) || ((uintptr_t)d_match & 3u))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs_counted: device pointers must be 16-byte aligned");
+    if (njobs == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<K2nnJobDev> jobs;
+    jobs.reserve(njobs);
+    for (int j = 0; j < njobs; ++j) {
+        if (h_jobs[j].nq == 0) continue;
+        // a planned train set of zero rows can hold nothing whatever the device count says; the sweep needs at least one split to
+        // answer the planned rows, so such a job is run with one (empty) planned row -- the count clamps it to zero again
+        if (!d_cnt_q[j] || !d_cnt_t[j]) return fail(ctx, CLC_ERR_BAD_ARG, "match_jobs_counted: null count pointer");
+        K2nnJobDev jb{};
+        jb.q = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].q_offset * CLC_DESC_BYTES);
+        jb.t = (const uint4*)((const uint8_t*)d_desc_base + (size_t)h_jobs[j].t_offset * CLC_DESC_BYTES);
+        jb.out = d_match + h_jobs[j].out_offset;
+        jb.nq = h_jobs[j].nq;
+        jb.nt = h_jobs[j].nt ? h_jobs[j].nt : 1u;
+        jb.thr = (uint32_t)(uint8_t)h_jobs[j].threshold;
+        jb.cnt_q = d_cnt_q[j]; jb.cnt_t = d_cnt_t[j]; jb.q_row0 = q_row0[j];
+        jobs.push_back(jb);
+    }
+    if (jobs.empty()) return CLC_OK;
+    return run_jobs(ctx, jobs, pick(ctx, stream));
+}
+
+/* ---- host-pointer match entry points ---------------------------------------------------------------------------------------
+ * GPUMatcher::computeMatches (GPUMatcher.hpp:180-226) uploads both descriptor sets in every call.  Here a set that the front end has
+ * published (desc_cache.h) is read where it already lies on the device.  Under the VERIFY mode -- the default -- that is optimistic:
+ * the sweep is enqueued on the device rows at once, and WHILE it runs the host folds the block it was handed and compares it with the
+ * fold taken at publish time; a block that has been edited anywhere since is uploaded and the sweep repeated, so the answer is always
+ * the one for the rows the caller passed.  Results come back through a pinned mirror (a copy into pageable memory would keep the host
+ * in the runtime instead of in the fold). */
+} // extern "C"
+
+namespace {
+
+struct HostSet {
+    const void* h = nullptr;      // the caller's block
+    int n = 0;
+    uint8_t* d_upload = nullptr;  // where it goes on the device when it has to be uploaded
+    const uint8_t* d = nullptr;   // where the sweep reads it
+    DescEntry* held = nullptr;
+    bool verify = false;
+    bool resident = false;        // already on the device at d (the map database): nothing to resolve
+};
+
+// device rows of a host set: the published block if one stands for it, else an upload (enqueued)
+int resolve(clc_ctx* ctx, HostSet& s)
+{
+    s.held = nullptr; s.verify = false;
+    if (s.resident) return CLC_OK;
+    s.d = nullptr;
+    if (s.n <= 0) { s.d = s.d_upload; return CLC_OK; }
+    s.d = desc_acquire(ctx->cache_mode, ctx->device, s.h, s.n, &s.held, &s.verify);
+    if (s.d) return CLC_OK;
+    const hipError_t e = hipMemcpyAsync(s.d_upload, s.h, (size_t)s.n * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "match: descriptor upload", e);
+    s.d = s.d_upload;
+    return CLC_OK;
+}
+// after the device work is enqueued: fold what has to be verified.  true: every set read on the device is the caller's rows;
+// false: at least one was not -- it has been uploaded (enqueued) and the device work must be repeated
+int verify_sets(clc_ctx* ctx, HostSet* sets, int n_sets, bool* all_good)
+{
+    *all_good = true;
+    for (int i = 0; i < n_sets; ++i) {
+        HostSet& s = sets[i];
+        if (!s.verify) continue;
+        s.verify = false;
+        if (desc_verify(s.held, s.h, s.n)) continue;
+        *all_good = false;
+        desc_release(s.held);
+        s.held = nullptr;
+        // (behind the sweep that read the stale rows, on the same stream: the upload buffer is not read by that sweep)
+        const hipError_t e = hipMemcpyAsync(s.d_upload, s.h, (size_t)s.n * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "match: descriptor upload", e);
+        s.d = s.d_upload;
+    }
+    return CLC_OK;
+}
+void release_sets(HostSet* sets, int n_sets)
+{
+    for (int i = 0; i < n_sets; ++i) { desc_release(sets[i].held); sets[i].held = nullptr; }
+}
+
+// one query set against one train set, both resolved; results into the caller's arrays
+int match_host(clc_ctx* ctx, HostSet& q, HostSet& t, int threshold, int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
+{
+    const size_t nq = (size_t)q.n;
+    const size_t off_best = nq * sizeof(int32_t), off_second = off_best + nq * sizeof(uint16_t);
+    int rc = ensure_results(ctx, off_second + nq * sizeof(uint16_t) + 64);
+    if (rc != CLC_OK) return rc;
+    HostSet* sets[2] = { &q, &t };
+    for (HostSet* s : sets) { rc = resolve(ctx, *s); if (rc != CLC_OK) { release_sets(&q, 1); release_sets(&t, 1); return rc; } }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        std::vector<K2nnJobDev> jobs(1);
+        jobs[0] = K2nnJobDev{};
+        jobs[0].q = (const uint4*)q.d;
+        jobs[0].t = (const uint4*)t.d;
+        jobs[0].out = ctx->d_match;
+        jobs[0].best_out = h_best ? ctx->d_best : nullptr;
+        jobs[0].second_out = h_second ? ctx->d_second : nullptr;
+        jobs[0].nq = (uint32_t)q.n;
+        jobs[0].nt = (uint32_t)t.n;
+        jobs[0].thr = (uint32_t)(uint8_t)threshold;
+        rc = run_jobs(ctx, jobs, ctx->stream);
+        hipError_t e = hipSuccess;
+        if (rc == CLC_OK) e = hipMemcpyAsync(ctx->h_res, ctx->d_match, nq * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (rc == CLC_OK && e == hipSuccess && h_best) e = hipMemcpyAsync(ctx->h_res + off_best, ctx->d_best, nq * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (rc == CLC_OK && e == hipSuccess && h_second) e = hipMemcpyAsync(ctx->h_res + off_second, ctx->d_second, nq * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (rc == CLC_OK && e != hipSuccess) rc = fail(ctx, CLC_ERR_HIP, "match: result download", e);
+        // the GPU is sweeping: now the pass over the host blocks that stand on published rows
+        bool good = true;
+        if (rc == CLC_OK) { rc = verify_sets(ctx, &q, 1, &good); bool g2 = true; if (rc == CLC_OK) rc = verify_sets(ctx, &t, 1, &g2); good = good && g2; }
+        if (rc == CLC_OK) { e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = fail(ctx, CLC_ERR_HIP, "hipStreamSynchronize", e); }
+        if (rc != CLC_OK || good) break;
+    }
+    release_sets(&q, 1); release_sets(&t, 1);
+    if (rc != CLC_OK) return rc;
+    memcpy(h_match, ctx->h_res, nq * sizeof(int32_t));
+    if (h_best) memcpy(h_best, ctx->h_res + off_best, nq * sizeof(uint16_t));
+    if (h_second) memcpy(h_second, ctx->h_res + off_second, nq * sizeof(uint16_t));
+    return CLC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt, int threshold,
+                  int32_t* h_match, uint16_t* h_best, uint16_t* h_second)
+{
+    if (!ctx || nq < 0 || nt < 0 || (nq > 0 && (!h_q || !h_match)) || (nt > 0 && !h_t))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_2nn: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "match_2nn: context created without matcher options");
+    if ((uint32_t)nq > ctx->mopts.maxkp || (uint32_t)nt > ctx->mopts.maxkp)
+        return fail(ctx, CLC_ERR_CAPACITY, "match_2nn: more descriptors than MatcherOptions.maxkp");
+    if (nq == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    HostSet q, t;
+    q.h = h_q; q.n = nq; q.d_upload = ctx->d_q;
+    t.h = h_t; t.n = nt; t.d_upload = ctx->d_t;
+    return match_host(ctx, q, t, threshold, h_match, h_best, h_second);
+}
+
+int clc_match_pairs(clc_ctx* ctx, const void* const* h_desc, const int* counts, int ncams, const int* pairs,
+                    int npairs, int threshold, int32_t* const* h_match)
+{
+    if (!ctx || ncams < 0 || npairs < 0 || (ncams > 0 && (!h_desc || !counts)) || (npairs > 0 && (!pairs || !h_match)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "match_pairs: bad argument");
+    if (npairs == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<size_t> cam_off(ncams + 1, 0);
+    for (int c = 0; c < ncams; ++c) {
+        if (counts[c] < 0 || (counts[c] > 0 && !h_desc[c])) return fail(ctx, CLC_ERR_BAD_ARG, "match_pairs: bad camera entry");
+        cam_off[c + 1] = cam_off[c] + (size_t)counts[c];
+    }
+    size_t out_rows = 0;
+    for (int p = 0; p < npairs; ++p) {
+        const int a = pairs[2 * p], b = pairs[2 * p + 1];
+        if (a < 0 || a >= ncams || b < 0 || b >= ncams || (counts[a] > 0 && !h_match[p]))
+            return fail(ctx, CLC_ERR_BAD_ARG, "match_pairs: bad pair entry");
+        out_rows += (size_t)counts[a];
+    }
+    const size_t desc_bytes = cam_off[ncams] * CLC_DESC_BYTES;
+    const size_t need = desc_bytes + out_rows * sizeof(int32_t) + 256;
+    if (need > ctx->pairs_cap) {
+        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_pairs) CLC_HIP(ctx, hipFree(ctx->d_pairs));
+        ctx->d_pairs = nullptr; ctx->pairs_cap = 0;
+        CLC_HIP(ctx, hipMalloc((void**)&ctx->d_pairs, need));
+        ctx->pairs_cap = need;
+    }
+    { const int rc = ensure_results(ctx, out_rows * sizeof(int32_t) + 64); if (rc != CLC_OK) return rc; }
+    // a camera whose block the front end published on this device is read where it lies; the others are uploaded
+    std::vector<HostSet> cams((size_t)ncams);
+    struct Release { std::vector<HostSet>& s; ~Release() { release_sets(s.data(), (int)s.size()); } } release{ cams };
+    for (int c = 0; c < ncams; ++c) {
+        HostSet& s = cams[(size_t)c];
+        s.h = h_desc[c]; s.n = counts[c]; s.d_upload = ctx->d_pairs + cam_off[c] * CLC_DESC_BYTES;
+        if (s.n <= 0) { s.d = ctx->d_pairs; continue; }
+        const int rc = resolve(ctx, s);
+        if (rc != CLC_OK) return rc;
+    }
+    int32_t* d_out = (int32_t*)(ctx->d_pairs + ((desc_bytes + 255) & ~(size_t)255));
+    std::vector<size_t> out_off(npairs, 0);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        std::vector<K2nnJobDev> jobs;
+        size_t o = 0;
+        for (int p = 0; p < npairs; ++p) {
+            const int a = pairs[2 * p], b = pairs[2 * p + 1];
+            out_off[p] = o;
+            if (counts[a] == 0) continue;
+            K2nnJobDev jb{};
+            jb.q = (const uint4*)cams[(size_t)a].d;
+            jb.t = (const uint4*)cams[(size_t)b].d;
+            jb.out = d_out + o;
+            jb.nq = (uint32_t)counts[a];
+            jb.nt = (uint32_t)counts[b];
+            jb.thr = (uint32_t)(uint8_t)threshold;
+            jobs.push_back(jb);
+            o += (size_t)counts[a];
+        }
+        if (!jobs.empty()) {
+            const int rc = run_jobs(ctx, jobs, ctx->stream);
+            if (rc != CLC_OK) return rc;
+        }
+        if (out_rows) CLC_HIP(ctx, hipMemcpyAsync(ctx->h_res, d_out, out_rows * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        bool good = true;
+        { const int rc = verify_sets(ctx, cams.data(), ncams, &good); if (rc != CLC_OK) return rc; }
+        CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (good) break;
+    }
+    for (int p = 0; p < npairs; ++p) {
+        const int a = pairs[2 * p];
+        if (counts[a] > 0) memcpy(h_match[p], ctx->h_res + out_off[p] * sizeof(int32_t), (size_t)counts[a] * sizeof(int32_t));
+    }
+    return CLC_OK;
+}
+
+int clc_set_map(clc_ctx* ctx, const void* h_desc, int n)
+{
+    if (!ctx || n < 0 || (n > 0 && !h_desc)) return fail(ctx, CLC_ERR_BAD_ARG, "set_map: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "set_map: context created without matcher options");
+    if ((uint32_t)n > ctx->mopts.maxkp) return fail(ctx, CLC_ERR_CAPACITY, "set_map: more descriptors than MatcherOptions.maxkp");
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    if (n > 0) CLC_HIP(ctx, hipMemcpyAsync(ctx->d_m, h_desc, (size_t)n * CLC_DESC_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->map_n = n;
+    return CLC_OK;
+}
+
+int clc_match_map(clc_ctx* ctx, const void* h_q, int nq, int threshold, int32_t* h_match)
+{
+    if (!ctx || nq < 0 || (nq > 0 && (!h_q || !h_match))) return fail(ctx, CLC_ERR_BAD_ARG, "match_map: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "match_map: context created without matcher options");
+    if (ctx->map_n < 0) return fail(ctx, CLC_ERR_STATE, "match_map before set_map");
+    if ((uint32_t)nq > ctx->mopts.maxkp) return fail(ctx, CLC_ERR_CAPACITY, "match_map: more descriptors than MatcherOptions.maxkp");
+    if (nq == 0) return CLC_OK;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    HostSet q, t;
+    q.h = h_q; q.n = nq; q.d_upload = ctx->d_q;
+    t.resident = true; t.d = ctx->d_m; t.n = ctx->map_n;      // the map is on the device already (clc_set_map)
+    return match_host(ctx, q, t, threshold, h_match, nullptr, nullptr);
+}
+
+int clc_match_map_dev(clc_ctx* ctx, const void* d_q, int nq, int threshold, int32_t* d_match, void* stream)
+{
+    if (!ctx || nq < 0 || (nq > 0 && (!d_q || !d_match))) return fail(ctx, CLC_ERR_BAD_ARG, "match_map_dev: bad argument");
+    if (!ctx->has_mat) return fail(ctx, CLC_ERR_STATE, "match_map_dev: context created without matcher options");
+    if (ctx->map_n < 0) return fail(ctx, CLC_ERR_STATE, "match_map_dev before set_map");
+    return clc_match_2nn_dev(ctx, d_q, nq, ctx->d_m, ctx->map_n, threshold, d_match, stream);
+}
+
+} // extern "C"

@@ -11,8 +11,10 @@
 // raw descriptor bytes (:181).
 // What differs underneath: the whole of detectAndDescribe (:216-291) -- pyramid, FAST-9 + NMS +
 // orientation on every level, CLATCH -- runs on the GPU in one enqueue sequence with a single
-// host synchronisation; the reference copies 7 levels back, runs KFAST on the CPU and synchronises
-// 8 + 3 times per frame.
+// host synchronisation (clc_detect_and_describe_view: the frame goes in and out through one pinned
+// block of the context); the reference copies 7 levels back, runs KFAST on the CPU and synchronises
+// 8 + 3 times per frame.  The descriptors are copied ONCE into regions[idx] (and once into the
+// public `desc`, which callers read: InterfaceROS.hpp:30,37; mirrorRawOutputs(false) drops that copy).
 #pragma once
 
 #include <cmath>
@@ -89,11 +91,13 @@ public:
             std::cerr << "HIPDetector: clc_ctx_create failed: " << clc_status_string(rc) << std::endl;
             ctx_ = nullptr;
         }
-        // the library a host was LINKED against and the header it was COMPILED against must agree (the surface grew in
-        // rounds 4 and 5 under one version number); a mismatch is reported, the calls that exist in both still work
+        // the library a host was LINKED against and the header it was COMPILED against must agree; a mismatch is reported, the calls
+        // that exist in both still work
         if (clc_abi_version() != CLC_ABI_VERSION)
             std::cerr << "HIPDetector: libcoloc_hip reports ABI version " << clc_abi_version() << ", this header was written for " << CLC_ABI_VERSION << std::endl;
-        trustPublishedRegions(true);
+        // GPUDetector.hpp:173: static_cast<float>(std::pow(1.2f, kps[i].scale)) -- one pow per LEVEL here, the same call with the
+        // same arguments (pow(float, integer) is evaluated in double)
+        for (int l = 0; l < 256; ++l) levelScale_[l] = static_cast<float>(std::pow(static_cast<double>(1.2f), static_cast<double>(l)));
     }
     HIPDetector(const HIPDetector&) = delete;
     HIPDetector& operator=(const HIPDetector&) = delete;
@@ -105,15 +109,22 @@ public:
         ctx_ = nullptr;
     }
 
-    // The descriptor block this detector stores in regions[idx] is published to the matcher without a second upload (below).  true (the
-    // default of the policy classes): the block is published for TRUSTING lookups -- the statement that nobody rewrites a stored
-    // regions block in place, which holds for the reference's flow (only the detectors write Descriptors(): GPUDetector.hpp:181,210,
-    // AKAZE.hpp:67).  false: it is published with a fold of all its rows, and a HIPMatcher switched the same way re-checks the whole
-    // block on every call (include/coloc_hip.h, clc_desc_cache_mode).
-    void trustPublishedRegions(bool on)
+    // The descriptor block this detector stores in regions[idx] is handed to the matcher without a second upload: the rows stay on the
+    // device in a block this detector's context owns, and storing them in regions[idx] publishes {address, count, generation} together
+    // with a fold of all rows (clc_detect_store_descriptors).  A HIPMatcher call that is handed regions[idx]->DescriptorRawData() sweeps
+    // the device rows at once and folds the host block behind the sweep: rows edited in place since are uploaded and matched as edited
+    // (include/coloc_hip.h, clc_desc_cache_mode).  publishRegions(false): nothing is published, every match call uploads (the
+    // reference's behaviour, GPUMatcher.hpp:188-196).  The publication of a frame dies when the next frame of the same idx is stored
+    // at the same address, with freeGPUMemory(), or when a lookup sees changed rows.
+    void publishRegions(bool on)
     {
-        if (ctx_) (void)clc_desc_cache_mode(ctx_, on ? CLC_DESC_CACHE_TRUST : CLC_DESC_CACHE_VERIFY);
+        if (ctx_) (void)clc_desc_cache_mode(ctx_, on ? CLC_DESC_CACHE_VERIFY : CLC_DESC_CACHE_OFF);
     }
+    // Callers of the reference read the public `kps` / `desc` after a detect call (InterfaceROS.hpp:30,37).  A host that only uses
+    // regions[idx] can switch the second descriptor copy off; `kps` is always filled.
+    void mirrorRawOutputs(bool on) { mirrorDesc_ = on; }
+    // the handle of the block published by the last detect call (host == nullptr: nothing was published)
+    const clc_desc_handle& lastPublished() const { return published_; }
 
     // Process an image read from disk (GPUDetector.hpp:158-184).
     T detectFeaturesFile(uint8_t idx, coloc::FeatureMap& regions, std::string& imageName)
@@ -137,21 +148,46 @@ public:
     // Same from a grey image already in host memory (what detectFeaturesTopic hands over, :188-212).
     T detectFeaturesImage(uint8_t idx, coloc::FeatureMap& regions, const uint8_t* image, int width, int height)
     {
-        if (!detectAndDescribe(image, static_cast<uint32_t>(width), static_cast<uint32_t>(height))) return EXIT_FAILURE;
-        receivedImg = true;
-        regions[idx] = std::unique_ptr<openMVG::features::AKAZE_Binary_Regions>(new openMVG::features::AKAZE_Binary_Regions);
-        regions[idx]->Features().resize(kps.size());
-        regions[idx]->Descriptors().resize(kps.size());
-        std::vector<float> feat(4 * kps.size());
-        clc_keypoints_to_features(reinterpret_cast<const clc_keypoint*>(kps.data()), static_cast<int>(kps.size()), feat.data());
-        for (size_t i = 0; i < kps.size(); ++i) {
-            regions[idx]->Features()[i] = { feat[4 * i], feat[4 * i + 1], feat[4 * i + 2], feat[4 * i + 3] };
-            std::memcpy(&(regions[idx]->Descriptors()[i]), &(desc[i * 8]), 8 * sizeof(uint64_t));
+        kps.clear();
+        desc.clear();
+        published_ = clc_desc_handle{};
+        if (!ctx_) return EXIT_FAILURE;
+        // GPUDetector::detectAndDescribe (:216-291) as ONE C-ABI call; keypoints and descriptors come back in the context's pinned block
+        const clc_keypoint* pk = nullptr;
+        const uint8_t* pd = nullptr;
+        int n = 0;
+        found_ = 0;
+        const int rc = clc_detect_and_describe_view(ctx_, image, static_cast<uint32_t>(width), static_cast<uint32_t>(height), &pk, &pd, &n, &found_);
+        if (rc != CLC_OK) {
+            std::cerr << "HIPDetector: " << clc_status_string(rc) << ": " << clc_last_error_string(ctx_) << std::endl;
+            return EXIT_FAILURE;
         }
-        // the rows just stored in regions[idx] are still in this context's device memory: publish them, so that a HIPMatcher call that
-        // is handed regions[idx]->DescriptorRawData() on the same device reads them there instead of uploading them again (the
-        // reference re-uploads per call, GPUMatcher.hpp:188-196).  A miss costs nothing; a failure to publish is not an error.
-        if (!kps.empty()) (void)clc_desc_cache_publish(ctx_, nullptr, regions[idx]->DescriptorRawData(), static_cast<int>(kps.size()));
+        receivedImg = true;
+        kps.resize(static_cast<size_t>(n));
+        if (n > 0) std::memcpy(static_cast<void*>(kps.data()), pk, static_cast<size_t>(n) * sizeof(Keypoint));
+        regions[idx] = std::unique_ptr<openMVG::features::AKAZE_Binary_Regions>(new openMVG::features::AKAZE_Binary_Regions);
+        auto& feats = regions[idx]->Features();
+        auto& descs = regions[idx]->Descriptors();
+        feats.resize(static_cast<size_t>(n));
+        descs.resize(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            const float scale = levelScale_[pk[i].scale];                 // GPUDetector.hpp:172-179
+            feats[static_cast<size_t>(i)] = { scale * static_cast<float>(pk[i].x), scale * static_cast<float>(pk[i].y), 7.0f * scale, pk[i].angle };
+        }
+        // the frame's one copy of its descriptors (:181), published on the way: a HIPMatcher call that is handed
+        // regions[idx]->DescriptorRawData() on this device reads the rows where they already are
+        if (n > 0) {
+            static_assert(sizeof(descs[0]) == CLC_DESC_BYTES, "a regions descriptor is the 64 raw bytes");
+            const int rs = clc_detect_store_descriptors(ctx_, static_cast<void*>(descs.data()), n, &published_);
+            if (rs != CLC_OK) {
+                std::cerr << "HIPDetector: " << clc_status_string(rs) << ": " << clc_last_error_string(ctx_) << std::endl;
+                return EXIT_FAILURE;
+            }
+            if (mirrorDesc_) {
+                desc.resize(static_cast<size_t>(8) * n);
+                std::memcpy(desc.data(), pd, static_cast<size_t>(n) * CLC_DESC_BYTES);
+            }
+        }
         return EXIT_SUCCESS;
     }
 
@@ -171,33 +207,13 @@ public:
 private:
     static_assert(sizeof(Keypoint) == sizeof(clc_keypoint), "Keypoint wire format (Keypoint.h:155-163) must be 20 bytes");
 
-    // GPUDetector::detectAndDescribe (:216-291) as ONE C-ABI call.
-    bool detectAndDescribe(const uint8_t* image, const uint32_t width, const uint32_t height)
-    {
-        kps.clear();
-        desc.clear();
-        if (!ctx_) return false;
-        kps.resize(opts_.maxkp);
-        desc.resize(static_cast<size_t>(8) * opts_.maxkp);
-        int n = 0;
-        found_ = 0;
-        const int rc = clc_detect_and_describe(ctx_, image, width, height, reinterpret_cast<clc_keypoint*>(kps.data()),
-                                               reinterpret_cast<uint8_t*>(desc.data()), static_cast<int>(opts_.maxkp), &n, &found_);
-        if (rc != CLC_OK) {
-            std::cerr << "HIPDetector: " << clc_status_string(rc) << ": " << clc_last_error_string(ctx_) << std::endl;
-            kps.clear();
-            desc.clear();
-            return false;
-        }
-        kps.resize(n);
-        desc.resize(static_cast<size_t>(8) * n);
-        return true;
-    }
-
     DetectorOptions opts_;
     clc_ctx* ctx_ = nullptr;
     int device_ = 0;
     int found_ = 0;
+    bool mirrorDesc_ = true;
+    float levelScale_[256];
+    clc_desc_handle published_{};
 };
 
 } // namespace coloc

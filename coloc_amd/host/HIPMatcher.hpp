@@ -43,11 +43,10 @@ public:
             std::cerr << "HIPMatcher: clc_ctx_create failed: " << clc_status_string(rc) << std::endl;
             ctx_ = nullptr;
         }
-        // the library a host was LINKED against and the header it was COMPILED against must agree (the surface grew in
-        // rounds 4 and 5 under one version number); a mismatch is reported, the calls that exist in both still work
+        // the library a host was LINKED against and the header it was COMPILED against must agree; a mismatch is reported, the calls
+        // that exist in both still work
         if (clc_abi_version() != CLC_ABI_VERSION)
             std::cerr << "HIPMatcher: libcoloc_hip reports ABI version " << clc_abi_version() << ", this header was written for " << CLC_ABI_VERSION << std::endl;
-        trustPublishedRegions(true);
     }
     HIPMatcher(const HIPMatcher&) = delete;
     HIPMatcher& operator=(const HIPMatcher&) = delete;
@@ -60,13 +59,18 @@ public:
     }
 
     // Descriptor blocks HIPDetector published are read on the device instead of being uploaded again (the reference uploads per call,
-    // GPUMatcher.hpp:188-196).  true (default): a published block is recognised by address, count and 18 sampled rows -- the caller's
-    // statement that regions blocks are not rewritten in place (true of the reference's flow); false: every lookup folds the whole
-    // host block and compares it with the fold taken at publish time, so a block changed anywhere is uploaded
-    // (clc_desc_cache_mode; the detector must be switched the same way, a trusting detector publishes no fold).
+    // GPUMatcher.hpp:188-196).  Default: checked -- the sweep starts on the device rows, the host folds the block it was handed while the
+    // GPU works and compares with the fold taken at publish time; a block edited anywhere is uploaded and swept again, so the answer is
+    // always the one for the rows passed in.  trustPublishedRegions(true) is the integrator's statement that published regions blocks
+    // are never edited in place: address, count, generation and 18 sampled rows then decide (the detector must publish folds -- it
+    // does by default -- for the checked mode to find its blocks).  usePublishedRegions(false): every call uploads, like the reference.
     void trustPublishedRegions(bool on)
     {
         if (ctx_) (void)clc_desc_cache_mode(ctx_, on ? CLC_DESC_CACHE_TRUST : CLC_DESC_CACHE_VERIFY);
+    }
+    void usePublishedRegions(bool on)
+    {
+        if (ctx_) (void)clc_desc_cache_mode(ctx_, on ? CLC_DESC_CACHE_VERIFY : CLC_DESC_CACHE_OFF);
     }
 
     void setMapData(int kpNum, void* desc)
@@ -84,6 +88,7 @@ public:
     {
         const uint64_t* p = static_cast<const uint64_t*>(desc);
         query_.assign(p, p + static_cast<size_t>(8) * kpNum);
+        queryRef_ = nullptr;
         kpQuery_ = kpNum;
     }
 
@@ -139,11 +144,15 @@ public:
                                          static_cast<int>(regions[pairIdx.second]->RegionCount()));
     }
 
+    // GPUMatcher.hpp:174-178: setQueryImage(regions[droneId]) + matchFeaturesWithMap().  The regions block itself is handed to the
+    // library (no copy into a query buffer first), so that a block HIPDetector published is found on the device.
     void matchSceneWithMap(int& droneId, colocData& data, openMVG::matching::IndMatches& mapMatches)
     {
-        setQueryImage(static_cast<int>(data.regions[droneId]->RegionCount()),
-                      const_cast<void*>(data.regions[droneId]->DescriptorRawData()));
-        mapMatches = matchFeaturesWithMap();
+        // (the query set by this call IS the regions block -- not a copy of it: a later computeMatchesPreset() / matchFeaturesWithMap()
+        // reads it there, so it must still exist then; in the reference's flow regions[droneId] lives until the drone's next frame)
+        kpQuery_ = static_cast<unsigned int>(data.regions[droneId]->RegionCount());
+        queryRef_ = data.regions[droneId]->DescriptorRawData();
+        mapMatches = matchWithMap(queryRef_, static_cast<int>(kpQuery_));
     }
 
     // GPUMatcher.hpp:180-226: IndMatch(i_ = query index, j_ = train index); dmatches(train, query, 0)
@@ -171,7 +180,7 @@ public:
         openMVG::matching::IndMatches matches;
         std::vector<int32_t> m(kpQuery_);
         dmatches.clear();
-        if (!check(clc_match_2nn(ctx_, query_.data(), static_cast<int>(kpQuery_), train_.data(), static_cast<int>(kpTrain_),
+        if (!check(clc_match_2nn(ctx_, queryData(), static_cast<int>(kpQuery_), train_.data(), static_cast<int>(kpTrain_),
                                  matchThreshold_, m.data(), nullptr, nullptr), "computeMatchesPreset"))
             return matches;
         for (size_t i = 0; i < m.size(); ++i) {
@@ -184,20 +193,23 @@ public:
     }
 
     // GPUMatcher.hpp:252-271: IndMatch(i_ = MAP index, j_ = query index)
-    openMVG::matching::IndMatches matchFeaturesWithMap()
+    openMVG::matching::IndMatches matchFeaturesWithMap() { return matchWithMap(queryData(), static_cast<int>(kpQuery_)); }
+
+    const char* lastError() const { return ctx_ ? clc_last_error_string(ctx_) : "no context"; }
+
+private:
+    const void* queryData() const { return queryRef_ ? queryRef_ : static_cast<const void*>(query_.data()); }
+
+    openMVG::matching::IndMatches matchWithMap(const void* desc, int n)
     {
         openMVG::matching::IndMatches matches;
-        std::vector<int32_t> m(kpQuery_);
-        if (!check(clc_match_map(ctx_, query_.data(), static_cast<int>(kpQuery_), matchThreshold_, m.data()), "matchFeaturesWithMap"))
-            return matches;
+        std::vector<int32_t> m(n > 0 ? n : 0);
+        if (!check(clc_match_map(ctx_, desc, n, matchThreshold_, m.data()), "matchFeaturesWithMap")) return matches;
         for (size_t i = 0; i < m.size(); ++i)
             if (m[i] != -1) matches.emplace_back(static_cast<openMVG::IndexT>(m[i]), static_cast<openMVG::IndexT>(i));
         return matches;
     }
 
-    const char* lastError() const { return ctx_ ? clc_last_error_string(ctx_) : "no context"; }
-
-private:
     bool check(int rc, const char* what)
     {
         if (rc == CLC_OK) return true;
@@ -209,6 +221,7 @@ private:
     uint8_t matchThreshold_;
     unsigned int kpTrain_ = 0, kpQuery_ = 0, kpMap_ = 0;
     std::vector<uint64_t> train_, query_;
+    const void* queryRef_ = nullptr;     // the query set by matchSceneWithMap: the regions block itself
 };
 
 } // namespace coloc

@@ -96,6 +96,17 @@ typedef struct clc_match_job {
     uint32_t threshold;  /* truncated to 8 bits, see clc_match_2nn          */
 } clc_match_job;
 
+/* descriptor hand-over (see clc_desc_cache_mode below) */
+/* what a publication hands out: the host address and row count it stands for, and the generation it was stamped with (a process-wide
+ * counter: publishing the same address again, destroying the publishing context -- freeGPUMemory -- or a lookup that sees changed
+ * rows ends a generation).  clc_desc_handle_live: 1 while that very publication still stands. */
+typedef struct clc_desc_handle {
+    const void* host;
+    uint64_t    generation;
+    uint32_t    count;
+    uint32_t    slot;
+} clc_desc_handle;
+
 /* ---- lifecycle --------------------------------------------------------------------------- */
 
 int clc_abi_version(void);
@@ -170,6 +181,17 @@ int clc_describe_detected_dev(clc_ctx* ctx, void* d_desc, void* stream);
  * upload image -> pyramid -> detect -> describe -> download keypoints + descriptors. */
 int clc_detect_and_describe(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32_t height,
                             clc_keypoint* h_kps, uint8_t* h_desc, int capacity, int* n_written, int* n_found);
+/* The same without the copies out: *h_kps / *h_desc point into the context's pinned staging block (valid until the next call of this
+ * family on the context), *n_written keypoints / rows of 64 B.  ONE enqueue sequence and ONE stream synchronisation per frame: image
+ * into pinned memory -> DMA upload -> pyramid -> detector -> CLATCH -> one small launch that mirrors the count, the keypoints and the
+ * descriptors that were found into the pinned block (the reference: 7 level downloads each with a synchronisation, two uploads, a
+ * download, a device synchronisation, GPUDetector.hpp:262-290). */
+int clc_detect_and_describe_view(clc_ctx* ctx, const uint8_t* h_img, uint32_t width, uint32_t height, const clc_keypoint** h_kps,
+                                 const uint8_t** h_desc, int* n_written, int* n_found);
+/* The frame's ONE copy of its descriptors into the caller's block (regions[idx]->Descriptors(), GPUDetector.hpp:181): copies the first n
+ * rows staged by the last clc_detect_and_describe* call to h_dst and -- when n is all of them and the context's cache mode is not OFF --
+ * publishes h_dst (see clc_desc_cache_mode): the rows are on the device already, the fold is taken during the copy. */
+int clc_detect_store_descriptors(clc_ctx* ctx, void* h_dst, int n, clc_desc_handle* handle /* nullable */);
 
 /* The device-resident front end for the frames of n_images <= CLC_MAX_BATCH cameras at once (GPUDetector::detectAndDescribe,
  * GPUDetector.hpp:216-291, once per drone in ColoC::processImages, coloc.hpp:150-163): ONE pyramid launch, TWO detector launches
@@ -208,21 +230,24 @@ int clc_keypoints_to_features(const clc_keypoint* h_kps, int n, float* h_feat4);
 int clc_match_2nn(clc_ctx* ctx, const void* h_q, int nq, const void* h_t, int nt, int threshold,
                   int32_t* h_match, uint16_t* h_best, uint16_t* h_second);
 /* Detector -> matcher hand-over without a second upload.  The reference passes descriptors between the two through host memory
- * (FeatureMap regions, GPUDetector.hpp:181 -> GPUMatcher.hpp:188-196) and uploads them again in every match call.  A host that has
- * just copied n rows from device memory (d_src; NULL = this context's own descriptor array, i.e. what clc_detect_and_describe filled)
- * to the host block h_desc can publish that fact: the rows are kept in a process-wide, per-device cache, and clc_match_2nn /
- * clc_match_map / clc_match_pairs skip the upload of a block whose ADDRESS and COUNT match an entry and which the looking-up
- * context's mode accepts as unchanged:
- *   CLC_DESC_CACHE_VERIFY (default): a 64-bit position-keyed fold of ALL rows of the host block equals the one taken when it was
- *       published -- a stale, rewritten (anywhere) or re-used block can only miss, at the price of one pass over the host block;
- *   CLC_DESC_CACHE_TRUST: first, last and 16 sampled rows are compared; the caller STATES that it does not rewrite a published block
- *       in place (the policy classes do, for FeatureMap regions, which only the detector writes: HIPMatcher::trustPublishedRegions);
- *   CLC_DESC_CACHE_OFF: every block is uploaded, like the reference (GPUMatcher.hpp:188-196).
+ * (FeatureMap regions, GPUDetector.hpp:181 -> GPUMatcher.hpp:188-196) and uploads them again in every match call.  Here the front end
+ * keeps a frame's descriptors in a device block of a process-wide, per-device table; when the host stores the rows at a host address it
+ * PUBLISHES that fact (clc_detect_store_descriptors does both; clc_desc_cache_publish for rows copied by the caller, d_src = where they
+ * lie on the device, NULL = the frame this context staged last), and clc_match_2nn / clc_match_map / clc_match_pairs given that ADDRESS
+ * and COUNT read the rows where they already are -- as far as the looking-up context's mode allows:
+ *   CLC_DESC_CACHE_VERIFY (default, the policy classes included): optimistic and checked -- the sweep starts on the device rows at once,
+ *       and while it runs the host folds ALL rows of the block it was handed (64-bit position-keyed fold) and compares with the fold
+ *       taken when the block was published; a block edited anywhere since is uploaded and the sweep repeated.  Edited host rows are
+ *       never matched stale; an unchanged block costs no upload and no extra latency (the fold hides behind the sweep);
+ *   CLC_DESC_CACHE_TRUST: address, count, generation and 18 sampled rows; the caller STATES that it does not edit published blocks in
+ *       place (opt-in: HIPMatcher::trustPublishedRegions(true));
+ *   CLC_DESC_CACHE_OFF: every block is uploaded, like the reference (GPUMatcher.hpp:188-196); the front end publishes nothing.
  * A block published by a TRUST context carries no fold and is invisible to VERIFY lookups.  Up to 32 blocks, least recently used
  * replaced; CLC_DESC_CACHE=0|verify|trust in the environment sets the mode contexts start with. */
 enum { CLC_DESC_CACHE_OFF = 0, CLC_DESC_CACHE_VERIFY = 1, CLC_DESC_CACHE_TRUST = 2 };
 int clc_desc_cache_mode(clc_ctx* ctx, int mode);
-int clc_desc_cache_publish(clc_ctx* ctx, const void* d_src, const void* h_desc, int n);
+int clc_desc_cache_publish(clc_ctx* ctx, const void* d_src, const void* h_desc, int n, clc_desc_handle* handle /* nullable */);
+int clc_desc_handle_live(const clc_desc_handle* handle);
 int clc_desc_cache_clear(void);
 /* lookups of the host-pointer match entry points answered from the cache / uploaded, since the process started */
 int clc_desc_cache_stats(unsigned long long* hits, unsigned long long* misses);

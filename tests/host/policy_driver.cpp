@@ -2,6 +2,7 @@
 // DiskInterface use GPUDetector / GPUMatcher (reference include/coloc/coloc.hpp:162,197,219,287,323;
 // InterfaceDisk.hpp:15) and dumps the results as raw files for tests/test_gpu_policy.py to compare
 // with the oracle.  usage: policy_driver <dir> <ncams> <width> <height> <maxkp>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -108,6 +109,51 @@ int main(int argc, char** argv)
     IndMatches common;
     matcher.matchMapFeatures(data.regions[0], data.regions[1], common);
     dump_matches(dir + "/mapmap_0_1.bin", common);
+    // ---- regions edited IN PLACE after the detector stored (and published) them, in the policy classes' DEFAULT mode: every match
+    // entry must answer for the rows the block holds NOW.  One byte of a middle row that no sampled row covers, then
+    // a stretch of rows copied over from camera 1 -- each followed by all the match entry points; the handle the detector got says when
+    // its publication has died.
+    {
+        coloc::FeatureMap fresh;
+        std::string name = dir + "/img0.pgm";
+        if (detector.detectFeaturesFile(0, fresh, name) != EXIT_SUCCESS) return 1;
+        const clc_desc_handle published = detector.lastPublished();
+        if (!published.host || published.host != fresh[0]->DescriptorRawData() || !clc_desc_handle_live(&published)) {
+            std::fprintf(stderr, "the detector did not publish regions[0] (host %p)\n", published.host);
+            return 1;
+        }
+        // regions 1 stays as the detector stored it (still published); regions 0 is the fresh block
+        data.regions[0] = std::move(fresh[0]);
+        const size_t n0 = data.regions[0]->RegionCount(), n1 = data.regions[1]->RegionCount();
+        IndMatches a;
+        matcher.computeMatchesPair({ 0, 1 }, data.regions, a);                       // unchanged block: served from the device
+        dump_matches(dir + "/edit0_0_1.bin", a);
+        if (!clc_desc_handle_live(&published)) { std::fprintf(stderr, "an unchanged block lost its publication\n"); return 1; }
+        const size_t mid = n0 / 2 + 3;
+        data.regions[0]->Descriptors()[mid][20] ^= 0x04;
+        if (n1 > 8) data.regions[0]->Descriptors()[mid] = data.regions[1]->Descriptors()[7];   // a row that now matches camera 1's row 7 exactly
+        matcher.computeMatchesPair({ 0, 1 }, data.regions, a);
+        dump_matches(dir + "/edit1_0_1.bin", a);
+        if (clc_desc_handle_live(&published)) { std::fprintf(stderr, "an edited block kept its publication\n"); return 1; }
+        dump(dir + "/edit1_desc0.bin", data.regions[0]->DescriptorRawData(), n0 * 64);
+        // publish it again through a second detect of the same frame, then overwrite a stretch and go through the other entries
+        coloc::FeatureMap again;
+        if (detector.detectFeaturesFile(0, again, name) != EXIT_SUCCESS) return 1;
+        data.regions[0] = std::move(again[0]);
+        const size_t k = std::min<size_t>(n1, std::min<size_t>(n0, 300)) / 2;
+        for (size_t i = 0; i < k; ++i) data.regions[0]->Descriptors()[n0 / 3 + i] = data.regions[1]->Descriptors()[i];
+        dump(dir + "/edit2_desc0.bin", data.regions[0]->DescriptorRawData(), n0 * 64);
+        PairWiseMatches all;
+        if (matcher.computeMatches(data.regions, all) != EXIT_SUCCESS) return 1;
+        dump_matches(dir + "/edit2_0_1.bin", all.count({ 0, 1 }) ? all[{ 0, 1 }] : IndMatches());
+        int d0 = 0;
+        IndMatches mm;
+        matcher.matchSceneWithMap(d0, data, mm);                                     // query = the edited regions 0, map = the old camera 0
+        dump_matches(dir + "/edit2_map_0.bin", mm);
+        IndMatches cm;
+        matcher.matchMapFeatures(data.regions[1], data.regions[0], cm);              // the edited block as the TRAIN side
+        dump_matches(dir + "/edit2_mapmap_1_0.bin", cm);
+    }
     std::printf("ok %d cams, %zu pairs with matches\n", ncams, putative.size());
     return 0;
 }

@@ -63,3 +63,19 @@ def test_policy_classes_end_to_end(tmp_path, oracle):
     m = oracle.k2nn(descs[0], descs[1], 60)
     assert np.array_equal(_pairs_from(np.fromfile(tmp_path / "mapmap_0_1.bin", dtype=np.uint32)),
                           np.stack([np.nonzero(m >= 0)[0], m[m >= 0]], 1))
+    # ---- regions edited in place after the detector published them, policy classes' DEFAULT mode: every entry
+    # answers for the rows the block holds now
+    def pairs_of(m):
+        return np.stack([np.nonzero(m >= 0)[0], m[m >= 0]], 1)
+    assert np.array_equal(_pairs_from(np.fromfile(tmp_path / "edit0_0_1.bin", dtype=np.uint32)), pairs_of(oracle.k2nn(descs[0], descs[1], 40)))
+    e1 = np.fromfile(tmp_path / "edit1_desc0.bin", dtype=np.uint8).reshape(-1, 64)
+    assert e1.shape == descs[0].shape and (e1 != descs[0]).any(axis=1).sum() == 1
+    assert np.array_equal(_pairs_from(np.fromfile(tmp_path / "edit1_0_1.bin", dtype=np.uint32)), pairs_of(oracle.k2nn(e1, descs[1], 40)))
+    e2 = np.fromfile(tmp_path / "edit2_desc0.bin", dtype=np.uint8).reshape(-1, 64)
+    assert (e2 != descs[0]).any(axis=1).sum() > 20
+    want = pairs_of(oracle.k2nn(e2, descs[1], 40))
+    assert len(want) > len(pairs_of(oracle.k2nn(descs[0], descs[1], 40)))           # the rows copied over from camera 1 match it now
+    assert np.array_equal(_pairs_from(np.fromfile(tmp_path / "edit2_0_1.bin", dtype=np.uint32)), want)
+    m = oracle.k2nn(e2, descs[0], 60)                                                # query = edited block, map = camera 0 as detected
+    assert np.array_equal(_pairs_from(np.fromfile(tmp_path / "edit2_map_0.bin", dtype=np.uint32)), np.stack([m[m >= 0], np.nonzero(m >= 0)[0]], 1))
+    assert np.array_equal(_pairs_from(np.fromfile(tmp_path / "edit2_mapmap_1_0.bin", dtype=np.uint32)), pairs_of(oracle.k2nn(descs[1], e2, 60)))

@@ -192,3 +192,36 @@ def test_lockstep_batches_equal_interleaved_batches_equal_single_solves():
     assert res["1"] == res["0"] and res["1"] == res["cap5"]
     assert res["1"]["tv"][4]["E"] is None and all(len(r["inl"]) > 60 for i, r in enumerate(res["1"]["tv"]) if i != 4)
     assert all(len(r["inl"]) > 200 for r in res["1"]["pnp"])
+
+
+def test_interleaved_batch_straight_before_a_lockstep_batch_on_the_same_contexts():
+    """a single or interleaved solve returns when its word says "done" -- the round enqueued ahead of it is still
+    queued on ITS context's stream and its keeper writes the state copies in that context's workspace.  A lockstep batch that follows
+    stages every solve's workspace from the FIRST context's stream: that stream must first be ordered behind each context's own.
+    Six resection solves without refinement (fewer than eight: interleaved, nothing polled to completion behind the rounds) and,
+    with no synchronisation in between, six two-view filters (four or more: lockstep) on the same contexts in another order, forty
+    times over; every result must be the single-solve entry's."""
+    from coloc_amd import Context
+    from coloc_amd.abi import essential_acransac_batch, pnp_localize_batch
+    ctxs = [Context(device=0, detector=False, matcher=False) for _ in range(6)]
+    ref = Context(device=0, detector=False, matcher=False)
+    try:
+        scenes = [synth.pnp_scene(400 + 150 * k, seed=9100 + k, outlier_frac=0.3) for k in range(6)]
+        poses = [(sc["X"], sc["x"], sc["K"]) for sc in scenes]
+        pairs = [_pair(300 + i, n=350 + 200 * i) for i in range(6)]
+        views = [(p["x1"], p["x2"], K, K, WH, 40 + i) for i, p in enumerate(pairs)]
+        want_p = [ref.pnp_acransac(X, x, Kc, max_iteration=256, seed=11 + k, refine=False) for k, (X, x, Kc) in enumerate(poses)]
+        want_v = [ref.essential_acransac(x1, x2, K, K, WH, max_iteration=256, seed=s) for (x1, x2, _, _, _, s) in views]
+        rng = np.random.default_rng(3)
+        for rep in range(40):
+            order = list(rng.permutation(6))
+            got_p = pnp_localize_batch(ctxs, poses, max_iteration=256, seeds=[11 + k for k in range(6)], refine=False)
+            got_v = essential_acransac_batch([ctxs[i] for i in order], views)
+            for k in range(6):
+                assert np.array_equal(got_p[k]["inliers"], want_p[k]["inliers"]) and np.array_equal(got_p[k]["Rt"], want_p[k]["Rt"]), (rep, k)
+                assert got_p[k]["iterations"] == want_p[k]["iterations"], (rep, k)
+                assert got_v[k]["iterations"] == want_v[k]["iterations"] and np.array_equal(got_v[k]["inliers"], want_v[k]["inliers"]), (rep, k)
+                assert np.array_equal(got_v[k]["E"], want_v[k]["E"]) and got_v[k]["min_nfa"] == want_v[k]["min_nfa"], (rep, k)
+    finally:
+        for c in ctxs + [ref]:
+            c.close()

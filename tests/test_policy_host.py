@@ -25,3 +25,9 @@ def test_policy_classes_compile_and_link(tmp_path):
 def test_localizer_and_robust_matcher_compile_and_link(tmp_path):
     exe = build_driver(str(tmp_path / "localizer_driver"), "localizer_driver.cpp")
     assert os.path.exists(exe)
+
+
+def test_policy_bench_compiles_and_links(tmp_path):
+    """tests/host/bench_policy.cpp (the drop-in path timed from C++; run by tests/test_gpu_policy_bench.py and bench.py)."""
+    exe = build_driver(str(tmp_path / "bench_policy"), "bench_policy.cpp")
+    assert os.path.exists(exe)
