@@ -257,6 +257,7 @@ def main():
                          "(rounds 1-4's headline).  Default since round 5: consecutive steps are dealt to --lanes contexts / streams / descriptor "
                          "arenas in turn, so that step i's sweep (matrix pipe) runs beside the next steps' pyramid + CLATCH -- the only describe / sweep overlap "
                          "this machine allows (profiles/r05_step_overlap.txt); the one-stream figure is then reported as `one_stream`.")
+    ap.add_argument("--sections", default="", help="comma list: run only these side sections (e.g. policy_path,front_end); default all")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the informational side sections (other formulation, shares, config[2], front end, pose, two-view, host path): "
                          "the rocprofv3 passes use it so that a kernel's average in their summaries is the average of the step's own launches")
@@ -717,7 +718,11 @@ def main():
                 "measured with the torch exchange." % (float(NKP) * NKP, pairs_n, float(pairs_n) * NKP * NKP, world))
         # Everything below is reported next to the headline line and never takes it down: each section runs guarded, a
         # failure is recorded under its own key -- and makes the process exit non-zero AFTER the line is printed.
+        only = set(k for k in (args.sections or "").split(",") if k)
+
         def guarded(key, fn):
+            if only and key not in only:
+                return
             try:
                 fn()
             except Exception as exc:
@@ -1128,10 +1133,11 @@ def main():
                                     "match_2nn_10k_x_10k_us": tm * 1e6, "Mmatches_per_s_incl_transfers": NKP * NKP / tm / 1e6,
                                     "match_2nn_10k_x_10k_published_blocks_us": tcache["trust"] * 1e6,
                                     "match_2nn_10k_x_10k_published_blocks_verified_us": tcache["verify"] * 1e6,
-                                    "published_what": "both descriptor blocks published by the detector (clc_desc_cache_publish): no upload, the call is sweep + 40 KB "
-                                                      "of indices back + one synchronisation; identical matches.  *_us: a TRUSTING context (what HIPDetector / "
-                                                      "HIPMatcher use: address + count + 18 sampled rows); *_verified_us: the default for raw callers, every "
-                                                      "lookup folds the whole 640 KB host block (two of them per call) and compares with the fold taken at publish time",
+                                    "published_what": "both descriptor blocks published by the front end (clc_desc_cache_publish): no upload, the call is sweep + 40 KB "
+                                                      "of indices back + one synchronisation; identical matches.  *_verified_us: the DEFAULT mode (policy classes "
+                                                      "included) -- the sweep starts on the device rows at once and the host folds both 640 KB blocks WHILE it runs, "
+                                                      "comparing with the folds taken at publish time (an edited block is uploaded and swept again); *_us: a TRUSTING "
+                                                      "context (opt-in: address + count + generation + 18 sampled rows, no pass over the block)",
                                     "pyramid_plus_describe_10k_us": td * 1e6, "Mdesc_per_s_incl_transfers": NKP / td / 1e6}
 
         def sec_policy_path():
@@ -1147,15 +1153,17 @@ def main():
             relief = synth.smooth_relief()
             Ra, ta = synth.look_at_plane_pose((7.0, 7.0), 5.0, yaw=0.0, tilt=(0.10, -0.06))
             Rb, tb = synth.look_at_plane_pose((7.6, 6.7), 5.2, yaw=0.12, tilt=(-0.08, 0.09))
+            Rc, tc = synth.look_at_plane_pose((6.5, 7.3), 4.9, yaw=-0.10, tilt=(0.05, 0.07))
             det = Context(device=dev_index, width=W, height=H, maxkp=12000, matcher=False)
             try:
                 frames = None
                 for n_rect in (900, 2500, 6000):          # a texture dense enough for ~5 k keypoints at 640 x 480
                     tex = synth.plane_texture(n_rect=n_rect)
-                    frames = [synth.render_plane(tex, 100.0, K, R, t, W, H, relief=relief) for R, t in ((Ra, ta), (Rb, tb))]
+                    frames = [synth.render_plane(tex, 100.0, K, R, t, W, H, relief=relief) for R, t in ((Rc, tc), (Rb, tb), (Ra, ta))]
                     kps0, desc0, _ = det.detect_and_describe(frames[0])
                     if len(kps0) >= 4500:
                         break
+                kps_map, _, _ = det.detect_and_describe(frames[2])         # the keyframe the map is made of
                 # the same frame through the device-pointer path: what the policy path's regions must hold
                 d_img = torch.from_numpy(frames[0]).to(dev)
                 det.pyramid_build_dev(d_img.data_ptr(), W, H, W, None)
@@ -1164,14 +1172,27 @@ def main():
                 det.describe_detected_dev(tmp.data_ptr(), None)
                 det.sync()
                 desc_dev = tmp.cpu().numpy()[:len(kp_dev)]
+                # the same frame's front end device-resident, back to back (what front_end.frame_us_no_events is for bench's own frame)
+                def fe_dev():
+                    det.pyramid_build_dev(d_img.data_ptr(), W, H, W, None)
+                    det.detect_dev(None)
+                    det.describe_detected_dev(tmp.data_ptr(), None)
+                for _ in range(200):
+                    fe_dev()
+                det.sync()
+                t1 = time.perf_counter()
+                for _ in range(200):
+                    fe_dev()
+                det.sync()
+                fe_dev_us = (time.perf_counter() - t1) / 200 * 1e6
             finally:
                 det.close()
             with tempfile.TemporaryDirectory() as d:
-                for c, img in enumerate(frames):
-                    with open(os.path.join(d, "cam%d.pgm" % c), "wb") as f:
+                for name, img in zip(("cam0", "cam1", "cam_map"), frames):
+                    with open(os.path.join(d, name + ".pgm"), "wb") as f:
                         f.write(b"P5\n# rendered\n%d %d\n255\n" % (W, H))
                         f.write(img.tobytes())
-                feat0 = keypoints_to_features(kps0)
+                feat0 = keypoints_to_features(kps_map)
                 synth.backproject_to_plane(feat0[:, :2].astype(np.float64), K, Ra, ta, relief=relief).astype(np.float64).tofile(os.path.join(d, "map_xyz.bin"))
                 exe = os.path.join(d, "bench_policy")
                 libdir = os.path.join(ROOT, "coloc_amd", "lib")
@@ -1199,8 +1220,10 @@ def main():
                         "pose + covariance out; pair_match_us = HIPMatcher::computeMatches of the two cameras (initMap, :161-164)",
                 "frame": "%dx%d rendered scene" % (W, H), "keypoints": r0["keypoints"], "map_points": r0["map_points"], "map_matches": r0["map_matches"],
                 "pose_inliers": r0["pose_inliers"],
-                "detect_us": r0["detect_us"], "match_us": r0["match_us"], "pose_us": r0["pose_us"], "frame_us": r0["frame_us"], "pair_match_us": r0["pair_match_us"],
+                "detect_us": r0["detect_us"], "detect_steps_us": r0.get("detect_steps_us"), "match_us": r0["match_us"], "pose_us": r0["pose_us"], "frame_us": r0["frame_us"], "pair_match_us": r0["pair_match_us"],
                 "p95": {k: r0[k + "_p95"] for k in ("detect_us", "match_us", "pose_us", "frame_us", "pair_match_us")},
+                "device_front_end_us_same_frame": fe_dev_us,
+                "pcie_bytes_per_frame": {"in": W * H, "out": int(r0["keypoints"][1]) * 84 + 8},
                 "identical_to_device_pointer_path": same, "same_results_every_frame": r0["same_results_every_frame"],
                 "descriptor_hand_over": {"default (published, verified behind the sweep)": {k: r0[k] for k in ("match_us", "pair_match_us")},
                                          "upload every call (reference behaviour)": {k: res["upload_every_call"][k] for k in ("match_us", "pair_match_us")},

@@ -9,6 +9,7 @@
 #include "clc_ctx.h"
 #include "desc_cache.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -174,7 +175,14 @@ int cache_mode_default()
 }
 
 
-// the last launch of the host front end (clc_detect_and_describe_view): count, keypoints and descriptors into pinned host memory
+// The host front end's way out (clc_detect_and_describe_view): the last launch of a frame mirrors the count, the keypoints and the
+// descriptors that were found -- nothing past the count -- into the context's pinned block; the frame's one stream synchronisation
+// follows.  Round 6 built and measured two other forms on the same frames (640 x 480, ~3 800 keypoints; profiles/r06_policy_path_notes.txt):
+// (a) no synchronisation at all -- keypoints mirrored behind the detector by a launch whose last workgroup publishes a polled word behind
+// system-scope fences, the CLATCH waves storing their descriptors twice, a one-thread launch marking them complete: 114 us per frame
+// against 94-97 (the fences 18 us, CLATCH + 5 us, 4 us for a 4-byte store to be acknowledged over PCIe); (b) two mirror launches and an
+// event behind the first, so that the host converts keypoints under CLATCH: 96-98 us (two more runtime calls in the enqueue phase and
+// 5 us of keypoint mirror in front of CLATCH take back what the overlap gives).
 __global__ __launch_bounds__(256) void frontend_mirror_kernel(const uint32_t* __restrict__ d_kps, const uint4* __restrict__ d_desc,
                                                               const uint32_t* __restrict__ d_count, uint32_t* __restrict__ h_kps,
                                                               uint4* __restrict__ h_desc, uint32_t* __restrict__ h_count)
@@ -196,6 +204,7 @@ static int ensure_stage(clc_ctx* ctx)
     const size_t desc = (size_t)ctx->dopts.maxkp * CLC_DESC_BYTES;
     ctx->stage_img = 0; ctx->stage_kps = img; ctx->stage_desc = img + kps; ctx->stage_cnt = img + kps + desc;
     CLC_HIP(ctx, hipHostMalloc((void**)&ctx->h_stage, img + kps + desc + 256, hipHostMallocDefault));
+    memset(ctx->h_stage + ctx->stage_cnt, 0, 256);          // {written, found}
     return CLC_OK;
 }
 
@@ -562,7 +571,9 @@ int clc_detect_and_describe_view(clc_ctx* ctx, const uint8_t* h_img, uint32_t wi
     if (!d_rows) d_rows = (uint8_t*)ctx->d_desc;
     const LevelDesc& L0 = ctx->pd.lv[0];
     uint8_t* hp = ctx->h_stage;
+    uint32_t* h_cnt = (uint32_t*)(hp + ctx->stage_cnt);
     memcpy(hp + ctx->stage_img, h_img, (size_t)width * height);
+    // (the DMA engine; a compute-queue copy kernel reading the pinned block was measured 3 us slower per frame, round 6)
     if (L0.pitch == width)
         CLC_HIP(ctx, hipMemcpyAsync(ctx->d_arena + L0.offset, hp + ctx->stage_img, (size_t)width * height, hipMemcpyHostToDevice, ctx->stream));
     else
@@ -573,7 +584,6 @@ int clc_detect_and_describe_view(clc_ctx* ctx, const uint8_t* h_img, uint32_t wi
     if (rc != CLC_OK) return rc;
     rc = clc_describe_detected_dev(ctx, d_rows, nullptr);
     if (rc != CLC_OK) return rc;
-    uint32_t* h_cnt = (uint32_t*)(hp + ctx->stage_cnt);
     const uint32_t blocks = (ctx->dopts.maxkp * 4u + 255u) / 256u;
     hipLaunchKernelGGL(frontend_mirror_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->d_kps, (const uint4*)d_rows,
                        (const uint32_t*)ctx->d_count, (uint32_t*)(hp + ctx->stage_kps), (uint4*)(hp + ctx->stage_desc), h_cnt);

@@ -50,6 +50,7 @@ static uint64_t fold_rows(void* dst, const void* src, const size_t n)
     uint64_t h0 = 0, h1 = 0, h2 = 0, h3 = 0, k = 0x9E3779B97F4A7C15ull;
     for (size_t r = 0; r < n; ++r, p += CLC_DESC_BYTES, k += 0xD1B54A32D192ED03ull) {
         uint64_t w[8];
+        __builtin_prefetch(p + 8 * CLC_DESC_BYTES);     // (a block the GPU has just written is not in any cache: ask eight rows ahead)
         memcpy(w, p, sizeof w);                          // (host blocks carry no alignment promise)
         if (COPY) { memcpy(o, w, sizeof w); o += CLC_DESC_BYTES; }
         h0 += fold_mul(w[0] ^ k, w[1] ^ 0x8BB84B93962EACC9ull);

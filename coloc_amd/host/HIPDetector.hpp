@@ -13,8 +13,8 @@
 // orientation on every level, CLATCH -- runs on the GPU in one enqueue sequence with a single
 // host synchronisation (clc_detect_and_describe_view: the frame goes in and out through one pinned
 // block of the context); the reference copies 7 levels back, runs KFAST on the CPU and synchronises
-// 8 + 3 times per frame.  The descriptors are copied ONCE into regions[idx] (and once into the
-// public `desc`, which callers read: InterfaceROS.hpp:30,37; mirrorRawOutputs(false) drops that copy).
+// 8 + 3 times per frame.  The descriptors are copied ONCE, into regions[idx] (the public `desc` is
+// filled on request: mirrorRawOutputs(true)).
 #pragma once
 
 #include <cmath>
@@ -120,8 +120,9 @@ public:
     {
         if (ctx_) (void)clc_desc_cache_mode(ctx_, on ? CLC_DESC_CACHE_VERIFY : CLC_DESC_CACHE_OFF);
     }
-    // Callers of the reference read the public `kps` / `desc` after a detect call (InterfaceROS.hpp:30,37).  A host that only uses
-    // regions[idx] can switch the second descriptor copy off; `kps` is always filled.
+    // The frame's descriptors are copied ONCE, into regions[idx] (GPUDetector.hpp:181).  The public `desc` (:33) is a second copy of the
+    // same rows; the only reader in the reference is InterfaceROS::processImagePair (InterfaceROS.hpp:30,37), whose call does not match
+    // GPUMatcher::setTrainingImage's signature.  mirrorRawOutputs(true) fills it as the reference does; `kps` is always filled.
     void mirrorRawOutputs(bool on) { mirrorDesc_ = on; }
     // the handle of the block published by the last detect call (host == nullptr: nothing was published)
     const clc_desc_handle& lastPublished() const { return published_; }
@@ -171,8 +172,9 @@ public:
         feats.resize(static_cast<size_t>(n));
         descs.resize(static_cast<size_t>(n));
         for (int i = 0; i < n; ++i) {
-            const float scale = levelScale_[pk[i].scale];                 // GPUDetector.hpp:172-179
-            feats[static_cast<size_t>(i)] = { scale * static_cast<float>(pk[i].x), scale * static_cast<float>(pk[i].y), 7.0f * scale, pk[i].angle };
+            const float scale = levelScale_[kps[static_cast<size_t>(i)].scale];   // GPUDetector.hpp:172-179
+            feats[static_cast<size_t>(i)] = { scale * static_cast<float>(kps[static_cast<size_t>(i)].x), scale * static_cast<float>(kps[static_cast<size_t>(i)].y),
+                                              7.0f * scale, kps[static_cast<size_t>(i)].angle };
         }
         // the frame's one copy of its descriptors (:181), published on the way: a HIPMatcher call that is handed
         // regions[idx]->DescriptorRawData() on this device reads the rows where they already are
@@ -185,7 +187,7 @@ public:
             }
             if (mirrorDesc_) {
                 desc.resize(static_cast<size_t>(8) * n);
-                std::memcpy(desc.data(), pd, static_cast<size_t>(n) * CLC_DESC_BYTES);
+                std::memcpy(desc.data(), descs.data(), static_cast<size_t>(n) * CLC_DESC_BYTES);
             }
         }
         return EXIT_SUCCESS;
@@ -211,7 +213,7 @@ private:
     clc_ctx* ctx_ = nullptr;
     int device_ = 0;
     int found_ = 0;
-    bool mirrorDesc_ = true;
+    bool mirrorDesc_ = false;
     float levelScale_[256];
     clc_desc_handle published_{};
 };

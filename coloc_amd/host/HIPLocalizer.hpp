@@ -85,20 +85,24 @@ public:
             std::cout << "Failure while setting up 2D-3D correspondences" << std::endl;
             return EXIT_FAILURE;
         }
-        if (!localize(cam, matching_data, pose)) {
+        // SfM_Localizer::Localize (:93) and refine() (:100-106) as ONE submission (clc_pnp_localize_ac: the refinement launch follows the
+        // a-contrario rounds on the device; one upload, no second round trip): the pose, covariance and rmse are those of
+        // localize() followed by refine()
+        bool refined = false;
+        if (!localize_with(ctx_, seed++, cam, matching_data, pose, &covariance, &rmse, &refined)) {
             std::cout << "Localization unsuccessful" << std::endl;
             return EXIT_FAILURE;
         }
         std::cout << "Localization successful" << std::endl;
         inliers = matching_data.vec_inliers;
-        if (!this->refine(idx, pose, matching_data, covariance, rmse)) std::cerr << "Refining pose for image failed." << std::endl;
+        if (!refined) std::cerr << "Refining pose for image failed." << std::endl;
         return EXIT_SUCCESS;
     }
 
     // localizeImage for SEVERAL cameras at once (not in the reference, whose loop calls localizeImage camera by camera, coloc.hpp:129-137;
     // BASELINE config[2]: "batched PnP/RANSAC pose").  The cameras' a-contrario solves -- chains of short launches with the host in the
-    // loop -- run through clc_pnp_localize_ac_batch, each on a light context of its own, and interleave on the device; the refinement
-    // follows per camera.  Poses, inliers, covariances and the sampler seeds are exactly those of calling localizeImage for idxs[0],
+    // loop -- run through clc_pnp_localize_ac_batch, each on a light context of its own, and interleave on the device; every camera's
+    // refinement rides behind its own rounds.  Poses, inliers, covariances and the sampler seeds are exactly those of calling localizeImage for idxs[0],
     // idxs[1], ... in this order.  Returns one status per camera in the members' convention (false = success).
     std::vector<bool> localizeImages(const std::vector<int>& idxs, std::vector<openMVG::geometry::Pose3>& poses, colocData& data,
                                      std::vector<Cov6>& covariances, std::vector<float>& rmses,
@@ -119,7 +123,7 @@ public:
         std::vector<openMVG::sfm::Image_Localizer_Match_Data> md(nc);
         std::vector<std::vector<double>> X(nc), x(nc);
         std::vector<std::vector<int32_t>> inl(nc);
-        std::vector<double> Kd(9 * nc), Rt(12 * nc);
+        std::vector<double> Kd(9 * nc), Rt(12 * nc), covs(36 * nc);
         std::vector<clc_pose_job> jobs;
         std::vector<size_t> who;
         for (size_t k = 0; k < nc; ++k) {
@@ -146,8 +150,8 @@ public:
             jb.X = X[k].data(); jb.x = x[k].data(); jb.K = &Kd[9 * k]; jb.n = n;
             jb.max_iteration = static_cast<int>(md[k].max_iteration); jb.seed = seed_value;
             jb.precision = md[k].error_max;                            // +inf: the a-contrario threshold
-            jb.refine = 0;
-            jb.Rt = &Rt[12 * k]; jb.inliers = inl[k].data();
+            jb.refine = 1; jb.huber_a = 16.0;                           // Refiner.hpp:122
+            jb.Rt = &Rt[12 * k]; jb.cov = &covs[36 * k]; jb.inliers = inl[k].data();
             jobs.push_back(jb);
             who.push_back(k);
         }
@@ -165,8 +169,8 @@ public:
             poses[k] = pose_from_Rt(&Rt[12 * k]);
             std::cout << "Localization successful" << std::endl;
             inliers[k] = md[k].vec_inliers;
-            int idx = idxs[k];
-            if (!this->refine(idx, poses[k], md[k], covariances[k], rmses[k])) std::cerr << "Refining pose for image failed." << std::endl;
+            for (int i = 0; i < 6; ++i) for (int j2 = 0; j2 < 6; ++j2) covariances[k](i, j2) = covs[36 * k + 6 * i + j2];
+            rmses[k] = mean_reprojection(poses[k], &Kd[9 * k], md[k]);
             status[k] = static_cast<bool>(EXIT_SUCCESS);
         }
         return status;
@@ -177,15 +181,19 @@ public:
     bool localize(const openMVG::cameras::Pinhole_Intrinsic_Radial_K3& cam, openMVG::sfm::Image_Localizer_Match_Data& matching_data,
                   openMVG::geometry::Pose3& pose)
     {
-        return localize_with(ctx_, seed++, cam, matching_data, pose);
+        return localize_with(ctx_, seed++, cam, matching_data, pose, nullptr, nullptr, nullptr);
     }
 
-    // the solve itself, on any context (shared with HIP_SfM_Localizer::Localize)
+    // the solve itself, on any context (shared with HIP_SfM_Localizer::Localize).  covariance != nullptr: the refinement (Huber(4^2) LM on
+    // the inliers + 6 x 6 covariance, refine() below) rides in the same submission; *refined says whether it ran, *rmse is the mean
+    // pixel distance of the reprojected inliers (the value the reference leaves in rmse, Localizer.hpp:141-170)
     static bool localize_with(clc_ctx* ctx_, const uint64_t seed_value, const openMVG::cameras::Pinhole_Intrinsic_Radial_K3& cam,
-                              openMVG::sfm::Image_Localizer_Match_Data& matching_data, openMVG::geometry::Pose3& pose)
+                              openMVG::sfm::Image_Localizer_Match_Data& matching_data, openMVG::geometry::Pose3& pose,
+                              Cov6* covariance = nullptr, float* rmse = nullptr, bool* refined = nullptr)
     {
         const int n = static_cast<int>(matching_data.pt3D.cols());
         matching_data.vec_inliers.clear();
+        if (refined) *refined = false;
         if (!ctx_ || n == 0) return false;
         std::vector<double> X(3 * static_cast<size_t>(n)), x(2 * static_cast<size_t>(n));
         for (int i = 0; i < n; ++i) {
@@ -196,57 +204,76 @@ public:
         double Kd[9];
         intrinsics(cam, Kd);
         const double precision = std::isinf(matching_data.error_max) ? matching_data.error_max : matching_data.error_max * matching_data.error_max;
-        double Rt[12], emax = 0.0, nfa = 0.0;
+        double Rt[12], cov[36], emax = 0.0, nfa = 0.0, r = 0.0;
         std::vector<int32_t> inl(static_cast<size_t>(n));
         int n_inl = 0, its = 0;
-        const int rc = clc_pnp_acransac(ctx_, X.data(), x.data(), n, Kd, static_cast<int>(matching_data.max_iteration), seed_value, precision, Rt,
-                                        nullptr, inl.data(), &n_inl, &emax, &nfa, &its);
+        const int rc = covariance
+            ? clc_pnp_localize_ac(ctx_, X.data(), x.data(), n, Kd, static_cast<int>(matching_data.max_iteration), seed_value, precision, 16.0, Rt, cov,
+                                  nullptr, inl.data(), &n_inl, &emax, &r)
+            : clc_pnp_acransac(ctx_, X.data(), x.data(), n, Kd, static_cast<int>(matching_data.max_iteration), seed_value, precision, Rt,
+                               nullptr, inl.data(), &n_inl, &emax, &nfa, &its);
         if (rc != CLC_OK) {
-            std::cerr << "HIPLocalizer: clc_pnp_acransac: " << clc_last_error_string(ctx_) << std::endl;
+            std::cerr << "HIPLocalizer: " << (covariance ? "clc_pnp_localize_ac: " : "clc_pnp_acransac: ") << clc_last_error_string(ctx_) << std::endl;
             return false;
         }
         matching_data.vec_inliers.assign(inl.begin(), inl.begin() + n_inl);
         if (n_inl > 0) matching_data.error_max = emax;
         if (!(n_inl > 2.5 * 3)) return false;                    // bResection = inliers > 2.5 * MINIMUM_SAMPLES
         pose = pose_from_Rt(Rt);
+        if (covariance) {
+            for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) (*covariance)(i, j) = cov[6 * i + j];
+            if (rmse) *rmse = mean_reprojection(pose, Kd, matching_data);
+            if (refined) *refined = true;
+        }
         return true;
+    }
+
+    // mean pixel distance between the observations and the reprojected inliers (Localizer.hpp:141-170: zero distortion, fy = fx)
+    static float mean_reprojection(const openMVG::geometry::Pose3& pose, const double* Kd, const openMVG::sfm::Image_Localizer_Match_Data& md)
+    {
+        const size_t n = md.vec_inliers.size();
+        if (n == 0) return 0.0f;
+        const openMVG::Vec3 tt = pose.translation();
+        double error = 0.0;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t c = md.vec_inliers[i];
+            double pc[3];
+            for (int a = 0; a < 3; ++a)
+                pc[a] = pose.rotation()(a, 0) * md.pt3D(0, c) + pose.rotation()(a, 1) * md.pt3D(1, c) + pose.rotation()(a, 2) * md.pt3D(2, c) + tt[a];
+            const double u = Kd[0] * pc[0] / pc[2] + Kd[2], v = Kd[0] * pc[1] / pc[2] + Kd[5];
+            error += std::sqrt((md.pt2D(0, c) - u) * (md.pt2D(0, c) - u) + (md.pt2D(1, c) - v) * (md.pt2D(1, c) - v));
+        }
+        return static_cast<float>(error / static_cast<double>(n));
     }
 
     bool refine(int& idx, openMVG::geometry::Pose3& pose, openMVG::sfm::Image_Localizer_Match_Data& matchData, Cov6& poseCovariance,
                 float& rmse)
     {
         const openMVG::cameras::Pinhole_Intrinsic_Radial_K3 cam = camera(idx);
-        const size_t n = matchData.vec_inliers.size();
-        if (!ctx_ || n < 3) return false;
+        const size_t n_inl = matchData.vec_inliers.size();
+        const size_t n = static_cast<size_t>(matchData.pt3D.cols());
+        if (!ctx_ || n_inl < 3) return false;
+        // all correspondences + the inlier mask: the launch localizeImage's single submission makes, hence the same bits
         std::vector<double> X(3 * n), x(2 * n);
+        std::vector<uint8_t> mask(n, 0);
         for (size_t i = 0; i < n; ++i) {
-            const size_t c = matchData.vec_inliers[i];
-            for (int r = 0; r < 3; ++r) X[3 * i + r] = matchData.pt3D(r, c);
-            x[2 * i] = matchData.pt2D(0, c);
-            x[2 * i + 1] = matchData.pt2D(1, c);
+            for (int r = 0; r < 3; ++r) X[3 * i + r] = matchData.pt3D(r, i);
+            x[2 * i] = matchData.pt2D(0, i);
+            x[2 * i + 1] = matchData.pt2D(1, i);
         }
+        for (size_t i = 0; i < n_inl; ++i) if (matchData.vec_inliers[i] < n) mask[matchData.vec_inliers[i]] = 1;
         double Kd[9], Rt0[12], Rt[12], cov[36], r = 0.0;
         intrinsics(cam, Kd);
         const openMVG::Vec3 t = pose.translation();
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Rt0[4 * i + j] = pose.rotation()(i, j); Rt0[4 * i + 3] = t[i]; }
         int its = 0;
-        const int rc = clc_pnp_refine(ctx_, X.data(), x.data(), static_cast<int>(n), Kd, nullptr, Rt0, 16.0, 50, Rt, cov, &r, &its);
+        const int rc = clc_pnp_refine(ctx_, X.data(), x.data(), static_cast<int>(n), Kd, mask.data(), Rt0, 16.0, 50, Rt, cov, &r, &its);
         const bool refineStatus = rc == CLC_OK;
         if (refineStatus) {
             pose = pose_from_Rt(Rt);
             for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) poseCovariance(i, j) = cov[6 * i + j];
         }
-        // mean pixel distance of the reprojected inliers (Localizer.hpp:141-170: zero distortion, fy = fx)
-        const openMVG::Vec3 tt = pose.translation();
-        double error = 0.0;
-        for (size_t i = 0; i < n; ++i) {
-            double pc[3];
-            for (int a = 0; a < 3; ++a)
-                pc[a] = pose.rotation()(a, 0) * X[3 * i] + pose.rotation()(a, 1) * X[3 * i + 1] + pose.rotation()(a, 2) * X[3 * i + 2] + tt[a];
-            const double u = Kd[0] * pc[0] / pc[2] + Kd[2], v = Kd[0] * pc[1] / pc[2] + Kd[5];
-            error += std::sqrt((x[2 * i] - u) * (x[2 * i] - u) + (x[2 * i + 1] - v) * (x[2 * i + 1] - v));
-        }
-        rmse = static_cast<float>(error / static_cast<double>(n));
+        rmse = mean_reprojection(pose, Kd, matchData);
         return refineStatus;
     }
 

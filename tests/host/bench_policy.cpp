@@ -7,12 +7,14 @@
 // What this measures is what coloc_node would link against: host buffers in, OpenMVG-shaped regions / matches / pose out, every copy,
 // allocation and synchronisation of the policy classes included -- next to bench.py's device-resident headline, never instead of it.
 // Images come from memory (what detectFeaturesTopic hands over, GPUDetector.hpp:188-212): the reference's file variant also times
-// cv::imread, which is not ours to speed up.  Frames: camera 1 and camera 0 alternate (mainThread's `for i < 2`), the map is camera 0's
-// first frame with the 3-D points the harness (tests/test_gpu_policy_bench.py, bench.py) computed for its features.
+// cv::imread, which is not ours to speed up.  Frames: camera 1 and camera 0 alternate (mainThread's `for i < 2`); the map is a THIRD view
+// of the scene (cam_map.pgm: a keyframe's features) with the 3-D points the harness (tests/test_gpu_policy_bench.py, bench.py) computed
+// for its features, so that both cameras track the map through a few hundred matches like a real frame does.
 // usage: bench_policy <dir> <width> <height> <focal> <ppx> <ppy> <frames> <warmup> [maxkp]
 // prints ONE line: POLICY {json}
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,11 +64,12 @@ int main(int argc, char** argv)
     Mat3 K; K(0, 0) = f; K(1, 1) = f; K(0, 2) = ppx; K(1, 2) = ppy; K(2, 2) = 1.0;
     coloc::colocParams params({ K, K }, { Vec3(0, 0, 0), Vec3(0, 0, 0) }, 'E', { (size_t)w, (size_t)h }, dir, dopts, mopts);
 
-    std::vector<uint8_t> img[2];
-    for (int c = 0; c < 2; ++c) {
+    std::vector<uint8_t> img[3];
+    const char* names[3] = { "/cam0.pgm", "/cam1.pgm", "/cam_map.pgm" };
+    for (int c = 0; c < 3; ++c) {
         int iw = 0, ih = 0;
-        if (!coloc::hip_detail::read_pgm(dir + "/cam" + std::to_string(c) + ".pgm", img[c], iw, ih) || (unsigned)iw != w || (unsigned)ih != h) {
-            std::fprintf(stderr, "cannot read cam%d.pgm\n", c);
+        if (!coloc::hip_detail::read_pgm(dir + names[c], img[c], iw, ih) || (unsigned)iw != w || (unsigned)ih != h) {
+            std::fprintf(stderr, "cannot read %s\n", names[c]);
             return 1;
         }
     }
@@ -78,19 +81,22 @@ int main(int argc, char** argv)
         if (e[0] == 't') matcher.trustPublishedRegions(true);
     }
     coloc::colocData data;
-    // the map: camera 0's first frame + the 3-D points under its features (initMap's outcome, coloc.hpp:150-194)
-    if (detector.detectFeaturesImage(0, data.regions, img[0].data(), (int)w, (int)h) != EXIT_SUCCESS) { std::fprintf(stderr, "detect failed\n"); return 1; }
-    const std::vector<double> X = slurp(dir + "/map_xyz.bin");
-    if (X.size() != 3 * data.regions[0]->RegionCount()) {
-        std::fprintf(stderr, "map_xyz.bin holds %zu points, camera 0 has %zu features\n", X.size() / 3, data.regions[0]->RegionCount());
-        return 1;
-    }
-    data.mapRegions.reset(new features::AKAZE_Binary_Regions);
-    for (size_t i = 0; i < data.regions[0]->RegionCount(); ++i) {
-        data.mapRegions->Features().push_back(data.regions[0]->Features()[i]);
-        data.mapRegions->Descriptors().push_back(data.regions[0]->Descriptors()[i]);
-        data.scene.structure[(IndexT)i].X = Vec3(X[3 * i], X[3 * i + 1], X[3 * i + 2]);
-        data.mapRegionIdx.push_back((IndexT)i);
+    // the map: the keyframe's features + the 3-D points under them (initMap's outcome, coloc.hpp:150-194)
+    {
+        coloc::FeatureMap key;
+        if (detector.detectFeaturesImage(0, key, img[2].data(), (int)w, (int)h) != EXIT_SUCCESS) { std::fprintf(stderr, "detect failed\n"); return 1; }
+        const std::vector<double> X = slurp(dir + "/map_xyz.bin");
+        if (X.size() != 3 * key[0]->RegionCount()) {
+            std::fprintf(stderr, "map_xyz.bin holds %zu points, the keyframe has %zu features\n", X.size() / 3, key[0]->RegionCount());
+            return 1;
+        }
+        data.mapRegions.reset(new features::AKAZE_Binary_Regions);
+        for (size_t i = 0; i < key[0]->RegionCount(); ++i) {
+            data.mapRegions->Features().push_back(key[0]->Features()[i]);
+            data.mapRegions->Descriptors().push_back(key[0]->Descriptors()[i]);
+            data.scene.structure[(IndexT)i].X = Vec3(X[3 * i], X[3 * i + 1], X[3 * i + 2]);
+            data.mapRegionIdx.push_back((IndexT)i);
+        }
     }
     matcher.setMapData((int)data.mapRegions->RegionCount(), const_cast<void*>(static_cast<const void*>(data.mapRegions->DescriptorRawData())));
 
@@ -127,6 +133,46 @@ int main(int argc, char** argv)
             kp[droneId] = data.regions[droneId]->RegionCount(); n_map[droneId] = mapMatches.size(); n_inl[droneId] = inliers.size();
         }
     }
+    // where detect_us goes: HIPDetector::detectFeaturesImage's own steps spelled out on a context of its own, each between two clock reads
+    // (the C entry: image into the pinned block, enqueue, the frame's synchronisation | keypoints + features | freeing the last frame's
+    //  regions, room for the new ones | the descriptors' one copy, folded and published)
+    std::vector<double> t_view;
+    double bd[4] = { 0, 0, 0, 0 };
+    {
+        clc_detector_opts d{ dopts.scale_factor, dopts.scale_levels, dopts.width, dopts.height, dopts.maxkp, dopts.thresh };
+        clc_ctx* raw = nullptr;
+        if (clc_ctx_create(0, &d, nullptr, &raw) == CLC_OK) {
+            coloc::FeatureMap fm;
+            std::vector<Keypoint> kv;
+            float ls[256];
+            for (int l = 0; l < 256; ++l) ls[l] = static_cast<float>(std::pow(static_cast<double>(1.2f), static_cast<double>(l)));
+            for (int it = 0; it < warmup + frames; ++it) {
+                const clc_keypoint* pk = nullptr; const uint8_t* pd = nullptr; int n = 0, found = 0;
+                const clk::time_point a = clk::now();
+                if (clc_detect_and_describe_view(raw, img[(it & 1) ? 0 : 1].data(), w, h, &pk, &pd, &n, &found) != CLC_OK) ++failures;
+                const clk::time_point b = clk::now();
+                kv.resize((size_t)n);
+                if (n > 0) std::memcpy(static_cast<void*>(kv.data()), pk, (size_t)n * sizeof(Keypoint));
+                const clk::time_point c = clk::now();
+                fm[0] = std::unique_ptr<features::AKAZE_Binary_Regions>(new features::AKAZE_Binary_Regions);
+                fm[0]->Features().resize((size_t)n);
+                fm[0]->Descriptors().resize((size_t)n);
+                for (int i = 0; i < n; ++i) {
+                    const float sc = ls[kv[(size_t)i].scale];
+                    fm[0]->Features()[(size_t)i] = { sc * (float)kv[(size_t)i].x, sc * (float)kv[(size_t)i].y, 7.0f * sc, kv[(size_t)i].angle };
+                }
+                const clk::time_point e = clk::now();
+                if (n > 0 && clc_detect_store_descriptors(raw, fm[0]->Descriptors().data(), n, nullptr) != CLC_OK) ++failures;
+                const clk::time_point g = clk::now();
+                if (it >= warmup) {
+                    t_view.push_back(us(a, g));
+                    bd[0] += us(a, b); bd[1] += us(b, c); bd[2] += us(c, e); bd[3] += us(e, g);
+                }
+            }
+            clc_ctx_destroy(raw);
+        }
+        for (double& v : bd) v /= frames > 0 ? frames : 1;
+    }
     // the pair match of initMap (coloc.hpp:161-164) on the two cameras' last frames
     size_t n_pair = 0;
     for (int it = 0; it < warmup / 4 + frames / 4 + 4; ++it) {
@@ -146,11 +192,11 @@ int main(int argc, char** argv)
     }
     std::printf("POLICY {\"frames\": %d, \"warmup\": %d, \"width\": %u, \"height\": %u, \"keypoints\": [%zu, %zu], \"map_points\": %zu, "
                 "\"map_matches\": [%zu, %zu], \"pose_inliers\": [%zu, %zu], \"pair_matches\": %zu, "
-                "\"detect_us\": %.1f, \"detect_us_p95\": %.1f, \"match_us\": %.1f, \"match_us_p95\": %.1f, \"pose_us\": %.1f, \"pose_us_p95\": %.1f, "
+                "\"detect_us\": %.1f, \"detect_us_p95\": %.1f, \"detect_steps_us\": {\"total_p50\": %.1f, \"c_entry_image_in_to_results_in_pinned_memory\": %.1f, \"keypoints_copy\": %.1f, \"regions_and_features\": %.1f, \"descriptor_copy_publish\": %.1f}, \"match_us\": %.1f, \"match_us_p95\": %.1f, \"pose_us\": %.1f, \"pose_us_p95\": %.1f, "
                 "\"frame_us\": %.1f, \"frame_us_p95\": %.1f, \"pair_match_us\": %.1f, \"pair_match_us_p95\": %.1f, \"failures\": %d, "
                 "\"same_results_every_frame\": %s}\n",
                 frames, warmup, w, h, kp[0], kp[1], data.mapRegions->RegionCount(), n_map[0], n_map[1], n_inl[0], n_inl[1], n_pair,
-                pct(t_detect, 0.5), pct(t_detect, 0.95), pct(t_match, 0.5), pct(t_match, 0.95), pct(t_pose, 0.5), pct(t_pose, 0.95),
+                pct(t_detect, 0.5), pct(t_detect, 0.95), pct(t_view, 0.5), bd[0], bd[1], bd[2], bd[3], pct(t_match, 0.5), pct(t_match, 0.95), pct(t_pose, 0.5), pct(t_pose, 0.95),
                 pct(t_frame, 0.5), pct(t_frame, 0.95), pct(t_pair, 0.5), pct(t_pair, 0.95), failures, failures == 0 ? "true" : "false");
     return failures == 0 ? 0 : 3;
 }
