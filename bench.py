@@ -132,7 +132,10 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
     step()
     fence()
     want = d_match[:n_out].clone()
-    for leg, mode in (("clc-rccl", 0), ("clc-peer", 1)):
+    # clc-rccl-overlap (round 6): the same exchange with step k + 1's describe + exchange on one stream and step k's sweep on another
+    # (clc_mc_set_overlap: three arena buffers, two event chains); same matches, timed the same way
+    for leg, mode in (("clc-rccl", 0), ("clc-peer", 1), ("clc-rccl-overlap", 0)):
+        overlap = leg.endswith("-overlap")
         if mc_headline is not None and args.exchange == leg:
             out[leg] = {"note": "this is the headline exchange of this run"}
             continue
@@ -155,6 +158,11 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
                 mcx = MultiCam(ctx, world=world, rank=rank, maxkp=NKP, unique_id=box[0])
             except Exception as exc:
                 err = "create: " + repr(exc)
+        if err is None and overlap:
+            try:
+                mcx.set_overlap(True)
+            except Exception as exc:
+                err = "set_overlap: " + repr(exc)
         if not all_ok(err is None):
             out[leg] = {"error": err or "another rank could not create its handle"}
         else:
@@ -167,6 +175,15 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
                 out[leg] = {"error": err or "another rank could not map the peers' arenas"}
             else:
                 got = torch.full_like(d_match, -9)
+                sweep_stream = torch.cuda.Stream(device=dev) if overlap else None
+                sweep_ptr = sweep_stream.cuda_stream if overlap else sptr
+                # what RCCL says about the communicator each rank holds (ncclCommCount, ncclCommUserRank): (0, -1) on rehearsal handles
+                try:
+                    info = mcx.comm_info()
+                except Exception as exc:
+                    info = "comm_info: " + repr(exc)
+                infos = [None] * world
+                dist.all_gather_object(infos, info)
 
                 def leg_step():
                     ctx.describe_batch_dev(img_ptrs, W, H, W, kp_ptrs, [NKP], [mine.data_ptr()], sptr)
@@ -175,7 +192,7 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
                             if o != rank:
                                 mcx.virtual_put(o, arena[o].data_ptr(), counts[o], stream=sptr)
                     mcx.gather_enqueue_dev(mine.data_ptr(), NKP, mode=mode, stream=sptr)
-                    mcx.match_enqueue_dev(THR, got.data_ptr(), got.numel(), stream=sptr)
+                    mcx.match_enqueue_dev(THR, got.data_ptr(), got.numel(), stream=sweep_ptr)
                 dtk, pf = 0.0, None
                 try:
                     for _ in range(3):
@@ -210,7 +227,9 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
                 out[leg] = {"us_per_step": float(t[0].item()) / args.steps * 1e6, "identical": bool(t[1].item() == 0.0),
                             "steps": args.steps, "seconds_max_over_ranks": float(t[0].item()), "sweep_prof_rank0": list(pf) if pf else None,
                             "exchange": ("ncclAllGather" if mode == 0 else "IPC peer copies + 4-byte fence all-gather") if real
-                                        else "REHEARSAL handle (blocks filed with clc_mc_virtual_put)"}
+                                        else "REHEARSAL handle (blocks filed with clc_mc_virtual_put)",
+                            "rccl_ranks": infos,           # per rank: [ncclCommCount, ncclCommUserRank] of the handle's communicator
+                            "overlapped_steps": overlap}
                 if err:
                     out[leg]["error"] = err
                 elif t[2].item() != 0.0:
@@ -248,6 +267,9 @@ def main():
                          "become the headline (the torch figure stays in `torch_exchange`), otherwise the torch measurement stands and "
                          "`collective_fallback` says why.  torch: never promote.  clc-rccl / clc-peer: drive the product's exchange from the "
                          "first step on (no fallback).")
+    ap.add_argument("--overlap-steps", action="store_true",
+                    help="N > 1: promote the OVERLAPPED form of the product's exchange (clc_mc_set_overlap: step k + 1's describe + exchange "
+                         "beside step k's sweep, leg clc-rccl-overlap) to the headline instead of the one-stream form; default off")
     ap.add_argument("--no-exchange-legs", action="store_true",
                     help="N > 1 only: skip the informational legs that run the same step through clc-rccl and clc-peer and compare the matches")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (N=1 only; no in-region events; implies --one-stream)")
@@ -575,17 +597,20 @@ def main():
     # ---- promotion: the product's exchange becomes the headline when it ran, agreed with the torch step on every rank and was timed ---
     torch_exchange, collective_fallback, promoted = None, None, None
     if world > 1 and args.exchange == "auto" and mc is None:
-        leg = (exchange_legs or {}).get("clc-rccl") if isinstance(exchange_legs, dict) else None
+        # --overlap-steps (default off until a multi-GPU node has measured it): the overlapped form of the product's exchange is the
+        # candidate instead -- under the same conditions (ran, agreed with the torch step on every rank, was timed)
+        leg_name = "clc-rccl-overlap" if args.overlap_steps else "clc-rccl"
+        leg = (exchange_legs or {}).get(leg_name) if isinstance(exchange_legs, dict) else None
         if args.no_exchange_legs:
             collective_fallback = "--no-exchange-legs: the product's exchange was not attempted"
         elif not isinstance(leg, dict):
             collective_fallback = "the exchange legs did not run: %r" % (exchange_legs,)
         elif leg.get("error"):
-            collective_fallback = "clc-rccl: " + str(leg["error"])
+            collective_fallback = leg_name + ": " + str(leg["error"])
         elif leg.get("identical") is not True:
-            collective_fallback = "clc-rccl: matches differ from the torch exchange's"
+            collective_fallback = leg_name + ": matches differ from the torch exchange's"
         elif not leg.get("seconds_max_over_ranks"):
-            collective_fallback = "clc-rccl: no timed region"
+            collective_fallback = leg_name + ": no timed region"
         else:
             promoted = leg
             torch_exchange = {"collective": "RCCL all_gather_into_tensor (torch.distributed)" if args.backend == "nccl" else "REHEARSAL: gloo all_gather staged through host memory",

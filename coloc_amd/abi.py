@@ -83,7 +83,7 @@ EXPORTS = [
     "clc_essential_fivepoint", "clc_describe_batch_dev", "clc_match_map_dev", "clc_k2nn_set_formulation",
     "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_k2nn_device_info", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
-    "clc_mc_gather_enqueue_dev", "clc_mc_match_enqueue_dev", "clc_mc_counts", "clc_match_jobs_counted_dev",
+    "clc_mc_gather_enqueue_dev", "clc_mc_match_enqueue_dev", "clc_mc_counts", "clc_mc_set_overlap", "clc_mc_comm_info", "clc_match_jobs_counted_dev",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -207,6 +207,8 @@ def load_library():
     lib.clc_mc_gather_enqueue_dev.argtypes = [vp, vp, ci, vp, ci, vp]
     lib.clc_mc_match_enqueue_dev.argtypes = [vp, ci, vp, ci, vp, ci, ip, vp]
     lib.clc_mc_counts.argtypes = [vp, vp, vp]
+    lib.clc_mc_set_overlap.argtypes = [vp, ci]
+    lib.clc_mc_comm_info.argtypes = [vp, ip, ip]
     lib.clc_match_jobs_counted_dev.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp]
     lib.clc_k2nn_clock_check.argtypes = [vp, vp, ci, vp, ci, vp, vp, dp, dp, dp, ip]
     lib.clc_k2nn_set_formulation.argtypes = [vp, ci]
@@ -371,6 +373,16 @@ class MultiCam:
         n = C.c_int()
         self._chk(self.lib.clc_mc_match_enqueue_dev(self.h, int(threshold), d_match, int(capacity), sh, cap, C.byref(n), stream))
         return [(s.first, s.second, s.q_begin, s.nq, s.out_offset) for s in sh[:n.value]]
+
+    def set_overlap(self, on=True):
+        """clc_mc_set_overlap: exchange (+ the caller's describe) on one stream, the sweep on another; before the first exchange."""
+        self._chk(self.lib.clc_mc_set_overlap(self.h, 1 if on else 0))
+
+    def comm_info(self):
+        """(ncclCommCount, ncclCommUserRank) of the communicator behind the handle; (0, -1): none."""
+        n, r = C.c_int(), C.c_int()
+        self._chk(self.lib.clc_mc_comm_info(self.h, C.byref(n), C.byref(r)))
+        return int(n.value), int(r.value)
 
     def counts(self, stream=None):
         cnt = (C.c_int * self.world)()

@@ -19,6 +19,16 @@
 // completes only when EVERY rank has joined it, i.e. has its step-k sweep (enqueued earlier on the same stream) behind
 // it.  So the skew between ranks is bounded to one step and no copy ever lands in a buffer a sweep still reads.  Every
 // rank must call the gather the same number of times (the parity is a local call count).
+// OVERLAPPED steps (round 6, clc_mc_set_overlap; default off): step k + 1's exchange -- and the describe the caller enqueues in front of
+// it -- runs on ONE stream while step k's sweep runs on ANOTHER.  All collectives stay on the exchange stream (one communicator is
+// enough: a rank's collectives keep their order), the sweep has none.  The arena then has THREE buffers, buffer j % 3 for step j, and
+// two event chains carry the ordering the single stream gave for free:
+//   sweep j waits for exchange j (event behind the exchange);
+//   exchange j waits for sweep j - 2 (event behind that sweep) before it enqueues anything.
+// Why that is enough, peer copies included: buffer j % 3 was last read by sweep j - 3, which precedes sweep j - 2 on the sweep stream.
+// A peer's copy of step j into this rank's buffer is enqueued behind the peer's count collective of step j - 1, which completes only
+// when THIS rank has joined it -- on its exchange stream, behind its wait for sweep (j - 1) - 2 = j - 3.  With two buffers the same
+// argument would need exchange j to wait for sweep j - 1, i.e. no overlap.
 // RCCL is resolved at run time (dlopen "librccl.so.1": the copy the process already has, e.g. PyTorch's, or the
 // system one) and its handful of types is declared here, so libcoloc_hip.so needs neither the RCCL headers to build
 // nor the library to load, and single-GPU hosts never touch it.
@@ -54,6 +64,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -71,6 +83,8 @@ Rccl& rccl()
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
     return r;
@@ -87,9 +101,14 @@ struct clc_mc {
     clc_ctx* ctx = nullptr;
     int world = 1, rank = 0, cap = 0, device = 0;
     ncclComm_t comm = nullptr;
-    uint8_t* d_arena = nullptr;            // [2][world][cap][64]: buffer (step & 1) receives step's blocks
-    int32_t* d_counts = nullptr;           // [2][world + 1]: the gathered counts of a buffer, this rank's own count at [world]
-    int32_t* h_counts = nullptr;           // pinned, [2][world + 1]: host mirror of the gathered counts (written by the device only)
+    int nbuf = 2;                          // arena buffers: 2 (steps on one stream), 3 (overlapped steps)
+    uint8_t* d_arena = nullptr;            // [nbuf][world][cap][64]: buffer (step % nbuf) receives step's blocks
+    int32_t* d_counts = nullptr;           // [nbuf][world + 1]: the gathered counts of a buffer, this rank's own count at [world]
+    int32_t* h_counts = nullptr;           // pinned, [nbuf][world + 1]: host mirror of the gathered counts (written by the device only)
+    bool overlap = false;                  // exchange and sweep on different streams (clc_mc_set_overlap)
+    hipEvent_t ev_exch[3] = {}, ev_sweep[3] = {};   // behind the exchange / the sweep of the step a buffer holds
+    long exch_step[3] = { -1, -1, -1 }, sweep_step[3] = { -1, -1, -1 };   // which step those events stand for (-1: none recorded)
+    long steps = 0;                        // exchanges enqueued so far = the number of the next step
     int fill = 0;                          // buffer the NEXT gather (and clc_mc_virtual_put) writes
     int cur = 0;                           // buffer of the last completed gather: what the match entries sweep
     bool counts_on_host = false;           // the last gather synchronised and left the counts in h_counts[cur]
@@ -114,6 +133,23 @@ int mc_fail(clc_mc* mc, int code, const char* what, hipError_t e = hipSuccess, n
 }
 #define MC_HIP(mc, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return mc_fail((mc), CLC_ERR_HIP, #call, e__); } while (0)
 #define MC_NCCL(mc, call) do { ncclResult_t n__ = (call); if (n__ != ncclSuccess) return mc_fail((mc), CLC_ERR_HIP, #call, hipSuccess, n__); } while (0)
+
+// the arena and the count rows for mc->nbuf buffers (again after clc_mc_set_overlap)
+int mc_alloc(clc_mc* mc)
+{
+    if (mc->d_arena) (void)hipFree(mc->d_arena);
+    if (mc->d_counts) (void)hipFree(mc->d_counts);
+    if (mc->h_counts) (void)hipHostFree(mc->h_counts);
+    mc->d_arena = nullptr; mc->d_counts = nullptr; mc->h_counts = nullptr;
+    const size_t nb = (size_t)mc->nbuf, rows = sizeof(int32_t) * (size_t)(mc->world + 1);
+    MC_HIP(mc, hipMalloc((void**)&mc->d_arena, nb * (size_t)mc->world * (size_t)mc->cap * CLC_DESC_BYTES));
+    MC_HIP(mc, hipMalloc((void**)&mc->d_counts, nb * rows));
+    MC_HIP(mc, hipMemset(mc->d_counts, 0, nb * rows));
+    MC_HIP(mc, hipHostMalloc((void**)&mc->h_counts, nb * rows, hipHostMallocDefault));
+    memset(mc->h_counts, 0, nb * rows);
+    mc->fill = 0; mc->cur = 0;
+    return CLC_OK;
+}
 
 // exchange the arenas' IPC handles once (through the communicator itself) and map the peers' arenas
 int open_peers(clc_mc* mc, hipStream_t st)
@@ -216,12 +252,40 @@ int clc_mc_create(clc_ctx* ctx, const uint8_t id[CLC_MC_ID_BYTES], int world, in
         memcpy(u.internal, id, CLC_MC_ID_BYTES);
         if (rccl().CommInitRank(&mc->comm, world, u, rank) != ncclSuccess) return bail(CLC_ERR_HIP);
     }
-    if (hipMalloc((void**)&mc->d_arena, 2 * (size_t)world * (size_t)maxkp * CLC_DESC_BYTES) != hipSuccess) return bail(CLC_ERR_HIP);
-    if (hipMalloc((void**)&mc->d_counts, 2 * sizeof(int32_t) * (size_t)(world + 1)) != hipSuccess) return bail(CLC_ERR_HIP);
-    if (hipMemset(mc->d_counts, 0, 2 * sizeof(int32_t) * (size_t)(world + 1)) != hipSuccess) return bail(CLC_ERR_HIP);
-    if (hipHostMalloc((void**)&mc->h_counts, 2 * sizeof(int32_t) * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess) return bail(CLC_ERR_HIP);
-    memset(mc->h_counts, 0, 2 * sizeof(int32_t) * (size_t)(world + 1));
+    const int rc = mc_alloc(mc);
+    if (rc != CLC_OK) return bail(rc);
     *out = mc;
+    return CLC_OK;
+}
+
+int clc_mc_set_overlap(clc_mc* mc, int on)
+{
+    if (!mc) return CLC_ERR_BAD_ARG;
+    if (mc->steps != 0 || !mc->peer_arena.empty()) return mc_fail(mc, CLC_ERR_STATE, "mc_set_overlap: only before the first exchange (and before clc_mc_open_peers)");
+    if ((on != 0) == mc->overlap) return CLC_OK;
+    MC_HIP(mc, hipSetDevice(mc->device));
+    MC_HIP(mc, hipDeviceSynchronize());
+    mc->overlap = on != 0;
+    mc->nbuf = mc->overlap ? 3 : 2;
+    if (mc->overlap)
+        for (int b = 0; b < 3; ++b) {
+            if (!mc->ev_exch[b]) MC_HIP(mc, hipEventCreateWithFlags(&mc->ev_exch[b], hipEventDisableTiming));
+            if (!mc->ev_sweep[b]) MC_HIP(mc, hipEventCreateWithFlags(&mc->ev_sweep[b], hipEventDisableTiming));
+        }
+    return mc_alloc(mc);
+}
+
+int clc_mc_comm_info(const clc_mc* mc, int* n_ranks, int* user_rank)
+{
+    if (!mc) return CLC_ERR_BAD_ARG;
+    if (n_ranks) *n_ranks = 0;                       // 0: no communicator behind this handle (one rank without an id, or a rehearsal handle)
+    if (user_rank) *user_rank = -1;
+    if (!mc->comm) return CLC_OK;
+    if (!rccl().CommCount || !rccl().CommUserRank) return CLC_ERR_STATE;
+    int n = 0, r = -1;
+    if (rccl().CommCount(mc->comm, &n) != ncclSuccess || rccl().CommUserRank(mc->comm, &r) != ncclSuccess) return CLC_ERR_HIP;
+    if (n_ranks) *n_ranks = n;
+    if (user_rank) *user_rank = r;
     return CLC_OK;
 }
 
@@ -232,6 +296,7 @@ int clc_mc_destroy(clc_mc* mc)
     for (int p = 0; p < (int)mc->peer_arena.size(); ++p)
         if (p != mc->rank && mc->peer_arena[(size_t)p]) (void)hipIpcCloseMemHandle(mc->peer_arena[(size_t)p]);
     if (mc->comm && rccl().ok) (void)rccl().CommDestroy(mc->comm);
+    for (int b = 0; b < 3; ++b) { if (mc->ev_exch[b]) (void)hipEventDestroy(mc->ev_exch[b]); if (mc->ev_sweep[b]) (void)hipEventDestroy(mc->ev_sweep[b]); }
     if (mc->d_arena) (void)hipFree(mc->d_arena);
     if (mc->d_counts) (void)hipFree(mc->d_counts);
     if (mc->h_counts) (void)hipHostFree(mc->h_counts);
@@ -255,6 +320,13 @@ static int mc_exchange(clc_mc* mc, const void* d_my_desc, int my_count, const in
 {
     const size_t block = (size_t)mc->cap * CLC_DESC_BYTES, buf = (size_t)mc->world * block;
     const int b = mc->fill;
+    const long step = mc->steps;
+    if (mc->overlap && step >= 2) {
+        // nothing of step `step` is enqueued before the sweep of step - 2 has ended (top of this file)
+        // (every recorded sweep up to step - 2: a caller that skipped a step's sweep still gets the buffer it is about to fill back)
+        for (int bw = 0; bw < 3; ++bw)
+            if (mc->sweep_step[bw] >= 0 && mc->sweep_step[bw] <= step - 2) MC_HIP(mc, hipStreamWaitEvent(st, mc->ev_sweep[bw], 0));
+    }
     uint8_t* arena = mc->d_arena + (size_t)b * buf;
     int32_t* d_cnt = mc->d_counts + (size_t)b * (size_t)(mc->world + 1);
     int32_t* h_cnt = mc->h_counts + (size_t)b * (size_t)(mc->world + 1);
@@ -289,8 +361,10 @@ static int mc_exchange(clc_mc* mc, const void* d_my_desc, int my_count, const in
     }
     // the host mirror of the counts travels behind the exchange; whoever needs it synchronises the stream first
     MC_HIP(mc, hipMemcpyAsync(h_cnt, d_cnt, sizeof(int32_t) * (size_t)mc->world, hipMemcpyDeviceToHost, st));
+    if (mc->overlap) { MC_HIP(mc, hipEventRecord(mc->ev_exch[b], st)); mc->exch_step[b] = step; }
     mc->cur = b;
-    mc->fill = b ^ 1;
+    mc->fill = (b + 1) % mc->nbuf;
+    mc->steps = step + 1;
     return CLC_OK;
 }
 
@@ -347,6 +421,7 @@ int clc_mc_virtual_put(clc_mc* mc, int other_rank, const void* d_desc, int count
     hipStream_t st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
     // plays another rank's part of the NEXT exchange: its block and count go where that rank's copy / collective would put them
     const size_t block = (size_t)mc->cap * CLC_DESC_BYTES;
+    if (mc->overlap && mc->sweep_step[mc->fill] >= 0) MC_HIP(mc, hipStreamWaitEvent(st, mc->ev_sweep[mc->fill], 0));   // (a real peer's copy comes behind the collective chain)
     if (count > 0)
         MC_HIP(mc, hipMemcpyAsync(mc->d_arena + ((size_t)mc->fill * (size_t)mc->world + (size_t)other_rank) * block, d_desc,
                                   (size_t)count * CLC_DESC_BYTES, hipMemcpyDeviceToDevice, st));
@@ -387,12 +462,15 @@ static int mc_sweep(clc_mc* mc, const std::vector<int>& counts, bool device_coun
     *n_shares = n;
     if (n == 0) return CLC_OK;
     const uint8_t* arena = mc->d_arena + (size_t)mc->cur * (size_t)mc->world * (size_t)mc->cap * CLC_DESC_BYTES;
+    hipStream_t sweep_st = stream ? (hipStream_t)stream : (hipStream_t)clc_stream(mc->ctx);
+    if (mc->overlap && mc->exch_step[mc->cur] >= 0) MC_HIP(mc, hipStreamWaitEvent(sweep_st, mc->ev_exch[mc->cur], 0));
     if (device_counts) {
         std::vector<uint32_t> row0((size_t)n);
         for (int k = 0; k < n; ++k) row0[(size_t)k] = shares[(size_t)k].q_begin;
         rc = clc_match_jobs_counted_dev(mc->ctx, arena, jobs.data(), n, cq.data(), ct.data(), row0.data(), d_match, stream);
     } else rc = clc_match_jobs_dev(mc->ctx, arena, jobs.data(), n, d_match, stream);
     if (rc != CLC_OK) return mc_fail(mc, rc, clc_last_error_string(mc->ctx));
+    if (mc->overlap) { MC_HIP(mc, hipEventRecord(mc->ev_sweep[mc->cur], sweep_st)); mc->sweep_step[mc->cur] = mc->exch_step[mc->cur]; }
     return CLC_OK;
 }
 

@@ -451,6 +451,16 @@ int clc_mc_gather_enqueue_dev(clc_mc* mc, const void* d_my_desc, int my_count, c
 int clc_mc_match_enqueue_dev(clc_mc* mc, int threshold, int32_t* d_match, int match_capacity, clc_mc_share* h_shares,
                              int share_capacity, int* n_shares, void* stream);
 int clc_mc_counts(clc_mc* mc, int* h_counts_out, void* stream);
+/* OVERLAPPED steps (round 6; default off, call before the handle's first exchange and before clc_mc_open_peers): the caller passes one
+ * stream to clc_mc_gather_enqueue_dev -- and enqueues its describe on it -- and ANOTHER to clc_mc_match_enqueue_dev; step k + 1's
+ * describe + exchange then run beside step k's sweep.  The handle keeps three arena buffers and orders the two streams with events
+ * (sweep k behind exchange k; exchange k behind sweep k - 2); all collectives stay on the exchange stream, so one communicator serves.
+ * Results are those of the one-stream step.  The context's front-end work (pyramid, CLATCH) must be enqueued on the exchange stream and
+ * nothing but the sweep on the other one: a context's matcher workspace and its detector workspace are separate. */
+int clc_mc_set_overlap(clc_mc* mc, int on);
+/* What RCCL itself says about the communicator behind the handle: *n_ranks = ncclCommCount, *user_rank = ncclCommUserRank
+ * (*n_ranks == 0: the handle has no communicator -- one rank without an id, or a rehearsal handle). */
+int clc_mc_comm_info(const clc_mc* mc, int* n_ranks, int* user_rank);
 
 /* ---- a-contrario model selection: what the reference actually runs ------------------------------------------------------
  * Localizer::localizeImage calls SfM_Localizer::Localize(P3P_KE_CVPR17, ..., {error_max = +inf, max_iteration = 256})

@@ -77,9 +77,12 @@ def _check_two_rank_line(d):
     # the guarded legs that run the same step through the C multi-camera entry points (clc-rccl / clc-peer at N > 1; rehearsal handles
     # here: the ranks share the one GPU) went through their whole control flow and reproduced the headline exchange's matches
     legs = d["exchange_legs"]
-    assert set(legs) == {"clc-rccl", "clc-peer"}
-    for leg in legs.values():
+    assert set(legs) == {"clc-rccl", "clc-peer", "clc-rccl-overlap"}
+    for name, leg in legs.items():
         assert leg["identical"] is True and leg["us_per_step"] > 0 and "error" not in leg and leg["steps"] == d["steps"]
+        # round 6: every leg records what RCCL says about each rank's communicator (rehearsal handles have none: [0, -1]) and whether
+        # its steps were overlapped (step k + 1's describe + exchange beside step k's sweep: same matches)
+        assert leg["rccl_ranks"] == [[0, -1], [0, -1]] and leg["overlapped_steps"] is (name == "clc-rccl-overlap")
     assert d["value_cold"] > 0 and d["warmup_effective"] >= d["warmup"]
     # round 5: the product's exchange, having agreed with the torch step on both ranks, IS the headline: its K timed steps give value /
     # ms_per_step, the torch exchange's figure stays beside it, nothing fell back; and the line says what an efficiency against N = 1 means
@@ -116,6 +119,12 @@ def test_two_rank_rehearsal_runs():
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
     _check_two_rank_line(_last_json(out.stdout))
+    # --overlap-steps: the overlapped form of the product's exchange is promoted instead (default off until a multi-GPU node measured it)
+    out = subprocess.run(cmd + ["--overlap-steps"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    d = _last_json(out.stdout)
+    assert d["collective_fallback"] is None and abs(d["ms_per_step"] - d["exchange_legs"]["clc-rccl-overlap"]["us_per_step"] / 1e3) < 1e-9
+    assert d["exchange_legs"]["clc-rccl-overlap"]["identical"] is True
     # --exchange torch: never promote -- the torch exchange is the headline, the legs stay informational
     out = subprocess.run(cmd + ["--exchange", "torch"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=280)
     assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]

@@ -270,3 +270,119 @@ def test_host_counts_of_four_steps_enqueued_behind_a_backed_up_stream(oracle):
             assert (res[off + valid:off + nq] == -1).all()
     mc.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_config3_at_size_eight_cameras_of_ten_thousand_keypoints(oracle, overlap):
+    """BASELINE config[3] AT SIZE on one GPU: 8 cameras x 10 000 descriptors, all 28 (first < second) pairs = 2.8e9
+    comparisons, every rank of the virtual world through clc_mc_gather_enqueue_dev + clc_mc_match_enqueue_dev (rehearsal handles: the
+    other ranks' blocks filed in place of the RCCL all-gather), over THREE steps of different descriptors so that every arena buffer is
+    used and re-used -- one-stream steps and OVERLAPPED steps (clc_mc_set_overlap: step k + 1's exchange on one stream beside step k's
+    sweep on another, three buffers, two event chains).  Reassembled over the ranks, every pair of every step must be the serial
+    all-pairs loop's result (GPUMatcher.hpp:143-155) as the OpenMP oracle computes it (checked against the scalar oracle on one pair)."""
+    import torch
+    from coloc_amd import Context, MultiCam
+    world, cap, nsteps = 8, 10000, 3
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    base = synth.random_descriptors(cap, seed=9001)
+    steps = []
+    for s in range(nsteps):
+        descs = []
+        for c in range(world):
+            d = synth.random_descriptors(cap, seed=9100 + 31 * s + c)
+            k = 3000 + 500 * ((c + s) % 4)
+            d[:k] = base[:k]
+            d[:k, (c + 3 * s) % 64] ^= (np.arange(k) % 251).astype(np.uint8)        # near-duplicates across the cameras
+            descs.append(d)
+        steps.append((descs, [torch.from_numpy(d).cuda() for d in descs]))
+    want = []
+    for descs, _ in steps:
+        w = {}
+        for (i, j) in multicam.exhaustive_pairs(world):
+            w[(i, j)], _ = oracle.k2nn_omp(descs[i], descs[j], rule=0, threshold=40)
+        want.append(w)
+    assert np.array_equal(want[0][(2, 5)], oracle.k2nn(steps[0][0][2], steps[0][0][5], 40))     # the OpenMP sweep pinned by the scalar one
+    assert sum(int((m >= 0).sum()) for m in want[0].values()) > 28 * 1500
+    st_x, st_s = torch.cuda.Stream(), torch.cuda.Stream()
+    sweep_stream = st_s if overlap else st_x
+    got = [dict() for _ in range(nsteps)]
+    for r in range(world):
+        mc = MultiCam(ctx, world=world, rank=r, maxkp=cap)
+        if overlap:
+            mc.set_overlap(True)
+        assert mc.comm_info() == (0, -1)                              # a rehearsal handle has no communicator
+        outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in range(nsteps)]
+        shares = []
+        for s, (descs, dev) in enumerate(steps):
+            for o in range(world):
+                if o != r:
+                    mc.virtual_put(o, dev[o].data_ptr(), cap, stream=st_x.cuda_stream)
+            mc.gather_enqueue_dev(dev[r].data_ptr(), cap, mode=0, stream=st_x.cuda_stream)
+            shares.append(mc.match_enqueue_dev(40, outs[s].data_ptr(), cap * world, stream=sweep_stream.cuda_stream))
+        torch.cuda.synchronize()
+        assert abs(sum(nq for (_, _, _, nq, _) in shares[0]) - 28 * cap // world) <= 256           # 3.5 pairs' worth of query rows per rank, to one block
+        for s in range(nsteps):
+            res = outs[s].cpu().numpy()
+            for (a, b, q0, nq, off) in shares[s]:
+                got[s].setdefault((a, b), np.full(cap, -7, np.int32))[q0:q0 + nq] = res[off:off + nq]
+        mc.close()
+    for s in range(nsteps):
+        assert sorted(got[s]) == multicam.exhaustive_pairs(world)
+        for p in got[s]:
+            assert np.array_equal(got[s][p], want[s][p]), (s, p)
+    ctx.close()
+
+
+def test_overlapped_steps_equal_one_stream_steps_with_ragged_counts(oracle):
+    """clc_mc_set_overlap with counts that change every step (read on the device on odd steps), four ranks, six steps: exchange (and the
+    filing of the peers' blocks) on one stream, sweeps on another, no host synchronisation in between -- every step's shares must be the
+    one-stream handle's, hence the oracle's.  And the handle refuses to switch once it has exchanged."""
+    import torch
+    from coloc_amd import Context, MultiCam, CLCError
+    world, cap = 4, 2600
+    counts_by_step = [[2000, 1500, 2500, 1800], [2500, 2500, 0, 2100], [1999, 2001, 2003, 1], [2600, 2600, 2600, 2600], [300, 2600, 17, 900], [2048, 2047, 2049, 1024]]
+    ctx = Context(device=0, width=160, height=120, maxkp=cap, detector=False)
+    st_x, st_s = torch.cuda.Stream(), torch.cuda.Stream()
+    steps = []
+    for s, counts in enumerate(counts_by_step):
+        descs = [synth.random_descriptors(n, seed=7000 + 13 * s + c) for c, n in enumerate(counts)]
+        for c in range(1, world):
+            k = min(len(descs[0]), len(descs[c])) // 2
+            descs[c][:k] = descs[0][:k]
+            if k:
+                descs[c][:k, (c + s) % 64] ^= 0x3C
+        dev = [torch.from_numpy(np.ascontiguousarray(np.concatenate([d, np.full((cap - len(d), 64), 0xA5, np.uint8)]))).cuda() for d in descs]
+        d_cnt = [torch.tensor([n], dtype=torch.int32, device="cuda") for n in counts]
+        steps.append((counts, descs, dev, d_cnt))
+    torch.cuda.synchronize()
+    for r in range(world):
+        results = {}
+        for overlap in (False, True):
+            mc = MultiCam(ctx, world=world, rank=r, maxkp=cap)
+            if overlap:
+                mc.set_overlap(True)
+            outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in steps]
+            shares = []
+            for s, (counts, descs, dev, d_cnt) in enumerate(steps):
+                for o in range(world):
+                    if o != r:
+                        mc.virtual_put(o, dev[o].data_ptr(), counts[o], stream=st_x.cuda_stream)
+                if s % 2 == 0:
+                    mc.gather_enqueue_dev(dev[r].data_ptr(), counts[r], mode=s % 2, stream=st_x.cuda_stream)
+                else:
+                    mc.gather_enqueue_dev(dev[r].data_ptr(), 0, mode=s % 2, stream=st_x.cuda_stream, d_my_count=d_cnt[r].data_ptr())
+                shares.append(mc.match_enqueue_dev(40, outs[s].data_ptr(), cap * world, stream=(st_s if overlap else st_x).cuda_stream))
+            torch.cuda.synchronize()
+            if overlap:
+                with pytest.raises(CLCError):
+                    mc.set_overlap(False)
+            results[overlap] = ([o.cpu().numpy() for o in outs], shares)
+            mc.close()
+        assert results[True][1] == results[False][1]
+        for s, (counts, descs, dev, d_cnt) in enumerate(steps):
+            assert np.array_equal(results[True][0][s], results[False][0][s]), (r, s)
+            for (a, b, q0, nq, off) in results[True][1][s]:
+                want = oracle.k2nn(descs[a], descs[b], 40) if counts[a] and counts[b] else np.full(counts[a], -1, np.int32)
+                valid = max(0, min(nq, counts[a] - q0))
+                assert np.array_equal(results[True][0][s][off:off + valid], want[q0:q0 + valid]), (r, s, a, b)
+    ctx.close()
