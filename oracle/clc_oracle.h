@@ -156,14 +156,14 @@ typedef int (*orc_acr_fit_fn)(void* user, const uint32_t* sample, double* models
  * residual order (capacity N), the precision found (pixels for kind 0), the minimum log10 NFA, the iteration that
  * produced the model and the number of iterations run.  Returns 1 if a meaningful model (NFA < 0) was found. */
 int orc_acransac(int kind, const double* a, const double* b, int n, const double* K1, int img_w, int img_h,
-                 int max_iteration, uint64_t seed, double precision, int use_libm, orc_acr_fit_fn fit, void* user,
+                 int max_iteration, uint64_t seed, double precision, orc_acr_fit_fn fit, void* user,
                  double* model_out, uint32_t* inliers_out, int* n_inliers_out, double* error_max_out, double* min_nfa_out,
                  int32_t* best_iter_out, int32_t* iterations_run_out);
 /* log10 C(n, k) and log10 C(k, m) float tables, k = 0..n */
-void orc_acr_tables(int n, int m, int use_libm, float* logc_n, float* logc_k);
+void orc_acr_tables(int n, int m, float* logc_n, float* logc_k);
 /* min_k NFA(k) of one model given its residuals (kernel units); *k_out = the minimising k */
-double orc_acr_best_nfa(const double* err, int n, int m, int max_models, double logalpha0, double mult, int use_libm, int* k_out);
-double orc_acr_log10(double x);
+double orc_acr_best_nfa(const double* err, int n, int m, int max_models, double logalpha0, double mult, int* k_out);
+/* the sample of iteration `iter`: m distinct positions in [0, n_index) -- the oracle's OWN statement of the documented sampler */
 void orc_acr_sample(uint64_t seed, uint32_t iter, uint32_t n_index, int m, uint32_t* pos);
 
 #ifdef __cplusplus

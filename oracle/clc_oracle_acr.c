@@ -29,21 +29,49 @@
  *   min_nfa >= 0 -> no model.
  *
  * What differs from OpenMVG by necessity: (1) the random sample of an iteration is NOT std::mt19937 + UniformSample
- * (bits unknowable here) but the counter-based sampler of coloc_amd/csrc/clc_acr.h, a pure function of (seed,
- * iteration, index-set size); (2) the minimal solver is a callback -- the tests plug in the product's own P3P /
- * five-point hypotheses (checked separately against independent solvers), so that this oracle checks exactly what it
- * restates: residual normalisation, ordering, NFA, model selection, the phase switch and the inlier set.
- * log10: `use_libm` != 0 takes libm's log10 everywhere (the literal restatement); 0 takes the portable log10 of
- * clc_acr.h for the NFA terms, which is what the GPU evaluates -- the two agree to 2 ulp and tests/test_acransac.py
- * checks that they select the same model on every scene used.
+ * (bits unknowable here) but a documented pure function of (seed, iteration, index-set size), STATED HERE ON ITS OWN
+ * (orc_acr_sample below; the product's statement is coloc_amd/csrc/clc_acr.h -- tests/test_acransac.py holds the two
+ * against each other); (2) the minimal solver is a callback -- the tests plug in hypotheses from the GPU kernels, or
+ * from HOST builds of the solvers (tests/host/p3p_host_lib.cpp, fivept_host_lib.cpp), so that this oracle checks exactly
+ * what it restates: residual normalisation, ordering, NFA, model selection, the phase switch and the inlier set.
+ * log10 is libm's, everywhere (round 6: this file shares NO code with the product -- it used to include clc_acr.h for
+ * the sampler and for a portable log10; the product's own log10 differs from libm's by at most 2 ulp, so the discrete
+ * results -- model, inlier list, iteration count -- must be identical and the NFA agrees to ~1e-15 relative).
  */
 #include "clc_oracle.h"
-#include "../coloc_amd/csrc/clc_acr.h"
 
 #include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* ---- the sample of an iteration: specification, restated -----------------------------------------------------------------
+ * stream:  z_0 = mix(seed XOR mix(iter + 1)),  z_{t+1} = mix(z_t),  with splitmix64's output function
+ *          mix(z): z += 0x9E3779B97F4A7C15;  z = (z XOR z >> 30) * 0xBF58476D1CE4E5B9;  z = (z XOR z >> 27) * 0x94D049BB133111EB;
+ *                  return z XOR z >> 31
+ * draw t:  position = floor( (z_t >> 32) * n_index / 2^32 )   (the high half of a 32 x 32 -> 64-bit product)
+ * sample:  the first m DISTINCT positions in draw order (a draw that repeats an earlier position is skipped). */
+static uint64_t orc_splitmix(uint64_t z)
+{
+    z = z + UINT64_C(0x9E3779B97F4A7C15);
+    z ^= z >> 30; z *= UINT64_C(0xBF58476D1CE4E5B9);
+    z ^= z >> 27; z *= UINT64_C(0x94D049BB133111EB);
+    z ^= z >> 31;
+    return z;
+}
+void orc_acr_sample(uint64_t seed, uint32_t iter, uint32_t n_index, int m, uint32_t* pos)
+{
+    uint64_t z = orc_splitmix(seed ^ orc_splitmix((uint64_t)iter + 1));
+    int have = 0;
+    while (have < m) {
+        z = orc_splitmix(z);
+        const uint32_t r = (uint32_t)(z >> 32);
+        const uint32_t p = (uint32_t)(((uint64_t)r * (uint64_t)n_index) / (UINT64_C(1) << 32));
+        int seen = 0;
+        for (int q = 0; q < have; ++q) seen |= pos[q] == p;
+        if (!seen) pos[have++] = p;
+    }
+}
 
 typedef struct { double e; uint32_t i; } err_index;
 
@@ -66,11 +94,11 @@ static float logcombi(uint32_t k, uint32_t n, const float* lg)
     return r;
 }
 
-void orc_acr_tables(int n, int m, int use_libm, float* logc_n, float* logc_k)
+void orc_acr_tables(int n, int m, float* logc_n, float* logc_k)
 {
     float* lg = (float*)malloc(sizeof(float) * (size_t)(n + 2));
     lg[0] = 0.0f;
-    for (int k = 1; k <= n + 1; ++k) lg[k] = use_libm ? (float)log10((double)k) : (float)clc_acr_log10((double)k);
+    for (int k = 1; k <= n + 1; ++k) lg[k] = (float)log10((double)k);
     /* logcombi(k, n) re-sums the same prefix for every k: O(n^2) as written in OpenMVG, a running prefix here -- the
      * additions and their order are identical, so are the floats */
     float* prefix = (float*)malloc(sizeof(float) * (size_t)(n + 1));
@@ -112,7 +140,7 @@ static void acr_errors(int kind, const double* model, const double* a, const dou
 }
 
 int orc_acransac(int kind, const double* a, const double* b, int n, const double* K1, int img_w, int img_h,
-                 int max_iteration, uint64_t seed, double precision, int use_libm, orc_acr_fit_fn fit, void* user,
+                 int max_iteration, uint64_t seed, double precision, orc_acr_fit_fn fit, void* user,
                  double* model_out, uint32_t* inliers_out, int* n_inliers_out, double* error_max_out, double* min_nfa_out,
                  int32_t* best_iter_out, int32_t* iterations_run_out)
 {
@@ -125,19 +153,19 @@ int orc_acransac(int kind, const double* a, const double* b, int n, const double
     if (n <= m) return 0;
     /* resection: log10(pi) (error on the normalised camera plane); essential: point-to-line, 2 D / A * 0.5 of image 2 */
     double logalpha0, mult, norm2;
-    if (kind == 0) { logalpha0 = use_libm ? log10(M_PI) : clc_acr_log10(M_PI); mult = 1.0; norm2 = (1.0 / K1[0]) * (1.0 / K1[0]); }
+    if (kind == 0) { logalpha0 = log10(M_PI); mult = 1.0; norm2 = (1.0 / K1[0]) * (1.0 / K1[0]); }
     else {
         const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
         const double al = 2.0 * D / A * .5;
-        logalpha0 = use_libm ? log10(al) : clc_acr_log10(al);
+        logalpha0 = log10(al);
         mult = 0.5;
         norm2 = 1.0;
     }
     const double max_threshold = isinf(precision) ? INFINITY : precision * norm2;
-    const double loge0 = use_libm ? log10((double)M * (double)(n - m)) : clc_acr_log10((double)M * (double)(n - m));
+    const double loge0 = log10((double)M * (double)(n - m));
     float* logc_n = (float*)malloc(sizeof(float) * (size_t)(n + 1));
     float* logc_k = (float*)malloc(sizeof(float) * (size_t)(n + 1));
-    orc_acr_tables(n, m, use_libm, logc_n, logc_k);
+    orc_acr_tables(n, m, logc_n, logc_k);
     double* e = (double*)malloc(sizeof(double) * (size_t)n);
     err_index* se = (err_index*)malloc(sizeof(err_index) * (size_t)n);
     uint32_t* index = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n);
@@ -153,7 +181,7 @@ int orc_acransac(int kind, const double* a, const double* b, int n, const double
     int iter = 0;
     for (; iter < n_iter; ++iter) {
         uint32_t pos[8], sample[8];
-        clc_acr_sample(seed, (uint32_t)iter, n_index, m, pos);
+        orc_acr_sample(seed, (uint32_t)iter, n_index, m, pos);
         for (int j = 0; j < m; ++j) sample[j] = index[pos[j]];
         const int nm = fit(user, sample, models);
         int better = 0;
@@ -171,11 +199,8 @@ int orc_acransac(int kind, const double* a, const double* b, int n, const double
             double best_nfa = INFINITY;
             int best_k = m;
             for (int kk = m + 1; kk <= n && se[kk - 1].e <= max_threshold; ++kk) {
-                double nfa;
-                if (use_libm) {
-                    const double logalpha = logalpha0 + mult * log10(se[kk - 1].e + (double)FLT_EPSILON);
-                    nfa = ((loge0 + logalpha * (double)(kk - m)) + (double)logc_n[kk]) + (double)logc_k[kk];
-                } else nfa = clc_acr_nfa(loge0, logalpha0, mult, se[kk - 1].e, kk, m, logc_n[kk], logc_k[kk]);
+                const double logalpha = logalpha0 + mult * log10(se[kk - 1].e + (double)FLT_EPSILON);
+                const double nfa = ((loge0 + logalpha * (double)(kk - m)) + (double)logc_n[kk]) + (double)logc_k[kk];
                 if (nfa < best_nfa) { best_nfa = nfa; best_k = kk; }
             }
             if (best_nfa < min_nfa) {
@@ -211,27 +236,22 @@ int orc_acransac(int kind, const double* a, const double* b, int n, const double
 }
 
 /* the NFA scan of ONE model on caller-supplied residuals (already in kernel units): for unit tests */
-double orc_acr_best_nfa(const double* err, int n, int m, int max_models, double logalpha0, double mult, int use_libm, int* k_out)
+double orc_acr_best_nfa(const double* err, int n, int m, int max_models, double logalpha0, double mult, int* k_out)
 {
     float* logc_n = (float*)malloc(sizeof(float) * (size_t)(n + 1));
     float* logc_k = (float*)malloc(sizeof(float) * (size_t)(n + 1));
-    orc_acr_tables(n, m, use_libm, logc_n, logc_k);
+    orc_acr_tables(n, m, logc_n, logc_k);
     err_index* se = (err_index*)malloc(sizeof(err_index) * (size_t)n);
     for (int i = 0; i < n; ++i) { se[i].e = err[i]; se[i].i = (uint32_t)i; }
     qsort(se, (size_t)n, sizeof(err_index), cmp_err_index);
-    const double loge0 = use_libm ? log10((double)max_models * (double)(n - m)) : clc_acr_log10((double)max_models * (double)(n - m));
+    const double loge0 = log10((double)max_models * (double)(n - m));
     double best = INFINITY;
     int bk = m;
     for (int kk = m + 1; kk <= n; ++kk) {
-        double nfa;
-        if (use_libm) nfa = ((loge0 + (logalpha0 + mult * log10(se[kk - 1].e + (double)FLT_EPSILON)) * (double)(kk - m)) + (double)logc_n[kk]) + (double)logc_k[kk];
-        else nfa = clc_acr_nfa(loge0, logalpha0, mult, se[kk - 1].e, kk, m, logc_n[kk], logc_k[kk]);
+        const double nfa = ((loge0 + (logalpha0 + mult * log10(se[kk - 1].e + (double)FLT_EPSILON)) * (double)(kk - m)) + (double)logc_n[kk]) + (double)logc_k[kk];
         if (nfa < best) { best = nfa; bk = kk; }
     }
     if (k_out) *k_out = bk;
     free(se); free(logc_k); free(logc_n);
     return best;
 }
-
-double orc_acr_log10(double x) { return clc_acr_log10(x); }
-void orc_acr_sample(uint64_t seed, uint32_t iter, uint32_t n_index, int m, uint32_t* pos) { clc_acr_sample(seed, iter, n_index, m, pos); }

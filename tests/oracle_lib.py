@@ -195,29 +195,25 @@ class Oracle:
 
 
     # -- a-contrario RANSAC
-    def acr_log10(self, x):
-        self.lib.orc_acr_log10.restype = C.c_double
-        return float(self.lib.orc_acr_log10(C.c_double(float(x))))
-
     def acr_sample(self, seed, it, n_index, m):
         pos = (C.c_uint32 * 8)()
         self.lib.orc_acr_sample(C.c_uint64(int(seed)), C.c_uint32(int(it)), C.c_uint32(int(n_index)), C.c_int(m), pos)
         return [int(pos[j]) for j in range(m)]
 
-    def acr_tables(self, n, m, use_libm=False):
+    def acr_tables(self, n, m):
         a = np.zeros(n + 1, dtype=np.float32); b = np.zeros(n + 1, dtype=np.float32)
-        self.lib.orc_acr_tables(C.c_int(n), C.c_int(m), C.c_int(1 if use_libm else 0), _ptr(a), _ptr(b))
+        self.lib.orc_acr_tables(C.c_int(n), C.c_int(m), _ptr(a), _ptr(b))
         return a, b
 
-    def acr_best_nfa(self, err, m, max_models, logalpha0, mult, use_libm=False):
+    def acr_best_nfa(self, err, m, max_models, logalpha0, mult):
         err = np.ascontiguousarray(err, dtype=np.float64)
         k = C.c_int()
         self.lib.orc_acr_best_nfa.restype = C.c_double
         v = self.lib.orc_acr_best_nfa(_ptr(err), C.c_int(err.shape[0]), C.c_int(m), C.c_int(max_models), C.c_double(logalpha0),
-                                      C.c_double(mult), C.c_int(1 if use_libm else 0), C.byref(k))
+                                      C.c_double(mult), C.byref(k))
         return float(v), int(k.value)
 
-    def acransac(self, kind, a, b, K1, fit, max_iteration=256, seed=1, precision=float("inf"), use_libm=False, img_wh=(0, 0)):
+    def acransac(self, kind, a, b, K1, fit, max_iteration=256, seed=1, precision=float("inf"), img_wh=(0, 0)):
         """Sequential AC-RANSAC.  kind 0: a = X (N,3), b = x (N,2); kind 1: a = x1, b = x2.  `fit(sample) -> array
         (n_models, 12 | 18)` is the minimal solver (valid models only, solver order).  Returns a dict."""
         a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
@@ -243,7 +239,7 @@ class Oracle:
         self.lib.orc_acransac.restype = C.c_int
         found = self.lib.orc_acransac(C.c_int(kind), _ptr(a), _ptr(b), C.c_int(n), _ptr(K1), C.c_int(int(img_wh[0])), C.c_int(int(img_wh[1])),
                                       C.c_int(int(max_iteration)), C.c_uint64(int(seed)), C.c_double(float(precision)),
-                                      C.c_int(1 if use_libm else 0), cb, None, _ptr(model), _ptr(inl), C.byref(n_inl), C.byref(emax),
+                                      cb, None, _ptr(model), _ptr(inl), C.byref(n_inl), C.byref(emax),
                                       C.byref(nfa), C.byref(best_it), C.byref(its))
         return dict(found=bool(found), model=model, inliers=inl[:n_inl.value].copy(), error_max=emax.value, min_nfa=nfa.value,
                     best_iter=best_it.value, iterations=its.value, samples=calls)

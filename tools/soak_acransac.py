@@ -27,7 +27,7 @@ for it in range(runs):
     got = ctx.pnp_acransac(sc["X"], sc["x"], sc["K"], max_iteration=max_it, seed=seed, precision=prec)
     want = orc.acransac(0, sc["X"], sc["x"], sc["K"], fit, max_iteration=max_it, seed=seed, precision=prec)
     ok = (got["Rt"] is not None) == want["found"] and got["iterations"] == want["iterations"] \
-        and (got["min_nfa"] == want["min_nfa"] or (math.isinf(got["min_nfa"]) and math.isinf(want["min_nfa"]))) \
+        and ((math.isinf(got["min_nfa"]) and math.isinf(want["min_nfa"])) or abs(got["min_nfa"] - want["min_nfa"]) <= 1e-12 * abs(want["min_nfa"])) \
         and np.array_equal(got["inliers"], want["inliers"].astype(np.int32))
     if ok and want["found"]:
         ok = np.array_equal(got["Rt"].reshape(-1), want["model"]) and got["error_max"] == want["error_max"]
