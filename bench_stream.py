@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--scene", choices=["plane", "synthetic"], default="plane")
     ap.add_argument("--pipelined", action="store_true", help="plane scene, one rank: the two-lane loop also below 4 cameras")
     ap.add_argument("--sequential", action="store_true", help="plane scene: the camera-by-camera loop only")
+    ap.add_argument("--no-inter-shortcut-run", action="store_true",
+                    help="plane scene: skip the second run of the loop that uses the map_index shortcut in the inter-camera step (inter_forms)")
     ap.add_argument("--no-overlap", action="store_true", help="plane scene, frame-batched loop: no pipelining -- a frame's front end is enqueued and waited for inside its own timed region")
     ap.add_argument("--unique-frames", type=int, default=6, help="plane scene: rendered frames per camera (the trajectory loops over them)")
     args = ap.parse_args()
@@ -339,6 +341,13 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
         return dict(C=Ce, cov=Cc, gt=gt, Rt=Rt, n=n, kps=kps, m=m)   # feature coordinates are derived for the rows a later stage needs
 
     inter_pool = {"ctxs": [], "d_pairs": None}
+    # how the inter-camera step finds the features the pair's temporary map shares with the global map (clc_inter_pose_batch):
+    # "reference" = the reference's own chain (coloc.hpp:317-323: the temporary map's descriptors -- the lower camera's rows of the
+    # correspondences -- matched against the global map's on the device, K2NN threshold 60); "map_index" = the shortcut of rounds 3-5
+    # (the source frame's own map matches say which of its features the global map holds).  The headline runs the reference's chain,
+    # the same loop runs again with the shortcut and both are reported (inter_forms).
+    inter_form = {"v": "reference"}
+    d_map_desc_t = torch.from_numpy(np.ascontiguousarray(desc_m)).to(dev)
 
     def inter_and_fuse(c, cptr, f, est, desc_ptr, d_pair, st):
         """inter-camera step + fusion for every camera of the frame: destination = cam, source = its neighbour (coloc.hpp:274-392).
@@ -378,7 +387,13 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
             x2 = feature_xy(D["kps"][pm[q]]) if "kps" in D else D["xy"][pm[q]]
             # filterMatchesPair + RelativePoseFromEssential + interReconstruct + scale + refinePose (coloc.hpp:296-340); the source frame's
             # map matches (threshold 60) say which of its features the global map holds
-            probs.append(dict(x1=x1, x2=x2, K=K, wh=(W, H), seed=f + 1, map_index=S["m"][q], Rt_source=S["Rt"]))
+            if inter_form["v"] == "reference":
+                # setupMapDatabase(inter): a temporary map point keeps the descriptor of its first observation = the camera with the lower id
+                lower, rows = (nb, q) if nb < cam else (cam, pm[q])
+                probs.append(dict(x1=x1, x2=x2, K=K, wh=(W, H), seed=f + 1, Rt_source=S["Rt"], d_first_desc=desc_ptr[lower],
+                                  first_feature=rows.astype(np.int32), d_map_desc=d_map_desc_t.data_ptr(), match_threshold=60))
+            else:
+                probs.append(dict(x1=x1, x2=x2, K=K, wh=(W, H), seed=f + 1, map_index=S["m"][q], Rt_source=S["Rt"]))
             meta.append((cam, nb, len(q)))
         res = inter_pose_batch(inter_pool["ctxs"][:len(probs)], probs, Xmap) if probs else []
         t5 = time.perf_counter()
@@ -394,6 +409,7 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
             om, Cf, pf = cov_intersection(D["cov"], Cci + 1e-12 * np.eye(3), D["C"], Ci)
             st["pos_err_inter"].append(np.linalg.norm(Ci - D["gt"])); st["pos_err_fused"].append(np.linalg.norm(pf - D["gt"]))
             st["n_pair"].append(nq); st["n_pair_inl"].append(len(r["inliers"])); st["n_common"].append(r["n_common"])
+            st.setdefault("inter_centres", {})[(f, cam)] = Ci
             n_ok += 1
         t6 = time.perf_counter()
         for _ in range(n_ok):
@@ -716,6 +732,12 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
     if batched:
         st = run_batched(overlap=not args.no_overlap)
         same = same and all(np.array_equal(seq["poses"][k], st["poses"].get(k)) for k in seq["poses"]) and len(seq["poses"]) == len(st["poses"])
+    # the same loop once more with the map_index shortcut in the inter-camera step (the headline above ran the reference's chain)
+    st_short = None
+    if not args.no_inter_shortcut_run:
+        inter_form["v"] = "map_index"
+        st_short = run_batched(overlap=not args.no_overlap) if batched else (run_pipelined() if pipelined else run_sequential(with_inter=True))
+        inter_form["v"] = "reference"
     if rank == 0:
         p50 = lambda v: float(np.median(v) * 1e3) if len(v) else None
         med = lambda v: float(np.median(v)) if len(v) else None
@@ -752,6 +774,29 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
                "camera_height": HEIGHT,
                "pose_rule": "a-contrario P3P, 256 iterations, error_max = inf (Localizer.hpp:82-93) + LM refinement",
                "note": "frames are rendered on the host before the loop; everything from the uploaded frame to the fused position is timed"}
+        def form_summary(s_):
+            return {"camera_frames_per_s_incl_inter": (len(s_["pos_err"]) / s_["wall"]) if s_.get("wall") else None,
+                    "cameras_at_30fps_per_gpu_incl_inter": (len(s_["pos_err"]) / s_["wall"] / 30.0) if s_.get("wall") else None,
+                    "inter_p50_ms": p50(s_["lat"]["inter"]), "position_error_inter_p50": med(s_["pos_err_inter"]),
+                    "position_error_inter_max": float(np.max(s_["pos_err_inter"])) if s_["pos_err_inter"] else None,
+                    "position_error_fused_p50": med(s_["pos_err_fused"]), "common_map_features_p50": med(s_["n_common"]),
+                    "inter_steps": len(s_["pos_err_inter"]), "inter_failures": s_["inter_fail"]}
+        out["inter_forms"] = {"reference_chain": dict(form_summary(st), what="the temporary map's descriptors (the lower camera's rows of the pair's "
+                                                      "correspondences, gathered on the device) matched against the global map's: K2NN, Q = map, T = temporary map, "
+                                                      "threshold 60 -- setupMapDatabase(inter) + matchMapFeatures, coloc.hpp:317-323; THE HEADLINE")}
+        if st_short is not None:
+            out["inter_forms"]["map_index_shortcut"] = dict(form_summary(st_short), what="the source frame's own map matches say which of its features the global "
+                                                            "map holds (rounds 3-5); no descriptor work in the inter-camera step")
+            a, b = st.get("inter_centres", {}), st_short.get("inter_centres", {})
+            both = sorted(set(a) & set(b))
+            dd = [float(np.linalg.norm(a[k] - b[k])) for k in both]
+            out["inter_forms"]["centres_compared"] = len(both)
+            out["inter_forms"]["centre_difference_p50"] = med(dd)
+            out["inter_forms"]["centre_difference_max"] = float(np.max(dd)) if dd else None
+            out["inter_forms"]["tolerance"] = ("the two forms walk (nearly) the same common features in different orders -- by global map index, by "
+                                               "correspondence -- through the same scale rule (mean of consecutive distance ratios, colocUtils.hpp:184-211): "
+                                               "centres agree to that rule's noise -- checked: the MEDIAN difference < 0.01 x camera height; single frames can differ by more, "
+                                               "where one form's consecutive-ratio mean meets a bad pair of neighbours (see each form's position_error_inter_max against ground truth)")
         if pipelined or batched:
             sl = seq["lat"]
             out["sequential"] = {"what": "the same frames camera by camera with a synchronisation between the stages (round 3's call pattern), "
@@ -771,6 +816,8 @@ def plane_scene(args, world, rank, local_rank, dev, my_cams, n_cams):
         print(json.dumps(out))
         if not same:
             sys.exit(3)
+        if out["inter_forms"].get("centre_difference_p50") is not None and out["inter_forms"]["centre_difference_p50"] > 0.01 * HEIGHT:
+            sys.exit(4)
     for c_ in inter_pool["ctxs"]:
         c_.close()
     ctx.close()

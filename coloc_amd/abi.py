@@ -68,8 +68,9 @@ class TwoViewJob(C.Structure):
 class InterPoseJob(C.Structure):
     """clc_inter_pose_job (include/coloc_hip.h)"""
     _fields_ = [("tv", TwoViewJob), ("map_index", C.c_void_p), ("map_X", C.c_void_p), ("map_n", C.c_int), ("Rt_source", C.c_void_p), ("huber_a", C.c_double),
+                ("d_first_desc", C.c_void_p), ("first_feature", C.c_void_p), ("d_map_desc", C.c_void_p), ("match_threshold", C.c_int),
                 ("Rt", C.c_double * 12), ("cov", C.c_double * 36), ("rmse", C.c_double), ("scale", C.c_double),
-                ("n_front", C.c_int), ("n_common", C.c_int), ("n_refined", C.c_int), ("stage", C.c_int)]
+                ("n_front", C.c_int), ("n_common", C.c_int), ("n_refined", C.c_int), ("stage", C.c_int), ("n_map_matches", C.c_int)]
 
 
 EXPORTS = [
@@ -273,9 +274,11 @@ def essential_acransac_batch(ctxs, problems, max_iteration=256, precision=float(
 
 
 def inter_pose_batch(ctxs, problems, map_X, max_iteration=256, huber_a=16.0):
-    """clc_inter_pose_batch: problems = [dict(x1, x2, K, wh, seed, map_index, Rt_source), ...] (x1 = source frame's features, x2 = the
-    destination's), one Context per problem, map_X the global map's points (M x 3); -> list of dicts (two-view result + Rt, cov, rmse,
-    scale, n_front, n_common, stage)."""
+    """clc_inter_pose_batch: problems = [dict(x1, x2, K, wh, seed, Rt_source, and map_index (the shortcut) OR d_first_desc, first_feature,
+    d_map_desc [, match_threshold] (the reference's chain: device addresses of the lower camera's descriptor block and of the global
+    map's descriptors, the correspondences' rows in the former)), ...] (x1 = source frame's features, x2 = the destination's), one
+    Context per problem, map_X the global map's points (M x 3); -> list of dicts (two-view result + Rt, cov, rmse, scale, n_front,
+    n_common, n_map_matches, stage)."""
     lib = load_library()
     n = len(problems)
     jobs = (InterPoseJob * n)()
@@ -283,10 +286,18 @@ def inter_pose_batch(ctxs, problems, map_X, max_iteration=256, huber_a=16.0):
     keep, outs = [map_X], []
     for j, p in zip(jobs, problems):
         outs.append(_two_view_fill(j.tv, keep, p["x1"], p["x2"], p["K"], p["K"], p["wh"], max_iteration, p["seed"], float("inf")))
-        mi = np.ascontiguousarray(p["map_index"], dtype=np.int32)
         rs = np.ascontiguousarray(p["Rt_source"], dtype=np.float64).reshape(12)
-        keep.append((mi, rs))
-        j.map_index, j.map_X, j.map_n, j.Rt_source, j.huber_a = mi.ctypes.data, map_X.ctypes.data, int(map_X.shape[0]), rs.ctypes.data, float(huber_a)
+        keep.append(rs)
+        j.map_X, j.map_n, j.Rt_source, j.huber_a = map_X.ctypes.data, int(map_X.shape[0]), rs.ctypes.data, float(huber_a)
+        if p.get("d_first_desc") is not None:
+            ff = np.ascontiguousarray(p["first_feature"], dtype=np.int32)
+            keep.append(ff)
+            j.d_first_desc, j.first_feature, j.d_map_desc = int(p["d_first_desc"]), ff.ctypes.data, int(p["d_map_desc"])
+            j.match_threshold = int(p.get("match_threshold", 60))
+        elif p.get("map_index") is not None:
+            mi = np.ascontiguousarray(p["map_index"], dtype=np.int32)
+            keep.append(mi)
+            j.map_index = mi.ctypes.data
     hs = (C.c_void_p * n)(*[c.h for c in ctxs])
     rc = lib.clc_inter_pose_batch(hs, jobs, n)
     if rc != CLC_OK:
@@ -295,7 +306,7 @@ def inter_pose_batch(ctxs, problems, map_X, max_iteration=256, huber_a=16.0):
     for j, o in zip(jobs, outs):
         d = _two_view_result(j.tv, *o)
         d.update(Rt=np.array(j.Rt).reshape(3, 4), cov=np.array(j.cov).reshape(6, 6), rmse=j.rmse, scale=j.scale, n_front=j.n_front,
-                 n_common=j.n_common, n_refined=j.n_refined, stage=j.stage)
+                 n_common=j.n_common, n_refined=j.n_refined, stage=j.stage, n_map_matches=j.n_map_matches)
         res.append(d)
     return res
 

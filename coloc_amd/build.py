@@ -62,7 +62,7 @@ def build(force=False, verbose=False):
         if stale:
             # (.cpp: host arithmetic only, compiled as plain C++ by the same driver)
             flags = [f for f in CFLAGS if not f.startswith("--offload-arch") and f not in ("-mllvm", "-amdgpu-mfma-vgpr-form")] if src.endswith(".cpp") else CFLAGS
-            jobs.append([hipcc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj])
+            jobs.append([hipcc] + flags + extra + (["-x", "c++"] if src.endswith(".cpp") else []) + ["-c", os.path.join(CSRC, src), "-o", obj])
     if verbose:
         for j in jobs:
             print(" ".join(j))

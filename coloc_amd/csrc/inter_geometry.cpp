@@ -19,16 +19,16 @@ static inline void normalise_px(const double* K, const double x, const double y,
     n[0] = (x - K[2] - K[1] * n[1]) / K[0];
 }
 
-// The host part of the inter-camera step between the two-view filter and the refinement (coloc.hpp:296-340): relative pose from E with
-// the chirality vote (RobustMatcher.hpp:176-183), the pair's temporary map in the source camera's frame, its scale against the global
-// map through the features both hold (colocUtils.hpp:184-211: mean of consecutive distance ratios, behind a depth-ratio screen), the
-// destination's first pose through the source's.  Triangulation: the depths along the two rays that bring them closest (closed form;
-// OpenMVG's TriangulateDLT differs from it by less than the measurement noise).  Returns 0, or which stage failed (CLC_INTER_*).
-int inter_geometry(clc_inter_pose_job& jb, std::vector<double>& Xw, std::vector<double>& x2f)
+// Step 1 of the host part (coloc.hpp:296-306): relative pose from E with the chirality vote (RobustMatcher.hpp:176-183) and the pair's
+// temporary map in the source camera's frame (unit baseline) -- the correspondences in front of both cameras.  Triangulation: the
+// depths along the two rays that bring them closest (closed form; OpenMVG's TriangulateDLT differs from it by less than the
+// measurement noise).  Returns CLC_INTER_OK, or which stage failed.
+int inter_relative(clc_inter_pose_job& jb, InterFront& fr)
 {
     const clc_two_view_job& tv = jb.tv;
     const int ni = tv.n_inliers;
-    jb.n_front = 0; jb.n_common = 0; jb.scale = 0.0;
+    jb.n_front = 0; jb.n_common = 0; jb.n_map_matches = 0; jb.scale = 0.0;
+    fr.Xt.clear(); fr.x2f.clear(); fr.corr.clear();
     if (ni < 13 || !tv.E || !tv.inliers) return CLC_INTER_NO_MODEL;
     openMVG::Mat3 E;
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E(i, j) = tv.E[3 * i + j];
@@ -42,7 +42,7 @@ int inter_geometry(clc_inter_pose_job& jb, std::vector<double>& Xw, std::vector<
     }
     int best = -1, best_cnt = -1;
     std::vector<double> l1((size_t)ni), bl1;
-    std::vector<uint8_t> fr((size_t)ni), bfr;
+    std::vector<uint8_t> front((size_t)ni), bfr;
     double Rb[9] = {}, tb[3] = {};
     for (size_t c = 0; c < cand.size(); ++c) {
         const openMVG::Mat3& R = cand[c].rotation();
@@ -60,11 +60,11 @@ int inter_geometry(clc_inter_pose_job& jb, std::vector<double>& Xw, std::vector<
             if (std::fabs(det) < 1e-18) det = 1e-18;
             const double d1 = (-at * bb + bt * ab) / det, d2 = (-at * ab + bt * aa) / det;
             l1[(size_t)k] = d1;
-            fr[(size_t)k] = d1 > 0.0 && d2 > 0.0;
-            cnt += fr[(size_t)k];
+            front[(size_t)k] = d1 > 0.0 && d2 > 0.0;
+            cnt += front[(size_t)k];
         }
         if (cnt > best_cnt) {
-            best_cnt = cnt; best = (int)c; bl1 = l1; bfr = fr;
+            best_cnt = cnt; best = (int)c; bl1 = l1; bfr = front;
             for (int r = 0; r < 3; ++r) { for (int q = 0; q < 3; ++q) Rb[3 * r + q] = R(r, q); tb[r] = t[r]; }
         }
     }
@@ -72,31 +72,44 @@ int inter_geometry(clc_inter_pose_job& jb, std::vector<double>& Xw, std::vector<
     jb.n_front = best_cnt;
     // the temporary map (source camera's frame, unit baseline) of the correspondences in front of both cameras
     const size_t nf = (size_t)best_cnt;
-    std::vector<double> Xt(3 * nf);
-    std::vector<int32_t> mi(nf);
-    x2f.resize(2 * nf);
+    fr.Xt.resize(3 * nf); fr.x2f.resize(2 * nf); fr.corr.resize(nf);
     size_t w = 0;
     for (int k = 0; k < ni; ++k) {
         if (!bfr[(size_t)k]) continue;
         const int i = tv.inliers[k];
-        Xt[3 * w] = n1[2 * (size_t)k] * bl1[(size_t)k]; Xt[3 * w + 1] = n1[2 * (size_t)k + 1] * bl1[(size_t)k]; Xt[3 * w + 2] = bl1[(size_t)k];
-        x2f[2 * w] = tv.x2[2 * i]; x2f[2 * w + 1] = tv.x2[2 * i + 1];
-        const int32_t gi = jb.map_index ? jb.map_index[i] : -1;
-        mi[w] = (gi >= 0 && gi < jb.map_n) ? gi : -1;
+        fr.Xt[3 * w] = n1[2 * (size_t)k] * bl1[(size_t)k]; fr.Xt[3 * w + 1] = n1[2 * (size_t)k + 1] * bl1[(size_t)k]; fr.Xt[3 * w + 2] = bl1[(size_t)k];
+        fr.x2f[2 * w] = tv.x2[2 * i]; fr.x2f[2 * w + 1] = tv.x2[2 * i + 1];
+        fr.corr[w] = i;
         ++w;
     }
-    // scale through the features both maps hold
+    for (int r = 0; r < 9; ++r) fr.R[r] = Rb[r];
+    for (int r = 0; r < 3; ++r) fr.t[r] = tb[r];
+    return CLC_INTER_OK;
+}
+
+// Step 2 (coloc.hpp:323-340): the temporary map's scale against the global map through the features both hold -- `common` = pairs (global
+// map point, temporary map point) IN THE ORDER the rule walks them -- by the reference's rule (colocUtils.hpp:184-211: the mean over
+// consecutive common features of |X12 - X11| / |X22 - X21|, the two norms rounded to float as there), behind a depth-ratio screen that is
+// ours (a wrong descriptor match would otherwise enter the mean twice; the reference has no such guard), then the destination's first
+// pose through the source's and the temporary map in world coordinates.
+int inter_scale_pose(clc_inter_pose_job& jb, const InterFront& fr, const std::vector<std::pair<int32_t, int32_t>>& common, std::vector<double>& Xw)
+{
+    const std::vector<double>& Xt = fr.Xt;
+    const size_t nf = fr.corr.size();
+    const double* Rb = fr.R; const double* tb = fr.t;
     const double* Rs = jb.Rt_source;          // [R|t] row-major 3 x 4
-    std::vector<size_t> com;
+    std::vector<size_t> com;                  // positions in `common`
     std::vector<double> ratio;
-    for (size_t k = 0; k < nf; ++k) {
-        if (mi[k] < 0) continue;
-        const double* Xg = jb.map_X + 3 * (size_t)mi[k];
+    for (size_t c = 0; c < common.size(); ++c) {
+        const int32_t gi = common[c].first;
+        const size_t k = (size_t)common[c].second;
+        if (gi < 0 || gi >= jb.map_n || k >= nf) continue;
+        const double* Xg = jb.map_X + 3 * (size_t)gi;
         double xs[3];
         for (int r = 0; r < 3; ++r) xs[r] = Rs[4 * r] * Xg[0] + Rs[4 * r + 1] * Xg[1] + Rs[4 * r + 2] * Xg[2] + Rs[4 * r + 3];
         const double ng = std::sqrt(xs[0] * xs[0] + xs[1] * xs[1] + xs[2] * xs[2]);
         const double nt = std::sqrt(Xt[3 * k] * Xt[3 * k] + Xt[3 * k + 1] * Xt[3 * k + 1] + Xt[3 * k + 2] * Xt[3 * k + 2]);
-        com.push_back(k);
+        com.push_back(c);
         ratio.push_back(ng / (nt > 1e-12 ? nt : 1e-12));
     }
     jb.n_common = (int)com.size();
@@ -110,11 +123,12 @@ int inter_geometry(clc_inter_pose_job& jb, std::vector<double>& Xw, std::vector<
     if (keep.size() < 8) return CLC_INTER_NO_SCALE;
     double sum = 0.0; size_t good = 0;
     for (size_t k = 0; k + 1 < keep.size(); ++k) {
-        const double* g0 = jb.map_X + 3 * (size_t)mi[keep[k]]; const double* g1 = jb.map_X + 3 * (size_t)mi[keep[k + 1]];
-        const double* t0 = &Xt[3 * keep[k]]; const double* t1 = &Xt[3 * keep[k + 1]];
-        const double d1 = std::sqrt((g1[0] - g0[0]) * (g1[0] - g0[0]) + (g1[1] - g0[1]) * (g1[1] - g0[1]) + (g1[2] - g0[2]) * (g1[2] - g0[2]));
-        const double d2 = std::sqrt((t1[0] - t0[0]) * (t1[0] - t0[0]) + (t1[1] - t0[1]) * (t1[1] - t0[1]) + (t1[2] - t0[2]) * (t1[2] - t0[2]));
-        if (d2 > 1e-9) { sum += d1 / d2; ++good; }
+        const double* g0 = jb.map_X + 3 * (size_t)common[keep[k]].first; const double* g1 = jb.map_X + 3 * (size_t)common[keep[k + 1]].first;
+        const double* t0 = &Xt[3 * (size_t)common[keep[k]].second]; const double* t1 = &Xt[3 * (size_t)common[keep[k + 1]].second];
+        // colocUtils.hpp:201-204: float dist1 = (X12 - X11).norm(); float dist2 = (X22 - X21).norm(); scale += dist1 / dist2;
+        const float d1 = (float)std::sqrt((g1[0] - g0[0]) * (g1[0] - g0[0]) + (g1[1] - g0[1]) * (g1[1] - g0[1]) + (g1[2] - g0[2]) * (g1[2] - g0[2]));
+        const float d2 = (float)std::sqrt((t1[0] - t0[0]) * (t1[0] - t0[0]) + (t1[1] - t0[1]) * (t1[1] - t0[1]) + (t1[2] - t0[2]) * (t1[2] - t0[2]));
+        if (d2 > 1e-9f) { sum += (double)(d1 / d2); ++good; }
     }
     if (good == 0) return CLC_INTER_NO_SCALE;
     const double scale = sum / (double)good;

@@ -556,24 +556,41 @@ int clc_essential_acransac_batch(clc_ctx* const* ctxs, clc_two_view_job* jobs, i
 /* The inter-camera step of ColoC::interPoseEstimator(source, dest) between the pair's putative matches and the covariance intersection
  * (coloc.hpp:296-340), for several camera pairs at once: a-contrario five-point filter (filterMatchesPair, :296) -> relative pose from
  * E with the chirality vote (RobustMatcher.hpp:176-183) -> the pair's temporary map triangulated in the source camera's frame (:306) ->
- * its scale against the global map through the features both hold (map_index; colocUtils.hpp:184-211) -> the destination's pose through
- * the source's, refined against the temporary map with its 6 x 6 covariance (refinePose, :340; Huber(huber_a)).  tv.x1 = the SOURCE
- * frame's features, tv.x2 = the destination's; tv.E and tv.inliers must be given.  stage says how far a job got. */
+ * the features it shares with the global map -> its scale against the global map through them (colocUtils.hpp:184-211) -> the
+ * destination's pose through the source's, refined against the temporary map with its 6 x 6 covariance (refinePose, :340;
+ * Huber(huber_a)).  tv.x1 = the SOURCE frame's features, tv.x2 = the destination's; tv.E and tv.inliers must be given.
+ * The common features come, per job, from one of two places:
+ *   THE REFERENCE'S CHAIN (d_first_desc, first_feature and d_map_desc given): setupMapDatabase(inter) keeps, for every point of the
+ *       temporary map, the descriptor of its FIRST observation -- the pair's camera with the lower id (colocData.hpp:109-117) --, and
+ *       matchMapFeatures(mapRegions, interMapRegions) matches the global map's descriptors against them: K2NN, Q = global map, T =
+ *       temporary map, threshold 60 (coloc.hpp:317-323, GPUMatcher.hpp:157-163); commonFeatures = the accepted map points in ascending
+ *       order.  Here: the rows are gathered on the device from that camera's descriptor block and swept against the map's block, which
+ *       both stay where they are (device pointers);
+ *   THE SHORTCUT (map_index given, the chain's pointers NULL): correspondence i's SOURCE feature is global map point map_index[i] (-1:
+ *       none) -- what the source frame's own map tracking (matchSceneWithMap) already found; no descriptor work, common features in
+ *       correspondence order.
+ * stage says how far a job got. */
 enum { CLC_INTER_OK = 0, CLC_INTER_NO_MODEL = 1 /* filter found < 13 inliers */, CLC_INTER_NO_RELATIVE_POSE = 2 /* < 8 points in front of both cameras */,
        CLC_INTER_NO_SCALE = 3 /* < 8 features shared with the global map */, CLC_INTER_NO_REFINEMENT = 4 };
 typedef struct clc_inter_pose_job {
     clc_two_view_job tv;
     /* in */
-    const int32_t* map_index; /* tv.n: index of correspondence i's SOURCE feature in the global map, -1 = none (nullable: no scale) */
+    const int32_t* map_index; /* the shortcut: tv.n, index of correspondence i's SOURCE feature in the global map, -1 = none (nullable) */
     const double*  map_X;     /* global map points, 3 doubles each                         */
     int            map_n;     /* number of map points: an index outside [0, map_n) counts as "not a map feature" */
     const double*  Rt_source; /* 12: [R|t] of the source camera, x_cam = R X + t           */
     double         huber_a;   /* <= 0: 16                                                  */
+    /* the reference's chain (all three, or none): */
+    const void*    d_first_desc;   /* DEVICE: the descriptor block (rows of 64 B, 16-byte aligned) of the pair's camera with the lower id */
+    const int32_t* first_feature;  /* tv.n: correspondence i's feature (row) in that block  */
+    const void*    d_map_desc;     /* DEVICE: the global map's descriptors, map_n rows in map_X's order, 16-byte aligned */
+    int            match_threshold;/* <= 0: 60 (GPUMatcher.hpp:162)                         */
     /* out */
     double         Rt[12];    /* the destination's pose through the source, refined        */
     double         cov[36];   /* [angle-axis | translation] order, as clc_pnp_refine       */
     double         rmse, scale;
     int            n_front, n_common, n_refined, stage;
+    int            n_map_matches; /* the reference's chain: global map points matched to the temporary map (before the depth-ratio screen) */
 } clc_inter_pose_job;
 int clc_inter_pose_batch(clc_ctx* const* ctxs, clc_inter_pose_job* jobs, int n_jobs);
 

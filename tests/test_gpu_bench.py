@@ -167,6 +167,34 @@ def test_streaming_scenario_runs_and_localizes():
     assert d["pair_matches_p50"] > 500 and d["pair_inliers_p50"] > 0.8 * d["pair_matches_p50"] and d["common_map_features_p50"] > 50
     assert d["position_error_inter_p50"] < 0.02 * d["camera_height"]
     assert d["position_error_fused_p50"] < 0.005 * d["camera_height"] and d["position_error_fused_max"] < 0.02 * d["camera_height"]
+    _check_inter_forms(d, 12)
+
+
+def _check_inter_forms(d, steps):
+    """Round 6: the inter-camera step finds the features the pair's temporary map shares with the global map the reference's way (the
+    headline: temporary-map descriptors matched against the map's, coloc.hpp:317-323) and, in a second run of the same loop, through the
+    source frame's map indices (rounds 3-5); both forms are reported and must land on the same positions to the scale rule's noise."""
+    f = d["inter_forms"]
+    ref, short = f["reference_chain"], f["map_index_shortcut"]
+    assert ref["inter_steps"] == steps and short["inter_steps"] == steps and ref["inter_failures"] == 0 and short["inter_failures"] == 0
+    assert ref["camera_frames_per_s_incl_inter"] == d["camera_frames_per_s_incl_inter"] and short["camera_frames_per_s_incl_inter"] > 0
+    assert ref["common_map_features_p50"] > 50 and short["common_map_features_p50"] > 50
+    assert f["centres_compared"] == steps and f["centre_difference_p50"] < 0.01 * d["camera_height"]
+    assert ref["position_error_inter_p50"] < 0.02 * d["camera_height"] and short["position_error_inter_p50"] < 0.02 * d["camera_height"]
+
+
+def test_streaming_scenario_eight_cameras():
+    """BASELINE config[4]'s camera count on one GPU: 8 cameras x 4 frames through the frame-batched loop (one front-end call, one counted
+    map-match launch, one batched a-contrario solve and ONE clc_inter_pose_batch call of eight pairs per frame: the lockstep form of the
+    two-view filters), every frame localized, every pair through, both forms of the inter-camera step."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench_stream.py"), "--cams", "8", "--frames", "4"],
+                         capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _last_json(out.stdout)
+    assert d["localized_frames"] == 32 and d["inter_steps"] == 32 and d["inter_failures"] == 0 and d["same_poses_both_modes"] is True
+    assert d["position_error_p50"] < 0.005 * d["camera_height"] and d["position_error_inter_p50"] < 0.02 * d["camera_height"]
+    assert d["position_error_fused_p50"] < 0.005 * d["camera_height"]
+    _check_inter_forms(d, 32)
 
 
 def test_streaming_scenario_synthetic_descriptors():

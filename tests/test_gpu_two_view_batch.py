@@ -64,30 +64,36 @@ def test_two_view_batch_equals_the_single_solves():
             c.close()
 
 
-def _numpy_chain(c, p, e):
-    """the chain bench_stream.py ran in numpy until round 4, on the batch's own E / inliers"""
+def _numpy_chain(c, p, e, common=None):
+    """the chain bench_stream.py ran in numpy until round 4, on the batch's own E / inliers.  common(front correspondences) -> (global map
+    index, temporary map point) pairs in the order the scale rule walks them; default: the shortcut (map_index, correspondence order)"""
     import bench_stream as bs
     inl = e["inliers"]
     x1, x2 = p["x1"], p["x2"]
     rp = bs.relative_pose_from_essential(e["E"], K, x1[inl], x2[inl])
     Rr, tr, Xtmp, front = rp
     Xtmp, x2i, qi = Xtmp[front], x2[inl][front], inl[front]
-    ms = p["map_index"][qi]
-    com = np.nonzero(ms >= 0)[0]
+    if common is None:
+        ms = p["map_index"][qi]
+        com = np.nonzero(ms >= 0)[0]
+        gidx = ms[com]
+    else:
+        gidx, com = common(qi)
     S = p["Rt_source"]
-    Xg = p["map_X"][ms[com]]
+    Xg = p["map_X"][gidx]
     Xg_s = Xg @ S[:, :3].T + S[:, 3]
     ratio = np.linalg.norm(Xg_s, axis=1) / np.maximum(np.linalg.norm(Xtmp[com], axis=1), 1e-12)
     keep = np.abs(ratio / np.median(ratio) - 1.0) < 0.2
     com, Xg = com[keep], Xg[keep]
-    d1 = np.linalg.norm(Xg[1:] - Xg[:-1], axis=1)
-    d2 = np.linalg.norm(Xtmp[com][1:] - Xtmp[com][:-1], axis=1)
-    good = d2 > 1e-9
-    scale = float(np.mean(d1[good] / d2[good]))
+    # colocUtils.hpp:201-204: `float dist1 = (X12 - X11).norm(); float dist2 = ...; scale += dist1 / dist2` -- the norms and their ratio in float
+    d1 = np.linalg.norm(Xg[1:] - Xg[:-1], axis=1).astype(np.float32)
+    d2 = np.linalg.norm(Xtmp[com][1:] - Xtmp[com][:-1], axis=1).astype(np.float32)
+    good = d2 > np.float32(1e-9)
+    scale = float(np.sum((d1[good] / d2[good]).astype(np.float64)) / good.sum())
     Rt0 = np.c_[Rr @ S[:, :3], Rr @ S[:, 3] + scale * tr]
     Xw = (scale * Xtmp - S[:, 3]) @ S[:, :3]
     Rt_i, cov_i, rmse_i, _ = c.pnp_refine(Xw, x2i, K, Rt0)
-    return dict(scale=scale, Rt=Rt_i, cov=cov_i, rmse=rmse_i, n_front=int(front.sum()), n_common=len(com))
+    return dict(scale=scale, Rt=Rt_i, cov=cov_i, rmse=rmse_i, n_front=int(front.sum()), n_common=len(com), n_raw=len(gidx))
 
 
 def test_inter_pose_batch_lands_on_the_destination_pose():
@@ -224,4 +230,77 @@ def test_interleaved_batch_straight_before_a_lockstep_batch_on_the_same_contexts
                 assert np.array_equal(got_v[k]["E"], want_v[k]["E"]) and got_v[k]["min_nfa"] == want_v[k]["min_nfa"], (rep, k)
     finally:
         for c in ctxs + [ref]:
+            c.close()
+
+
+def test_inter_pose_through_the_references_own_chain(oracle):
+    """the common features of the temporary and the global map found the reference's way -- setupMapDatabase(inter)
+    keeps the descriptor of every temporary map point's first observation (the pair's camera with the lower id, colocData.hpp:109-117),
+    matchMapFeatures matches the global map's descriptors against them (K2NN, Q = map, T = temporary map, threshold 60,
+    coloc.hpp:317-323) -- on the device, from the camera's descriptor block and the map's block where they lie.  Against a numpy
+    statement of the same chain whose K2NN is the oracle's; and against the shortcut (the source frame's map indices): the same pose to
+    the scale rule's noise.  Source id below / above the destination's: the lower camera's rows are the ones gathered."""
+    import torch
+    from coloc_amd import Context
+    from coloc_amd.abi import inter_pose_batch
+    ctxs = [Context(device=0, detector=False, matcher=False) for _ in range(4)]
+    try:
+        world = _pair(410, n=1200)
+        n, M = len(world["x1"]), len(world["map_X"])
+        rng = np.random.default_rng(9)
+        point = synth.random_descriptors(n, seed=411)                 # a descriptor per world point ...
+
+        def noisy(rows, flips):
+            d = rows.copy()
+            for r in range(len(d)):
+                for b in rng.choice(512, flips, replace=False):
+                    d[r, b >> 3] ^= 1 << (b & 7)
+            return d
+        # ... seen with a few bits flipped by the source frame, by the destination frame (in ANOTHER row order) and by the map
+        src_desc = noisy(point, 12)
+        perm = rng.permutation(n)
+        dst_desc = np.empty_like(point); dst_desc[perm] = noisy(point, 14)          # destination feature of correspondence i: row perm[i]
+        in_map = np.nonzero(world["map_index"] >= 0)[0]
+        map_desc = np.empty((M, 64), np.uint8)
+        map_desc[world["map_index"][in_map]] = noisy(point[in_map], 10)
+        d_src, d_dst, d_map = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (src_desc, dst_desc, map_desc))
+        probs = []
+        for i in range(4):
+            q = dict(world)
+            q["seed"] = 70 + i
+            q.pop("map_index")
+            if i % 2 == 0:     # source id < destination id: the temporary map keeps the SOURCE frame's descriptors
+                q.update(d_first_desc=d_src.data_ptr(), first_feature=np.arange(n, dtype=np.int32), d_map_desc=d_map.data_ptr())
+            else:              # destination id lower: the destination frame's
+                q.update(d_first_desc=d_dst.data_ptr(), first_feature=perm.astype(np.int32), d_map_desc=d_map.data_ptr())
+            probs.append(q)
+        res = inter_pose_batch(ctxs, probs, world["map_X"])
+        short = inter_pose_batch(ctxs, [dict(world, seed=70 + i) for i in range(4)], world["map_X"])
+        for i, (p, r, sh) in enumerate(zip(probs, res, short)):
+            assert r["status"] == 0 and r["stage"] == 0, (i, r["stage"])
+            first = src_desc if i % 2 == 0 else dst_desc
+            rows = p["first_feature"]
+
+            def common(qi):
+                m = oracle.k2nn(map_desc, first[rows[qi]], 60)        # Q = global map, T = the temporary map's descriptors
+                g = np.nonzero(m >= 0)[0]
+                return g, m[g]
+            ref = _numpy_chain(ctxs[0], dict(world), r, common)
+            assert r["n_front"] == ref["n_front"] and r["n_map_matches"] == ref["n_raw"] and r["n_common"] == ref["n_common"]
+            assert r["n_map_matches"] > 0.5 * len(in_map) * len(r["inliers"]) / n
+            assert abs(r["scale"] / ref["scale"] - 1) < 1e-9 and np.allclose(r["Rt"], ref["Rt"], atol=1e-6) and abs(r["rmse"] - ref["rmse"]) < 1e-6
+            # the two sources of common features walk (nearly) the same features in different orders: the same filter result, poses that
+            # agree to the noise of the scale rule
+            assert np.array_equal(r["inliers"], sh["inliers"]) and r["n_front"] == sh["n_front"]
+            assert abs(r["scale"] / sh["scale"] - 1) < 0.02
+            Cd = -p["Rd"].T @ p["td"]
+            for rr in (r, sh):
+                Ce = -rr["Rt"][:, :3].T @ rr["Rt"][:, 3]
+                assert np.linalg.norm(Ce - Cd) < 0.2
+        # all three pointers or none
+        bad = dict(probs[0]); bad.pop("first_feature")
+        with pytest.raises(Exception):
+            inter_pose_batch([ctxs[0]], [bad], world["map_X"])
+    finally:
+        for c in ctxs:
             c.close()
