@@ -31,7 +31,7 @@
 
 namespace clc {
 
-// -DCLC_ACR_STAMP (experiments only, tools/acr_stamps.py): thread 0 of slot workgroup 0 leaves s_memtime at the phase boundaries of
+// -DCLC_ACR_STAMP (experiments only, tools/archive/acr_stamps.py): thread 0 of slot workgroup 0 leaves s_memtime at the phase boundaries of
 // acr_round_kernel in a device array that clc_debug_acr_stamps copies out
 #if defined(CLC_ACR_STAMP)
 __device__ unsigned long long g_acr_stamp[16];

@@ -185,7 +185,7 @@ int clc_k2nn_clock_check(clc_ctx* ctx, const void* d_q, int nq, const void* d_t,
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_stamps);
     if (e != hipSuccess) return fail(ctx, CLC_ERR_HIP, "k2nn_clock_check", e);
-    if (const char* dump = getenv("CLC_K2NN_STAMP_DUMP")) {            // diagnostic: raw per-workgroup stamps for tools/k2nn_timeline.py
+    if (const char* dump = getenv("CLC_K2NN_STAMP_DUMP")) {            // diagnostic: raw per-workgroup stamps for tools/archive/k2nn_timeline.py
         if (FILE* f = fopen(dump, "wb")) { fwrite(h.data(), sizeof(uint64_t), h.size(), f); fclose(f); }
     }
     std::vector<double> ghz;

@@ -117,7 +117,7 @@ __device__ __forceinline__ int clamp_i32(int v, int hi)   // min(max(v, 0), hi) 
 
 __global__ __launch_bounds__(64) void clatch_kernel(const ClatchArgs args, const uint8_t* __restrict__ arena_base)
 {
-    // One keypoint per wave, no loop (the grid is the keypoint count).  Round 3 (tools/clatch_lab.hip, in-kernel stamps): a wave
+    // One keypoint per wave, no loop (the grid is the keypoint count).  Round 3 (tools/archive/clatch_lab.hip, in-kernel stamps): a wave
     // used to spend 4.7 k of its 21.5 k cycles before its first gather -- it waited for its eight slot-table loads, THEN fetched
     // the keypoint with a vector load, THEN the level -- so: the table loads are issued first and consumed after the fill (they
     // are only needed by the tests), the keypoint comes through the scalar unit, and the copy phase is straight-line code with

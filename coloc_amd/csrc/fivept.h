@@ -20,7 +20,7 @@
 // fp64 throughout.  Inputs are NORMALISED image coordinates (K^-1 applied).
 //
 // This file is the sequential statement of the algorithm (it runs on the host in tests/test_fivept_host.py and
-// tools/fivept_host.cpp) plus the per-element math shared with the GPU form; csrc/fivept_wave.h lays the same steps out over
+// tools/archive/fivept_host.cpp) plus the per-element math shared with the GPU form; csrc/fivept_wave.h lays the same steps out over
 // the 64 lanes of one wave.
 #ifndef CLC_FIVEPT_H
 #define CLC_FIVEPT_H
@@ -119,7 +119,7 @@ __device__ __forceinline__ double fpt_rcp_rough(const double x) { return __built
 FPT_HD double fpt_rcp(const double x) { return 1.0 / x; }
 FPT_HD double fpt_rcp_rough(const double x) { return 1.0 / x; }
 #endif
-// phase time stamps for tools/fivept_bench.hip (no-op in the library)
+// phase time stamps for tools/archive/fivept_bench.hip (no-op in the library)
 #ifndef FPT_STAMP
 #define FPT_STAMP(i) ((void)0)
 #endif

@@ -343,7 +343,7 @@ __device__ __forceinline__ uint32_t mx_decode_rel(const uint32_t bits, const uin
 
 // STAMP: diagnostic build for the clock check (MI355X guide, DVFS item 6): lane 0 of every workgroup brackets its tile loop
 // with s_memtime (shader clock) / s_memrealtime (constant 100 MHz) and stores them, with its entry / folded-in times and its
-// XCC id (tools/k2nn_timeline.py), in a buffer nothing else reads.  The product kernel (STAMP = false) contains no stamp.
+// XCC id (tools/archive/k2nn_timeline.py), in a buffer nothing else reads.  The product kernel (STAMP = false) contains no stamp.
 //
 // The loop (round 3): the two 32-query tiles of a wave are swept as two MFMA chains of eight, one after the other, and the
 // running top-2 of a chain's accumulators is updated in the shadow of the NEXT chain's MFMAs (sched_group_barrier spells the
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64 * kMxWaves) void k2nn_sweep_mx_kernel(const K2nn
     // The wave's 64 rows are fetched with COALESCED 16-byte loads (4 KB = four wave instructions) and handed round
     // through the wave's own LDS staging area; every lane then picks its 8 words per tile.  (Each lane loading its own
     // words straight from memory -- 16 strided dword loads touching 32 cache lines per instruction -- took 11 k cycles
-    // per wave, a quarter of the kernel, measured with in-kernel stamps: tools/k2nn_mfma.hip.)
+    // per wave, a quarter of the kernel, measured with in-kernel stamps: tools/archive/k2nn_mfma.hip.)
     mx_v4i b[QT][8];
     {
         uint32_t* stage = s_mem + wave * (QT * 32 * kQRow);

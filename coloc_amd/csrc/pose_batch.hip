@@ -394,7 +394,7 @@ void drive_runs(std::vector<AcrRun>& runs)
 // launches finds nothing to replay and returns.  Why: eight interleaved poses were ~80 launches from one thread (4-5 us each inside the
 // runtime, and the runtime serialises launching threads), eight two-view filters ~100; in lockstep they are ~10 and ~16.  Same bits per
 // solve: a chain's kernels take its batch from its own device state, the grid and the sort width (the largest chain's) only bound them.
-// Measured (MI355X, N = 1 000, 30 % outliers, tools/time_two_view.py / time_pose_batch2.py; interleaved -> lockstep, one staging launch
+// Measured (MI355X, N = 1 000, 30 % outliers, tools/time_two_view.py; interleaved -> lockstep, one staging launch
 // for the batch, a round's launches carrying only the solves still in their rounds):
 //     two-view filters   2: 0.417 -> 0.439 ms   4: 0.570 -> 0.574   8: 1.08-1.21 -> 0.75-0.80      (rounds of <= 12 / 16 iterations)
 //     resection poses    2: 0.190 -> 0.189      4: 0.251 -> 0.271   8: 0.514 -> 0.508; with rounds of <= 8 iterations 0.429 (4: 0.295)

@@ -3,7 +3,7 @@
 iteration budgets and thresholds on ONE long-lived context (state, parity copies and pinned blocks are reused from solve to solve);
 model, inlier list (order included), NFA, threshold and iteration count must be identical, every time.  usage: soak_acransac.py [runs]"""
 import math, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, synth, oracle_lib
 from coloc_amd import Context

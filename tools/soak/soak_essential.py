@@ -4,7 +4,7 @@ sequential oracle: random sizes (6 .. 3000), outlier rates, seeds, iteration bud
 entry; model (F and E), inlier list (order included), NFA, threshold and iteration count must be identical, every time.
 usage: soak_essential.py [runs]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, synth, oracle_lib
 from coloc_amd import Context

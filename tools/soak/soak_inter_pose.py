@@ -3,7 +3,7 @@
 worlds (100 .. 2000 correspondences, outlier rates, noise, map coverage), 1 .. 4 pairs per call: same front / common counts, scale to
 1e-9, refined pose to 1e-6, or the same stage of failure.  usage: soak_inter_pose.py [calls]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from coloc_amd import Context

@@ -2,7 +2,7 @@
 """Soak test of the matcher's self re-arming workspace: many random shapes and repeated large calls on one context,
 every result compared with the CPU oracle (tests/oracle_lib.py).  Not part of the test suite (minutes, not seconds)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import synth

@@ -3,7 +3,7 @@
 2 500..30 000 train rows), the three matrix/popcount formulations in turn, every result (indices and both distances) compared with the CPU
 oracle; reports how many shapes took each plan.  Not part of the test suite (minutes)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import synth

@@ -2,7 +2,7 @@
 """Soak test of clc_pnp_localize (pinned staging read/written by the kernels themselves): 600 problems of random size on
 a long-lived context against a fresh context each, results must be identical; poses are checked against ground truth."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, synth
 from coloc_amd import Context
