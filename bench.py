@@ -639,7 +639,7 @@ def main():
             # measured HBM traffic of this kernel comes from separate rocprofv3 --pmc passes (profiles/); it is attached
             # only when the recorded plan (formulation, shape) is the one that just ran, and says where it came from
             traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "r05_k2nn_hbm_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r06_k2nn_hbm_traffic.json")
             if os.path.exists(tpath) and world == 1:
                 try:
                     rec = json.load(open(tpath))
