@@ -78,7 +78,9 @@ def test_job_structs_match_the_c_header(tmp_path):
     from coloc_amd import abi
     probes = {"clc_pose_job": (abi.PoseJob, ["X", "n", "seed", "precision", "refine", "huber_a", "Rt", "n_inliers", "error_max", "rmse"]),
               "clc_two_view_job": (abi.TwoViewJob, ["x1", "K2", "n", "max_iteration", "seed", "precision", "E", "inliers", "n_inliers", "status", "error_max", "min_nfa"]),
-              "clc_inter_pose_job": (abi.InterPoseJob, ["tv", "map_index", "map_X", "map_n", "Rt_source", "huber_a", "Rt", "cov", "rmse", "scale", "n_front", "stage"])}
+              "clc_inter_pose_job": (abi.InterPoseJob, ["tv", "map_index", "map_X", "map_n", "Rt_source", "huber_a", "d_first_desc", "first_feature", "d_map_desc",
+                                                        "match_threshold", "Rt", "cov", "rmse", "scale", "n_front", "stage", "n_map_matches"]),
+              "clc_desc_handle": (abi.DescHandle, ["host", "generation", "count", "slot"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "coloc_hip.h"', 'int main(void) {']
     for name, (_, fields) in probes.items():
         src.append('printf("%s %%zu", sizeof(%s));' % (name, name))
