@@ -49,7 +49,7 @@ class PoseJob(C.Structure):
                 ("n_inliers", C.c_int), ("iterations", C.c_int), ("status", C.c_int), ("error_max", C.c_double), ("rmse", C.c_double)]
 
 
-ABI_VERSION = 3          # CLC_ABI_VERSION of include/coloc_hip.h
+ABI_VERSION = 4          # CLC_ABI_VERSION of include/coloc_hip.h
 DESC_CACHE_OFF, DESC_CACHE_VERIFY, DESC_CACHE_TRUST = 0, 1, 2
 
 class DescHandle(C.Structure):
@@ -85,6 +85,7 @@ EXPORTS = [
     "clc_k2nn_queries_per_block", "clc_k2nn_plan_query", "clc_k2nn_device_info", "clc_pnp_acransac", "clc_pnp_localize_ac", "clc_essential_acransac", "clc_k2nn_clock_check", "clc_ctx_device", "clc_mc_plan", "clc_mc_unique_id",
     "clc_mc_create", "clc_mc_destroy", "clc_mc_last_error_string", "clc_mc_arena", "clc_mc_gather_dev", "clc_mc_match_dev", "clc_mc_virtual_put", "clc_mc_open_peers",
     "clc_mc_gather_enqueue_dev", "clc_mc_match_enqueue_dev", "clc_mc_counts", "clc_mc_set_overlap", "clc_mc_comm_info", "clc_match_jobs_counted_dev",
+    "clc_two_view_acransac", "clc_two_view_acransac_batch", "clc_two_view_minimal",
 ]
 KERNELS = ["pyramid_kernel", "clatch_kernel", "k2nn_sweep_kernel", "k2nn_merge_kernel", "pnp_residual_kernel",
            "pnp_score_kernel", "detect_kernels"]
@@ -194,6 +195,9 @@ def load_library():
     lib.clc_pnp_acransac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, vp, vp, vp, ip, dp, dp, ip]
     lib.clc_pnp_localize_ac.argtypes = [vp, vp, vp, ci, vp, ci, C.c_uint64, C.c_double, C.c_double, vp, vp, vp, vp, ip, dp, dp]
     lib.clc_essential_acransac.argtypes = [vp, vp, vp, ci, vp, vp, ci, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, ip, dp, dp, ip]
+    lib.clc_two_view_acransac.argtypes = [vp, ci, vp, vp, ci, vp, vp, ci, ci, ci, C.c_uint64, C.c_double, vp, vp, vp, vp, ip, dp, dp, ip]
+    lib.clc_two_view_acransac_batch.argtypes = [vp, ci, vp, ci]
+    lib.clc_two_view_minimal.argtypes = [vp, ci, vp, vp, ci, ci, ci, vp, ci, vp]
     lib.clc_mc_plan.argtypes = [vp, ci, ci, ci, ci, vp, ci, ip]
     lib.clc_mc_unique_id.argtypes = [vp]
     lib.clc_mc_create.argtypes = [vp, vp, ci, ci, ci, C.POINTER(vp)]
@@ -268,6 +272,22 @@ def essential_acransac_batch(ctxs, problems, max_iteration=256, precision=float(
         outs.append(_two_view_fill(j, keep, x1, x2, K1, K2, wh, max_iteration, seed, precision))
     hs = (C.c_void_p * n)(*[c.h for c in ctxs])
     rc = lib.clc_essential_acransac_batch(hs, jobs, n)
+    if rc != CLC_OK:
+        raise CLCError(rc, lib.clc_status_string(rc).decode())
+    return [_two_view_result(j, *o) for j, o in zip(jobs, outs)]
+
+
+def two_view_acransac_batch(ctxs, model, problems, max_iteration=256, precision=float("inf")):
+    """clc_two_view_acransac_batch: model 'E' | 'F' | 'H'; problems = [(x1, x2, K1, K2, (w, h), seed), ...] (K1 / K2 read for 'E' only), one
+    Context per problem; -> list of result dicts, "E" = the model matrix (E, F or H in pixels)."""
+    lib = load_library()
+    n = len(problems)
+    jobs = (TwoViewJob * n)()
+    keep, outs = [], []
+    for j, (x1, x2, K1, K2, wh, seed) in zip(jobs, problems):
+        outs.append(_two_view_fill(j, keep, x1, x2, np.eye(3) if K1 is None else K1, np.eye(3) if K2 is None else K2, wh, max_iteration, seed, precision))
+    hs = (C.c_void_p * n)(*[c.h for c in ctxs])
+    rc = lib.clc_two_view_acransac_batch(hs, ord(model), jobs, n)
     if rc != CLC_OK:
         raise CLCError(rc, lib.clc_status_string(rc).decode())
     return [_two_view_result(j, *o) for j, o in zip(jobs, outs)]
@@ -842,6 +862,37 @@ class Context:
         ok = ni.value > 0
         return dict(E=E.reshape(3, 3) if ok else None, F=F.reshape(3, 3) if ok else None, mask=mask[:n].astype(bool),
                     inliers=inl[:ni.value].copy(), error_max=emax.value, min_nfa=nfa.value, iterations=its.value)
+
+    def two_view_acransac(self, model, x1, x2, img_wh, K1=None, K2=None, max_iteration=256, seed=1, precision=float("inf")):
+        """clc_two_view_acransac: the a-contrario filter under model 'E' (five points; K1, K2 needed), 'F' (seven points) or 'H' (four points).
+        Returns a dict: M (3,3: E, F or H in pixels) or None, F (3,3; zeros for 'H') or None, mask, inliers, error_max, min_nfa, iterations."""
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        K1 = None if K1 is None else np.ascontiguousarray(K1, dtype=np.float64).reshape(9)
+        K2 = None if K2 is None else np.ascontiguousarray(K2, dtype=np.float64).reshape(9)
+        n = x1.shape[0]
+        M = np.zeros(9); F = np.zeros(9)
+        mask = np.zeros(max(n, 1), dtype=np.uint8); inl = np.zeros(max(n, 1), dtype=np.int32)
+        ni, its = C.c_int(), C.c_int()
+        emax, nfa = C.c_double(), C.c_double()
+        self._chk(self.lib.clc_two_view_acransac(self.h, ord(model), _p(x1), _p(x2), n, _p(K1), _p(K2), int(img_wh[0]), int(img_wh[1]),
+                                                 int(max_iteration), int(seed), float(precision), _p(M), _p(F), _p(mask), _p(inl),
+                                                 C.byref(ni), C.byref(emax), C.byref(nfa), C.byref(its)))
+        ok = ni.value > 0
+        return dict(M=M.reshape(3, 3) if ok else None, F=F.reshape(3, 3) if ok else None, mask=mask[:n].astype(bool),
+                    inliers=inl[:ni.value].copy(), error_max=emax.value, min_nfa=nfa.value, iterations=its.value)
+
+    def two_view_minimal(self, model, x1, x2, img_wh, samples):
+        """clc_two_view_minimal: the seven-point ('F') / four-point ('H') models of the given samples (S x 7 | 4 indices), in the
+        coordinates conditioned by the image size: array (S, 3 | 1, 9), NaN rows where a sample has fewer real roots."""
+        x1 = np.ascontiguousarray(x1, dtype=np.float64).reshape(-1, 2)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64).reshape(-1, 2)
+        m, M = (7, 3) if model == "F" else (4, 1)
+        smp = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1, m)
+        out = np.zeros((smp.shape[0], M, 9))
+        self._chk(self.lib.clc_two_view_minimal(self.h, ord(model), _p(x1), _p(x2), x1.shape[0], int(img_wh[0]), int(img_wh[1]), _p(smp),
+                                                smp.shape[0], _p(out)))
+        return out
 
     def pnp_refine(self, X, x, K, Rt0, mask=None, huber_a=16.0, max_iter=50):
         """LM refinement of one pose: returns (Rt (3,4), cov (6,6), rmse, iterations)."""

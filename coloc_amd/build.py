@@ -13,7 +13,7 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libcoloc_hip.so")
 SOURCES = ["capi_core.hip", "capi_match.hip", "desc_cache.hip", "capi_pose.hip", "pose_batch.hip", "inter_pose.hip", "inter_geometry.cpp",
            "k2nn.hip", "clatch.hip", "lerp.hip", "pnp.hip", "detect.hip", "acransac.hip", "multicam.hip"]
-HEADERS = ["clc_internal.h", "clc_ctx.h", "desc_cache.h", "inter_geometry.h", "clc_sincos.h", "clc_acr.h", "p3p.h", "fivept.h", "fivept_wave.h", "latch_pattern.inc", "latch_layout.inc", "latch_layout_swap.inc", os.path.join("..", "host", "HIPCovIntersection.hpp"), os.path.join("..", "host", "HIPRobustMatcher.hpp"), os.path.join("..", "host", "coloc_hip_geometry.hpp"), os.path.join("..", "..", "include", "coloc_hip.h")]
+HEADERS = ["clc_internal.h", "clc_ctx.h", "desc_cache.h", "inter_geometry.h", "clc_sincos.h", "clc_acr.h", "p3p.h", "fivept.h", "fivept_wave.h", "twoview_min.h", "latch_pattern.inc", "latch_layout.inc", "latch_layout_swap.inc", os.path.join("..", "host", "HIPCovIntersection.hpp"), os.path.join("..", "host", "HIPRobustMatcher.hpp"), os.path.join("..", "host", "coloc_hip_geometry.hpp"), os.path.join("..", "..", "include", "coloc_hip.h")]
 # -ffp-contract=off: the fp32 sample-coordinate / bilinear expressions and the fp64 residuals must
 # evaluate in source order without fused multiply-add.
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in plain VGPRs (gfx950's register file is unified), so the K2NN top-2 reads

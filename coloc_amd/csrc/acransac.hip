@@ -28,6 +28,7 @@
 #include "clc_acr.h"
 #include "p3p.h"
 #include "fivept_wave.h"
+#include "twoview_min.h"
 
 namespace clc {
 
@@ -57,8 +58,9 @@ __device__ __forceinline__ void acr_finish_block(const AcrProblem& pb, const Acr
         AcrResult r;
         for (int e = 0; e < 18; ++e) r.model[e] = ok ? s.model[e] : 0.0;
         r.min_nfa = s.min_nfa;
-        // unormalizeError: resection sqrt(e) / N1(0,0) -> pixels; essential: the squared pixel distance as it is
-        r.error_max = !ok ? 0.0 : (pb.kind == 0 ? sqrt(s.error_max) / pb.norm : s.error_max);
+        // unormalizeError: resection sqrt(e) / N1(0,0), fundamental / homography sqrt(e) / N2(0,0) -> pixels; essential: the squared
+        // pixel distance as it is
+        r.error_max = !ok ? 0.0 : (pb.kind != 1 ? sqrt(s.error_max) / pb.norm : s.error_max);
         r.n_inliers = n_inl;
         r.valid = ok ? s.best_iter : -1;
         r.iterations = s.iter;
@@ -101,6 +103,26 @@ __device__ __forceinline__ double acr_err_epipolar(const double* __restrict__ f,
     const double b1 = (f[1] * u2 + f[4] * v2) + f[7];
     const double d = (u2 * a0 + v2 * a1) + a2;
     return (d * d) * (1.0 / (a0 * a0 + a1 * a1) + 1.0 / (b0 * b0 + b1 * b1)) / 4.0;
+}
+
+// fundamental::kernel::EpipolarDistanceError: squared distance of x2 to the line F x1 (normalised coordinates); operation order of
+// oracle/clc_oracle_twoview.c orc_tv_residuals
+__device__ __forceinline__ double acr_err_line(const double* __restrict__ f, const double u1, const double v1, const double u2, const double v2)
+{
+    const double a0 = (f[0] * u1 + f[1] * v1) + f[2];
+    const double a1 = (f[3] * u1 + f[4] * v1) + f[5];
+    const double a2 = (f[6] * u1 + f[7] * v1) + f[8];
+    const double d = (u2 * a0 + v2 * a1) + a2;
+    return (d * d) / (a0 * a0 + a1 * a1);
+}
+// homography::kernel::AsymmetricError: squared transfer error |x2 - H x1|^2 (normalised coordinates)
+__device__ __forceinline__ double acr_err_transfer(const double* __restrict__ h, const double u1, const double v1, const double u2, const double v2)
+{
+    const double a0 = (h[0] * u1 + h[1] * v1) + h[2];
+    const double a1 = (h[3] * u1 + h[4] * v1) + h[5];
+    const double a2 = (h[6] * u1 + h[7] * v1) + h[8];
+    const double du = u2 - a0 / a2, dv = v2 - a1 / a2;
+    return du * du + dv * dv;
 }
 
 // (residual bits, index) pairs in lexicographic order: what std::sort does with pair<double, uint32_t>
@@ -426,9 +448,9 @@ __device__ __forceinline__ void acr_nfa_body(const AcrProblem& pb, const int P /
         return;
     }
     auto residual = [&](const int i) -> double {
-        return pb.kind == 0
-            ? acr_err_resection(model, pb.K1v, pb.norm, pb.a[3 * i], pb.a[3 * i + 1], pb.a[3 * i + 2], pb.b[2 * i], pb.b[2 * i + 1])
-            : acr_err_epipolar(model, pb.a[2 * i], pb.a[2 * i + 1], pb.b[2 * i], pb.b[2 * i + 1]);
+        if (pb.kind == 0) return acr_err_resection(model, pb.K1v, pb.norm, pb.a[3 * i], pb.a[3 * i + 1], pb.a[3 * i + 2], pb.b[2 * i], pb.b[2 * i + 1]);
+        const double u1 = pb.a[2 * i], v1 = pb.a[2 * i + 1], u2 = pb.b[2 * i], v2 = pb.b[2 * i + 1];
+        return pb.kind == 1 ? acr_err_epipolar(model, u1, v1, u2, v2) : (pb.kind == 2 ? acr_err_line(model, u1, v1, u2, v2) : acr_err_transfer(model, u1, v1, u2, v2));
     };
     uint64_t key[E];
     uint32_t idx[E];
@@ -766,7 +788,48 @@ __device__ __forceinline__ void acr_keep(const AcrProblem& pb, const AcrCore& c,
 // (state, slots, sorted lists, models); best_inliers / index_set are written by the keeper only in the cases in which the slot
 // workgroups read the other list (acr_sample_source).  The word of round r therefore comes out of launch r + 1 -- early in it, so
 // the host has launch r + 2 enqueued long before r + 1 ends, and the launch that reports "done" is the last one in the stream.
-template <int E>
+// The same one-launch round serves the two cheap two-view solvers (round 6: 'F' seven points, 'H' four points -- twoview_min.h): a
+// slot workgroup solves its iteration's sample on thread 0 (all the slots of an iteration solve the same sample and keep their own
+// root), everything else is the resection round.  KIND = AcrProblem::kind; slots and models keep the resection's strides (4 slots per
+// iteration between the parity copies, 12 doubles per model) so that the host lays one workspace out for all three.
+template <int KIND> struct AcrKind;
+template <> struct AcrKind<0> { static constexpr int m = 3, M = 4; };
+template <> struct AcrKind<2> { static constexpr int m = 7, M = 3; };
+template <> struct AcrKind<3> { static constexpr int m = 4, M = 1; };
+
+// the model of root `root` of the sample {id[0..m)} of a seven-point / four-point problem -> out[0..12) (9 used; NaN: no such root)
+template <int KIND>
+__device__ __forceinline__ void acr_twoview_sample_root(const double* __restrict__ x1, const double* __restrict__ x2, const int (&id)[AcrKind<KIND>::m],
+                                                        const int N, const int root, double* out)
+{
+    constexpr int m = AcrKind<KIND>::m;
+    double a[m][2], b[m][2];
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < m; ++p) {
+        int i = id[p];
+        if (i < 0 || i >= N) { ok = false; i = 0; }
+        a[p][0] = x1[2 * i]; a[p][1] = x1[2 * i + 1];
+        b[p][0] = x2[2 * i]; b[p][1] = x2[2 * i + 1];
+    }
+    const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+    double M9[9];
+    bool have;
+    if constexpr (KIND == 2) {
+        double F[3][9];
+        const int nr = tv::seven_point(a, b, F);
+        have = ok && root < nr;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) M9[e] = root == 0 ? F[0][e] : (root == 1 ? F[1][e] : F[2][e]);
+    } else {
+        have = ok && tv::four_point(a, b, M9) > 0 && root == 0;
+    }
+    have = have && M9[0] == M9[0];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) out[e] = have ? (e < 9 ? M9[e] : 0.0) : qnan;
+}
+
+template <int E, int KIND>
 __device__ __forceinline__ void acr_round_body(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
                                                const int par, const int P /* = blockDim.x * E */, const AcrProblem& pb,
                                                uint32_t* __restrict__ sorted /* [2][slots * n] */,
@@ -786,7 +849,8 @@ __device__ __forceinline__ void acr_round_body(AcrState* __restrict__ states /* 
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
     unsigned long long t_replay = 0;
 #endif
-    constexpr bool kPre = E <= 2;                                   // (more elements per thread: the registers are worth more than the latency)
+    constexpr int m = AcrKind<KIND>::m, M = AcrKind<KIND>::M;
+    constexpr bool kPre = KIND == 0 && E <= 2;                      // (more elements per thread: the registers are worth more than the latency)
     AcrPre<kPre ? E : 1> pre;
     if (kPre && !keeper) acr_prefetch<kPre ? E : 1>(pb, tid, pre);
     const AcrState* st_in = states + (par ^ 1);
@@ -796,7 +860,7 @@ __device__ __forceinline__ void acr_round_body(AcrState* __restrict__ states /* 
     if (tid < 64) {
         AcrCore c = acr_core_load(st_in);
         AcrPick pick{ -1, 0, 0 };
-        if (c.evaluated && c.cur_batch > 0) pick = acr_select_wave<4>(pb, c, hyp_in, tid);   // else: the first launch of a run, or a launch after its end
+        if (c.evaluated && c.cur_batch > 0) pick = acr_select_wave<M>(pb, c, hyp_in, tid);   // else: the first launch of a run, or a launch after its end
         c.evaluated = 1;
         if (tid == 0) { s_core = c; s_pick = pick; }
 #if defined(CLC_ACR_STAMP)
@@ -810,7 +874,7 @@ __device__ __forceinline__ void acr_round_body(AcrState* __restrict__ states /* 
         acr_keep(pb, s, pick, models_in, sorted_in, st_in, states + par, best_inliers, index_set, h_word, fin, s_full, tid, T);
         return;
     }
-    if (slot >= s.cur_batch * 4) return;                            // the grid covers an upper bound of the batch
+    if (slot >= s.cur_batch * M) return;                            // the grid covers an upper bound of the batch
     if (tid == 0) {
 #if defined(CLC_ACR_STAMP)
         if (blockIdx.x == 0) { g_acr_stamp[0] = t_start; g_acr_stamp[1] = t_replay; }
@@ -818,16 +882,17 @@ __device__ __forceinline__ void acr_round_body(AcrState* __restrict__ states /* 
         ACR_STAMP(2);
         const uint32_t* win = pick.best_h >= 0 ? sorted_in + (size_t)pick.best_h * pb.n : nullptr;
         const uint32_t* src = acr_sample_source(s, pick, win, best_inliers, index_set);
-        uint32_t pos[3];
-        clc_acr_sample_t<3>(pb.seed, (uint32_t)(s.iter + (slot >> 2)), (uint32_t)s.n_index, pos);
-        int id[3];
+        uint32_t pos[m];
+        clc_acr_sample_t<m>(pb.seed, (uint32_t)(s.iter + slot / M), (uint32_t)s.n_index, pos);
+        int id[m];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) id[j] = (int)(src ? src[pos[j]] : pos[j]);
+        for (int j = 0; j < m; ++j) id[j] = (int)(src ? src[pos[j]] : pos[j]);
 #if defined(CLC_ACR_STAMP)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         ACR_STAMP(3);
-        p3p_sample_root(pb.a, pb.b, pb.K1v, id[0], id[1], id[2], pb.n, slot & 3, s_model);
+        if constexpr (KIND == 0) p3p_sample_root(pb.a, pb.b, pb.K1v, id[0], id[1], id[2], pb.n, slot & 3, s_model);
+        else acr_twoview_sample_root<KIND>(pb.a, pb.b, id, pb.n, slot % M, s_model);
         ACR_STAMP(4);
         double* mo = models + ((size_t)par * kSlots + slot) * 12;
 #pragma unroll
@@ -839,7 +904,7 @@ __device__ __forceinline__ void acr_round_body(AcrState* __restrict__ states /* 
                           reinterpret_cast<uint64_t*>(acr_lds), &pre);
 }
 
-template <int E>
+template <int E, int KIND>
 __global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ states /* [2] */, AcrHyp* __restrict__ hyps /* [2][slots] */,
                                                          const int par, const int P /* = blockDim.x * E */, const AcrProblem pb,
                                                          uint32_t* __restrict__ sorted /* [2][slots * n] */,
@@ -847,14 +912,41 @@ __global__ __launch_bounds__(1024) void acr_round_kernel(AcrState* __restrict__ 
                                                          uint32_t* __restrict__ best_inliers, uint32_t* __restrict__ index_set,
                                                          unsigned long long* __restrict__ h_word, const AcrFinish fin)
 {
-    acr_round_body<E>(states, hyps, par, P, pb, sorted, models, best_inliers, index_set, h_word, fin);
+    acr_round_body<E, KIND>(states, hyps, par, P, pb, sorted, models, best_inliers, index_set, h_word, fin);
 }
 // the same round for up to kMaxBatch solves at once: blockIdx.y = chain (same code, same bits: the file is compiled without contraction)
-template <int E>
+template <int E, int KIND>
 __global__ __launch_bounds__(1024) void acr_round_chains_kernel(const AcrChains chains, const int par, const int P)
 {
     const AcrChain& ch = chains.c[blockIdx.y];
-    acr_round_body<E>(ch.states, ch.hyps, par, P, ch.pb, ch.sorted, ch.models, ch.best_inliers, ch.index_set, ch.h_word, ch.fin);
+    acr_round_body<E, KIND>(ch.states, ch.hyps, par, P, ch.pb, ch.sorted, ch.models, ch.best_inliers, ch.index_set, ch.h_word, ch.fin);
+}
+
+// The seven-point / four-point models of caller-chosen samples (clc_two_view_minimal: the hypothesis generator the tests hand to the
+// sequential oracle, as p3p_kernel / fivept_kernel are for the other two kinds): one thread per (sample, root), the body the round runs.
+template <int KIND>
+__global__ __launch_bounds__(64) void twoview_minimal_kernel(const double* __restrict__ x1, const double* __restrict__ x2, const int N,
+                                                             const int32_t* __restrict__ samples, const int S, double* __restrict__ out /* S x M x 9 */)
+{
+    constexpr int m = AcrKind<KIND>::m, M = AcrKind<KIND>::M;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= S * M) return;
+    const int sidx = t / M, root = t % M;
+    int id[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) id[j] = samples[sidx * m + j];
+    double mo[12];
+    acr_twoview_sample_root<KIND>(x1, x2, id, N, root, mo);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) out[(size_t)t * 9 + e] = mo[e];
+}
+hipError_t launch_twoview_minimal(int kind, const double* d_x1, const double* d_x2, int N, const int32_t* d_samples, int S, double* d_out, hipStream_t stream)
+{
+    if (S <= 0) return hipSuccess;
+    if (kind == 2) hipLaunchKernelGGL(twoview_minimal_kernel<2>, dim3((S * 3 + 63) / 64), dim3(64), 0, stream, d_x1, d_x2, N, d_samples, S, d_out);
+    else if (kind == 3) hipLaunchKernelGGL(twoview_minimal_kernel<3>, dim3((S + 63) / 64), dim3(64), 0, stream, d_x1, d_x2, N, d_samples, S, d_out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
 }
 
 // ---- the five-point round in TWO launches (round 5) ---------------------------------------------------------------------------
@@ -941,8 +1033,8 @@ static hipError_t acr_launch_nfa(const AcrProblem& pb, int B, int P, const doubl
     return hipGetLastError();
 }
 
-template <int E>
-static hipError_t acr_launch_round_p3p(const AcrProblem& pb, int B, int P, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted,
+template <int E, int KIND>
+static hipError_t acr_launch_round_one(const AcrProblem& pb, int B, int P, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted,
                                        double* d_models, uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word,
                                        const AcrFinish& fin, hipStream_t stream)
 {
@@ -950,15 +1042,26 @@ static hipError_t acr_launch_round_p3p(const AcrProblem& pb, int B, int P, int p
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        const hipError_t e = hipFuncSetAttribute((const void*)acr_round_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcrMaxLds);
+        const hipError_t e = hipFuncSetAttribute((const void*)acr_round_kernel<E, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kAcrMaxLds);
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
     const int T = P / E;
     const size_t lds = (T > 64 ? (size_t)P * 8 : 0) + (E <= 8 ? (size_t)P * 8 : 0);
-    hipLaunchKernelGGL(acr_round_kernel<E>, dim3(B * 4 + 1 /* the keeper */), dim3(T), lds, stream, d_states, d_hyps, par, P, pb, d_sorted,
-                       d_models, d_best_inliers, d_index_set, h_word, fin);
+    hipLaunchKernelGGL((acr_round_kernel<E, KIND>), dim3(B * AcrKind<KIND>::M + 1 /* the keeper */), dim3(T), lds, stream, d_states, d_hyps, par, P, pb,
+                       d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin);
     return hipGetLastError();
+}
+template <int KIND>
+static hipError_t acr_launch_round_kind(const AcrProblem& pb, int B, int P, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted,
+                                        double* d_models, uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word,
+                                        const AcrFinish& fin, hipStream_t stream)
+{
+    if (P <= 1024) return acr_launch_round_one<1, KIND>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (P == 2048) return acr_launch_round_one<2, KIND>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (P == 4096) return acr_launch_round_one<4, KIND>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (P == 8192) return acr_launch_round_one<8, KIND>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    return acr_launch_round_one<16, KIND>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
 }
 
 hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted, double* d_models,
@@ -969,11 +1072,11 @@ hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_state
     int P = 64;
     while (P < pb.n) P <<= 1;
     const AcrFinish fin{ d_mask, d_res, h_mask, h_inliers, h_res };
-    if (P <= 1024) return acr_launch_round_p3p<1>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
-    if (P == 2048) return acr_launch_round_p3p<2>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
-    if (P == 4096) return acr_launch_round_p3p<4>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
-    if (P == 8192) return acr_launch_round_p3p<8>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
-    return acr_launch_round_p3p<16>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    // (kind 0: P3P; 2 / 3: the seven-point / four-point models -- one launch per round for all three)
+    if (pb.kind == 2) return acr_launch_round_kind<2>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (pb.kind == 3) return acr_launch_round_kind<3>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
+    if (pb.kind != 0) return hipErrorInvalidValue;
+    return acr_launch_round_kind<0>(pb, B, P, par, d_states, d_hyps, d_sorted, d_models, d_best_inliers, d_index_set, h_word, fin, stream);
 }
 
 // the two-view round: acr_solve5_kernel (replay + samples + five-point; the keeper publishes the PREVIOUS round's word) and the nfa
@@ -1022,27 +1125,37 @@ static int acr_chains_width(const AcrChains& chains, int n_chains)
     for (int c = 0; c < n_chains; ++c) while (P < chains.c[c].pb.n) P <<= 1;
     return P;
 }
-template <int E>
-static hipError_t acr_launch_round_p3p_chains(const AcrChains& chains, int n_chains, int B, int P, int par, hipStream_t stream)
+template <int E, int KIND>
+static hipError_t acr_launch_round_one_chains(const AcrChains& chains, int n_chains, int B, int P, int par, hipStream_t stream)
 {
     static bool attr_set[64] = {};
-    const hipError_t e = acr_dyn_lds(acr_round_chains_kernel<E>, attr_set);
+    const hipError_t e = acr_dyn_lds(acr_round_chains_kernel<E, KIND>, attr_set);
     if (e != hipSuccess) return e;
     const int T = P / E;
     const size_t lds = (T > 64 ? (size_t)P * 8 : 0) + (E <= 8 ? (size_t)P * 8 : 0);
-    hipLaunchKernelGGL(acr_round_chains_kernel<E>, dim3(B * 4 + 1 /* the keeper */, n_chains), dim3(T), lds, stream, chains, par, P);
+    hipLaunchKernelGGL((acr_round_chains_kernel<E, KIND>), dim3(B * AcrKind<KIND>::M + 1 /* the keeper */, n_chains), dim3(T), lds, stream, chains, par, P);
     return hipGetLastError();
+}
+template <int KIND>
+static hipError_t acr_launch_round_kind_chains(const AcrChains& chains, int n_chains, int B, int P, int par, hipStream_t stream)
+{
+    if (P <= 1024) return acr_launch_round_one_chains<1, KIND>(chains, n_chains, B, P, par, stream);
+    if (P == 2048) return acr_launch_round_one_chains<2, KIND>(chains, n_chains, B, P, par, stream);
+    if (P == 4096) return acr_launch_round_one_chains<4, KIND>(chains, n_chains, B, P, par, stream);
+    if (P == 8192) return acr_launch_round_one_chains<8, KIND>(chains, n_chains, B, P, par, stream);
+    return acr_launch_round_one_chains<16, KIND>(chains, n_chains, B, P, par, stream);
 }
 hipError_t launch_acr_round_p3p_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream)
 {
     if (n_chains < 1 || n_chains > kMaxBatch) return hipErrorInvalidValue;
     const int B = batch_bound < 1 ? 1 : (batch_bound > kAcrMaxBatch ? kAcrMaxBatch : batch_bound);
     const int P = acr_chains_width(chains, n_chains);                // every chain sorts at the widest chain's width: the order of its n real elements is the same
-    if (P <= 1024) return acr_launch_round_p3p_chains<1>(chains, n_chains, B, P, par, stream);
-    if (P == 2048) return acr_launch_round_p3p_chains<2>(chains, n_chains, B, P, par, stream);
-    if (P == 4096) return acr_launch_round_p3p_chains<4>(chains, n_chains, B, P, par, stream);
-    if (P == 8192) return acr_launch_round_p3p_chains<8>(chains, n_chains, B, P, par, stream);
-    return acr_launch_round_p3p_chains<16>(chains, n_chains, B, P, par, stream);
+    const int kind = chains.c[0].pb.kind;                            // (a batch is one kind: check_batch / drive_group)
+    for (int c = 1; c < n_chains; ++c) if (chains.c[c].pb.kind != kind) return hipErrorInvalidValue;
+    if (kind == 2) return acr_launch_round_kind_chains<2>(chains, n_chains, B, P, par, stream);
+    if (kind == 3) return acr_launch_round_kind_chains<3>(chains, n_chains, B, P, par, stream);
+    if (kind != 0) return hipErrorInvalidValue;
+    return acr_launch_round_kind_chains<0>(chains, n_chains, B, P, par, stream);
 }
 template <int E>
 static hipError_t acr_launch_nfa_chains(const AcrChains& chains, int n_chains, int B, int P, int par, hipStream_t stream)

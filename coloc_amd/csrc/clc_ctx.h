@@ -137,7 +137,7 @@ int run_jobs(clc_ctx* ctx, std::vector<K2nnJobDev>& jobs, hipStream_t st, bool p
 void k2nn_probe_bias(clc_ctx* ctx);                       // once per process and device: which unequal shares suit this device
 
 // all two-view a-contrario filters of a batch (pose_batch.hip); jobs[i] on ctxs[i]
-int acr_two_view_batch(clc_ctx* const* ctxs, clc_two_view_job* const* jobs, int n_jobs);
+int acr_two_view_batch(clc_ctx* const* ctxs, clc_two_view_job* const* jobs, int n_jobs, int kind /* 1 'E', 2 'F', 3 'H' */);
 int check_batch_contexts(clc_ctx* const* ctxs, int n_jobs, const char* what);
 
 } // namespace clc

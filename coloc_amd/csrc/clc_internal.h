@@ -194,17 +194,18 @@ static constexpr int kAcrMaxBatch = 128;           // iterations evaluated per r
 static constexpr int kAcrMaxN = 16384;             // correspondences per solve: 8 B x 16 384 = 128 KB of LDS per model slot (16 elements per thread)
 static constexpr size_t kAcrMaxLds = (size_t)kAcrMaxN * 8;
 struct AcrProblem {        // passed by value to every kernel of a solve
-    int kind;              // 0: resection (P3P, [R|t] models of 12 doubles), 1: essential (five-point, {F, E} models of 18)
+    int kind;              // 0: resection (P3P, [R|t] models of 12 doubles), 1: essential (five-point, {F, E} models of 18),
+                           // 2: fundamental (seven-point), 3: homography (four-point): 9 doubles in a stride of 12, normalised coordinates
     int n, m, max_models, model_doubles;
     int batch_cap;         // most iterations a round evaluates (<= kAcrMaxBatch): the schedule, not the result, depends on it
-    const double* a;       // X (3 n)  | x1 (2 n)
+    const double* a;       // X (3 n)  | x1 (2 n; kinds 2, 3: conditioned by the image size)
     const double* b;       // x (2 n)  | x2 (2 n)
     const double* K1;      // 9 doubles row-major (+ padding)
     const double* K2;
     const float* logc_n;   // log10 C(n, k), k = 0..n
     const float* logc_k;   // log10 C(k, m)
     double loge0, logalpha0, mult, max_threshold;
-    double norm;           // resection: 1 / focal (residuals are scaled to the normalised camera plane); essential: 1
+    double norm;           // resection: 1 / focal (residuals are scaled to the normalised camera plane); essential: 1; kinds 2, 3: N2(0,0)
     uint64_t seed;
     double K1v[9];         // resection: K1 by value -- kernel arguments sit in scalar registers, a load of K1 is a ~1 us round trip
 };
@@ -252,7 +253,9 @@ hipError_t launch_acr_round_p3p_chains(const AcrChains& chains, int n_chains, in
 hipError_t launch_acr_round_5pt_chains(const AcrChains& chains, int n_chains, int par, int batch_bound, hipStream_t stream);
 // batch_bound: iterations the launch grids cover (>= the batch the device state asks for); d_mask .. h_res: where the round that
 // completes the run leaves mask / inlier list / result record (device copies + pinned host mirrors)
-// the resection round as ONE launch (replay of the previous round + P3P + nfa; acransac.hip): d_states / d_hyps / d_sorted / d_models
+// the seven-point / four-point models (kind 2: <= 3 per sample, kind 3: 1) of S samples of normalised correspondences: d_out S x M x 9, NaN = no model
+hipError_t launch_twoview_minimal(int kind, const double* d_x1, const double* d_x2, int N, const int32_t* d_samples, int S, double* d_out, hipStream_t stream);
+// the resection round (and the rounds of kinds 2 / 3, by pb.kind) as ONE launch (replay of the previous round + solve + nfa; acransac.hip): d_states / d_hyps / d_sorted / d_models
 // hold two copies, this launch reads copy par ^ 1 and writes copy par; the initial state goes into copy 1 and the first launch has par 0
 hipError_t launch_acr_round_p3p(const AcrProblem& pb, int par, AcrState* d_states, AcrHyp* d_hyps, uint32_t* d_sorted, double* d_models,
                                 uint32_t* d_best_inliers, uint32_t* d_index_set, unsigned long long* h_word, hipStream_t stream,

@@ -110,7 +110,7 @@ int clc_inter_pose_batch(clc_ctx* const* ctxs, clc_inter_pose_job* jobs, int n_j
     // 1. the a-contrario five-point filters of all pairs, their chains of launches interleaved (or sharing their launches)
     std::vector<clc_two_view_job*> tv((size_t)n_jobs);
     for (int i = 0; i < n_jobs; ++i) tv[(size_t)i] = &jobs[i].tv;
-    int worst = acr_two_view_batch(ctxs, tv.data(), n_jobs);
+    int worst = acr_two_view_batch(ctxs, tv.data(), n_jobs, 1);
     struct Pending { int job; int32_t* ready; double* rec; };
     std::vector<Pending> pend;
     std::vector<InterFront> fr((size_t)n_jobs);

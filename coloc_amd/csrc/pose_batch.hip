@@ -1,8 +1,10 @@
 // pose_batch.hip -- the a-contrario robust solvers behind the C ABI (include/coloc_hip.h): what Localizer::localizeImage
 // (reference include/coloc/Localizer.hpp:82-93, SfM_Localizer::Localize with error_max = +inf) and RobustMatcher::filterEssential
-// (RobustMatcher.hpp:153-171, robust::ACRANSAC) run, single solves and batches of them driven from one host thread.
+// (RobustMatcher.hpp:153-171, robust::ACRANSAC) run -- and, since round 6, filterFundamental / filterHomography (:128-151, :188-239) --,
+// single solves and batches of them driven from one host thread.
 #include "clc_ctx.h"
 #include "clc_acr.h"
+#include "twoview_min.h"
 
 #include <algorithm>
 #include <chrono>
@@ -48,8 +50,11 @@ void acr_tables(int n, int m, float* logc_n, float* logc_k, std::vector<float>& 
 
 size_t dbl(size_t bytes) { return (bytes + 7) / 8; }
 
-// kind 0: a = X (3 N), b = x (2 N), K1 = intrinsics; kind 1: a = x1, b = x2 (2 N each), K1 / K2, image 2 of img_w x img_h.
-// h_model: 12 doubles [R|t] (kind 0) or {E (9), F (9)} (kind 1).
+// kind 0: a = X (3 N), b = x (2 N), K1 = intrinsics; kind 1: a = x1, b = x2 (2 N each), K1 / K2, image 2 of img_w x img_h;
+// kinds 2 / 3 (round 6: RobustMatcher's 'F' / 'H' models, RobustMatcher.hpp:128-151, :188-239): a = x1, b = x2 in pixels, both images
+// img_w x img_h -- the points are conditioned by the image size on their way into the pinned block (ACKernelAdaptor), the rounds are
+// the resection's one-launch rounds with the seven-point / four-point solve in place of P3P, the model is brought back to pixels in finish().
+// h_model: 12 doubles [R|t] (kind 0), {E (9), F (9)} (kind 1), F or H (9, pixels; kinds 2 / 3).
 //
 // One a-contrario solve as a small state machine (round 4): begin() stages the inputs and enqueues the first two rounds, poll() looks at the
 // pinned progress word ONCE -- if the round the host waits for has come out it enqueues the next one (rounds stay enqueued one ahead of
@@ -73,6 +78,7 @@ struct AcrRun {
     int m = 0, M = 0, md = 0;
     bool refine = false;
     AcrProblem pb{};
+    tv::Normalizer norm_t{};          // kinds 2, 3: the conditioning of both point sets
     hipStream_t st = nullptr;
     int launches = 0, bound = 0, reserve0 = 0;
     uint32_t round = 0, spins = 0;
@@ -102,9 +108,9 @@ struct AcrRun {
     int enqueue_round(const int bnd)
     {
         const int S = bnd < 1 ? 1 : (bnd > kAcrMaxBatch ? kAcrMaxBatch : bnd);
-        if (kind == 0) {
-            // one launch: replay of the previous round, this round's samples, P3P, residuals / sort / NFA; the word of round r comes
-            // out of launch r + 1
+        if (kind != 1) {
+            // one launch: replay of the previous round, this round's samples, P3P (seven-point, four-point), residuals / sort / NFA;
+            // the word of round r comes out of launch r + 1
             CLC_HIP(ctx, launch_acr_round_p3p(pb, launches & 1, d_state, d_hyp, d_sorted, d_models, d_best, d_index, h_word, st, S, d_mask,
                                               d_res, nullptr, p_inl, h_res));
         } else {
@@ -120,9 +126,11 @@ struct AcrRun {
     // validates, stages, enqueues the first two rounds.  Returns a status; phase == DONE afterwards means there is nothing to wait for.
     int begin()
     {
-        m = kind == 0 ? 3 : 5; M = kind == 0 ? 4 : 10; md = kind == 0 ? 12 : 18;
+        static const int k_m[4] = { 3, 5, 7, 4 }, k_M[4] = { 4, 10, 3, 1 }, k_md[4] = { 12, 18, 12, 12 };
+        if (kind < 0 || kind > 3) return stop(fail(ctx, CLC_ERR_BAD_ARG, "acransac: unknown model"));
+        m = k_m[kind]; M = k_M[kind]; md = k_md[kind];
         const int ad = kind == 0 ? 3 : 2;
-        if (!ctx || N < 0 || max_iteration < 0 || !h_K1 || (kind == 1 && !h_K2) || (N > 0 && (!h_a || !h_b)))
+        if (!ctx || N < 0 || max_iteration < 0 || (kind <= 1 && !h_K1) || (kind == 1 && !h_K2) || (N > 0 && (!h_a || !h_b)))
             return stop(fail(ctx, CLC_ERR_BAD_ARG, "acransac: bad argument"));
         if (n_inliers) *n_inliers = 0;
         if (error_max) *error_max = 0.0;
@@ -133,7 +141,7 @@ struct AcrRun {
         if (N <= m || max_iteration == 0) return stop(CLC_OK);                 // ACRANSAC: nData <= sizeSample -> (0, 0), no model
         if (N > kAcrMaxN) return stop(fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 16384 correspondences per solve"));
         if (max_iteration > 500000) return stop(fail(ctx, CLC_ERR_CAPACITY, "acransac: more than 500000 iterations"));
-        if (kind == 1 && (img_w <= 0 || img_h <= 0)) return stop(fail(ctx, CLC_ERR_BAD_ARG, "acransac: image size needed for the point-to-line model"));
+        if (kind >= 1 && (img_w <= 0 || img_h <= 0)) return stop(fail(ctx, CLC_ERR_BAD_ARG, "acransac: image size needed for the two-view models"));
         phase = DONE; status = CLC_ERR_HIP;                                     // (what an early CLC_HIP return leaves behind)
         const int rc0 = begin_body(ad);
         if (rc0 != CLC_OK) { phase = DONE; status = rc0; }
@@ -150,12 +158,13 @@ struct AcrRun {
         const size_t in_d = (size_t)(ad + 2) * N + 32 + 2 * dbl(sizeof(float) * ((size_t)N + 1)) + state_d;
         // a round's launches read what the round before them wrote: two copies of state, models, slots and sorted lists, indexed by
         // launch parity (acransac.hip: acr_round_kernel, acr_solve5_kernel)
-        if (grouped) batch_cap = kind == 0 ? 8 : 12;                   // (a shared launch carries every chain's speculative slots: shorter rounds)
+        if (grouped) batch_cap = kind == 1 ? 12 : 8;                   // (a shared launch carries every chain's speculative slots: shorter rounds)
         if (const char* e = getenv("CLC_ACR_BATCH_CAP")) { const int v = atoi(e); if (v >= 1 && v <= kAcrMaxBatch) batch_cap = v; }
         const int copies = 2;
-        const size_t models_d = (size_t)copies * kAcrMaxBatch * M * md;
-        const size_t hyp_d = dbl(acr_hyp_bytes() * copies * kAcrMaxBatch * M);
-        const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)copies * kAcrMaxBatch * M * N);
+        const int Ms = kind == 1 ? 10 : 4;                             // slots per iteration between the parity copies (the kernels' stride)
+        const size_t models_d = (size_t)copies * kAcrMaxBatch * Ms * md;
+        const size_t hyp_d = dbl(acr_hyp_bytes() * copies * kAcrMaxBatch * Ms);
+        const size_t sorted_d = dbl(sizeof(uint32_t) * (size_t)copies * kAcrMaxBatch * Ms * N);
         const size_t idx_d = dbl(sizeof(uint32_t) * (size_t)N);
         const size_t res_d = dbl(sizeof(AcrResult)), mask_d = dbl((size_t)N);
         const size_t ref_d = refine ? dbl(pnp_refine_out_bytes()) : 0;
@@ -182,11 +191,22 @@ struct AcrRun {
         d_mask = (uint8_t*)d;                  d += mask_d;
         d_ref = d;
         double* hp = (double*)ctx->h_pin;
-        memcpy(hp, h_a, sizeof(double) * ad * N);
-        memcpy(hp + (size_t)ad * N, h_b, sizeof(double) * 2 * N);
+        if (kind >= 2) {
+            // ACKernelAdaptor: NormalizePoints(x, &x_, &N_, w, h) for both point sets (x_n = d x + t, oracle/clc_oracle_twoview.c orc_tv_normalize)
+            norm_t = tv::normalizer(img_w, img_h);
+            double* q1 = hp;
+            double* q2 = hp + (size_t)2 * N;
+            for (int i = 0; i < N; ++i) {
+                q1[2 * i] = h_a[2 * i] * norm_t.d + norm_t.tx; q1[2 * i + 1] = h_a[2 * i + 1] * norm_t.d + norm_t.ty;
+                q2[2 * i] = h_b[2 * i] * norm_t.d + norm_t.tx; q2[2 * i + 1] = h_b[2 * i + 1] * norm_t.d + norm_t.ty;
+            }
+        } else {
+            memcpy(hp, h_a, sizeof(double) * ad * N);
+            memcpy(hp + (size_t)ad * N, h_b, sizeof(double) * 2 * N);
+        }
         double* hK = hp + (size_t)(ad + 2) * N;
         memset(hK, 0, sizeof(double) * 32);
-        memcpy(hK, h_K1, sizeof(double) * 9);
+        if (h_K1) memcpy(hK, h_K1, sizeof(double) * 9);
         if (h_K2) memcpy(hK + 16, h_K2, sizeof(double) * 9);
         float* h_cn = (float*)(hK + 32);
         float* h_ck = (float*)(hK + 32 + dbl(sizeof(float) * ((size_t)N + 1)));
@@ -220,12 +240,19 @@ struct AcrRun {
             pb.mult = 1.0;
             pb.norm = 1.0 / h_K1[0];
             for (int e = 0; e < 9; ++e) pb.K1v[e] = h_K1[e];
-        } else {
+        } else if (kind == 1) {
             // ACKernelAdaptorEssential: point-to-line, logalpha0 = log10(2 D / A * 0.5) of image 2, error^(1/2)
             const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
             pb.logalpha0 = clc_acr_log10(2.0 * D / A * .5);
             pb.mult = 0.5;
             pb.norm = 1.0;
+        } else {
+            // ACKernelAdaptor on conditioned points: 'F' point-to-line, log10(2 D / A / N2(0,0)), error^(1/2); 'H' point-to-point,
+            // log10(pi / A / N2(0,0)^2); thresholds and the reported precision scale with N2(0,0) = d
+            const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
+            pb.norm = norm_t.d;
+            if (kind == 2) { pb.logalpha0 = clc_acr_log10(2.0 * D / A / pb.norm); pb.mult = 0.5; }
+            else { pb.logalpha0 = clc_acr_log10(M_PI / A / (pb.norm * pb.norm)); pb.mult = 1.0; }
         }
         pb.max_threshold = std::isinf(precision) ? INFINITY : precision * (pb.norm * pb.norm);
         pb.seed = seed;
@@ -348,7 +375,11 @@ struct AcrRun {
         const AcrResult r = *h_res;
         if (h_model) {
             if (kind == 0) memcpy(h_model, r.model, sizeof(double) * 12);
-            else { memcpy(h_model, r.model + 9, sizeof(double) * 9); memcpy(h_model + 9, r.model, sizeof(double) * 9); }   // slots hold {F, E}
+            else if (kind >= 2) {
+                // Unnormalize(&model): F = N2^T Fn N1, H = N2^-1 Hn N1 (no model: zeros stay zeros)
+                if (r.n_inliers > 0) tv::unnormalize(kind == 3, norm_t, r.model, h_model);
+                else memset(h_model, 0, sizeof(double) * 9);
+            } else { memcpy(h_model, r.model + 9, sizeof(double) * 9); memcpy(h_model + 9, r.model, sizeof(double) * 9); }   // slots hold {F, E}
         }
         // the mask is rebuilt from the inlier list here (h_mask was cleared above): the device does not push N bytes + one scattered byte
         // per inlier over PCIe for it
@@ -409,7 +440,7 @@ bool acr_lockstep(const int kind, const int n_jobs)
     static const int mode = [] { const char* e = getenv("CLC_ACR_LOCKSTEP"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
     if (n_jobs < 2 || mode == 0) return false;
     if (mode == 1) return true;
-    return kind == 1 ? n_jobs >= 4 : n_jobs >= 8;
+    return kind == 1 ? n_jobs >= 4 : n_jobs >= 8;      // (kinds 2, 3 run the resection's one-launch rounds: its break-even)
 }
 void drive_group(std::vector<AcrRun>& runs)
 {
@@ -447,7 +478,7 @@ void drive_group(std::vector<AcrRun>& runs)
         int n = 0;
         auto flush = [&]() -> bool {
             if (n == 0) return true;
-            const hipError_t e = kind == 0 ? launch_acr_round_p3p_chains(pack, n, launches & 1, bound, st)
+            const hipError_t e = kind != 1 ? launch_acr_round_p3p_chains(pack, n, launches & 1, bound, st)
                                            : launch_acr_round_5pt_chains(pack, n, launches & 1, bound, st);
             n = 0;
             if (e != hipSuccess) { fail_all(fail(ctx0, CLC_ERR_HIP, "acransac: shared round launch", e)); return false; }
@@ -592,17 +623,66 @@ int clc_essential_acransac(clc_ctx* ctx, const double* h_x1, const double* h_x2,
     return rc;
 }
 
+// RobustMatcher's model letter -> the solve kind (colocParams::model, RobustMatcher.hpp:399-405)
+static int two_view_kind(const int model) { return model == CLC_MODEL_ESSENTIAL ? 1 : (model == CLC_MODEL_FUNDAMENTAL ? 2 : (model == CLC_MODEL_HOMOGRAPHY ? 3 : -1)); }
+
+int clc_two_view_acransac(clc_ctx* ctx, int model, const double* h_x1, const double* h_x2, int N, const double* h_K1, const double* h_K2,
+                          int img_w, int img_h, int max_iteration, uint64_t seed, double precision, double* h_M, double* h_F,
+                          uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers, double* error_max, double* min_nfa, int* iterations)
+{
+    const int kind = two_view_kind(model);
+    if (kind < 0) return fail(ctx, CLC_ERR_BAD_ARG, "two_view_acransac: model must be 'E', 'F' or 'H'");
+    if (kind == 1)
+        return clc_essential_acransac(ctx, h_x1, h_x2, N, h_K1, h_K2, img_w, img_h, max_iteration, seed, precision, h_M, h_F, h_inlier_mask,
+                                      h_inliers, n_inliers, error_max, min_nfa, iterations);
+    double M9[9] = {};
+    const int rc = acr_impl(ctx, kind, h_x1, h_x2, N, nullptr, nullptr, img_w, img_h, max_iteration, seed, precision, -1.0, M9, h_inlier_mask,
+                            h_inliers, n_inliers, error_max, min_nfa, iterations, nullptr, nullptr, nullptr);
+    if (h_M) memcpy(h_M, M9, sizeof M9);
+    if (h_F) { if (kind == 2) memcpy(h_F, M9, sizeof M9); else memset(h_F, 0, sizeof M9); }
+    return rc;
+}
+
+int clc_two_view_minimal(clc_ctx* ctx, int model, const double* h_x1, const double* h_x2, int N, int img_w, int img_h, const int32_t* h_samples,
+                         int S, double* h_models)
+{
+    const int kind = two_view_kind(model);
+    if (!ctx || kind < 2 || N <= 0 || S < 0 || !h_x1 || !h_x2 || img_w <= 0 || img_h <= 0 || (S > 0 && (!h_samples || !h_models)))
+        return fail(ctx, CLC_ERR_BAD_ARG, "two_view_minimal: bad argument (models 'F' and 'H')");
+    if (S == 0) return CLC_OK;
+    const int m = kind == 2 ? 7 : 4, M = kind == 2 ? 3 : 1;
+    CLC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t pts = (size_t)4 * N, smp = dbl(sizeof(int32_t) * (size_t)S * m), out = (size_t)S * M * 9;
+    int rc = ensure_pnp(ctx, pts + smp + out + 8);
+    if (rc != CLC_OK) return rc;
+    std::vector<double> q(pts);
+    const tv::Normalizer t = tv::normalizer(img_w, img_h);
+    for (int i = 0; i < N; ++i) {
+        q[2 * i] = h_x1[2 * i] * t.d + t.tx; q[2 * i + 1] = h_x1[2 * i + 1] * t.d + t.ty;
+        q[(size_t)2 * N + 2 * i] = h_x2[2 * i] * t.d + t.tx; q[(size_t)2 * N + 2 * i + 1] = h_x2[2 * i + 1] * t.d + t.ty;
+    }
+    double* d = ctx->d_pnp;
+    int32_t* d_smp = (int32_t*)(d + pts);
+    double* d_out = d + pts + smp;
+    CLC_HIP(ctx, hipMemcpyAsync(d, q.data(), sizeof(double) * pts, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, hipMemcpyAsync(d_smp, h_samples, sizeof(int32_t) * (size_t)S * m, hipMemcpyHostToDevice, ctx->stream));
+    CLC_HIP(ctx, launch_twoview_minimal(kind, d, d + (size_t)2 * N, N, d_smp, S, d_out, ctx->stream));
+    CLC_HIP(ctx, hipMemcpyAsync(h_models, d_out, sizeof(double) * out, hipMemcpyDeviceToHost, ctx->stream));
+    CLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CLC_OK;
+}
+
 } // extern "C"
 
 namespace {
 
-void two_view_begin(AcrRun& r, clc_ctx* ctx, clc_two_view_job& jb, double* EF, const bool lockstep, hipStream_t group_stream)
+void two_view_begin(AcrRun& r, clc_ctx* ctx, clc_two_view_job& jb, double* EF, const bool lockstep, hipStream_t group_stream, const int kind)
 {
     r.grouped = lockstep; r.group_stream = group_stream;
     if (jb.E) memset(jb.E, 0, sizeof(double) * 9);
     if (jb.F) memset(jb.F, 0, sizeof(double) * 9);
     jb.n_inliers = 0; jb.iterations = 0; jb.error_max = 0.0; jb.min_nfa = INFINITY;
-    r.ctx = ctx; r.kind = 1; r.h_a = jb.x1; r.h_b = jb.x2; r.N = jb.n; r.h_K1 = jb.K1; r.h_K2 = jb.K2; r.img_w = jb.img_w; r.img_h = jb.img_h;
+    r.ctx = ctx; r.kind = kind; r.h_a = jb.x1; r.h_b = jb.x2; r.N = jb.n; r.h_K1 = jb.K1; r.h_K2 = jb.K2; r.img_w = jb.img_w; r.img_h = jb.img_h;
     r.max_iteration = jb.max_iteration; r.seed = jb.seed; r.precision = jb.precision; r.refine_huber = -1.0;
     r.h_model = EF; r.h_mask = jb.inlier_mask; r.h_inliers = jb.inliers; r.n_inliers = &jb.n_inliers; r.error_max = &jb.error_max;
     r.min_nfa = &jb.min_nfa; r.iterations = &jb.iterations;
@@ -626,12 +706,14 @@ int check_batch_contexts(clc_ctx* const* ctxs, int n_jobs, const char* what)
 }
 
 
-int acr_two_view_batch(clc_ctx* const* ctxs, clc_two_view_job* const* jobs, int n_jobs)
+// kind 1: E -> job.E, F -> job.F; kinds 2 / 3: the model matrix -> job.E (RelativePose_Info::essential_matrix receives it, whatever the
+// model: RobustMatcher.hpp:141, :207), and job.F = F for kind 2, zeros for kind 3
+int acr_two_view_batch(clc_ctx* const* ctxs, clc_two_view_job* const* jobs, int n_jobs, int kind)
 {
     std::vector<AcrRun> runs((size_t)n_jobs);
     std::vector<double> EF((size_t)18 * n_jobs, 0.0);
-    const bool lockstep = acr_lockstep(1, n_jobs);
-    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], *jobs[i], &EF[(size_t)18 * i], lockstep, ctxs[0]->stream);
+    const bool lockstep = acr_lockstep(kind, n_jobs);
+    for (int i = 0; i < n_jobs; ++i) two_view_begin(runs[(size_t)i], ctxs[i], *jobs[i], &EF[(size_t)18 * i], lockstep, ctxs[0]->stream, kind);
     if (lockstep) drive_group(runs); else drive_runs(runs);
     int worst = CLC_OK;
     for (int i = 0; i < n_jobs; ++i) {
@@ -639,7 +721,7 @@ int acr_two_view_batch(clc_ctx* const* ctxs, clc_two_view_job* const* jobs, int 
         r.finish();
         jobs[i]->status = r.status;
         if (jobs[i]->E) memcpy(jobs[i]->E, &EF[(size_t)18 * i], sizeof(double) * 9);
-        if (jobs[i]->F) memcpy(jobs[i]->F, &EF[(size_t)18 * i + 9], sizeof(double) * 9);
+        if (jobs[i]->F) memcpy(jobs[i]->F, &EF[(size_t)18 * i + (kind == 1 ? 9 : (kind == 2 ? 0 : 9))], sizeof(double) * 9);
         if (r.status != CLC_OK && worst == CLC_OK) worst = r.status;
     }
     return worst;
@@ -657,7 +739,19 @@ int clc_essential_acransac_batch(clc_ctx* const* ctxs, clc_two_view_job* jobs, i
     if (rc0 != CLC_OK) return rc0;
     std::vector<clc_two_view_job*> ptr((size_t)n_jobs);
     for (int i = 0; i < n_jobs; ++i) ptr[(size_t)i] = &jobs[i];
-    return acr_two_view_batch(ctxs, ptr.data(), n_jobs);
+    return acr_two_view_batch(ctxs, ptr.data(), n_jobs, 1);
+}
+
+int clc_two_view_acransac_batch(clc_ctx* const* ctxs, int model, clc_two_view_job* jobs, int n_jobs)
+{
+    const int kind = two_view_kind(model);
+    if (kind < 0 || n_jobs < 0 || (n_jobs > 0 && (!ctxs || !jobs))) return CLC_ERR_BAD_ARG;
+    if (n_jobs == 0) return CLC_OK;
+    const int rc0 = check_batch_contexts(ctxs, n_jobs, "two_view_acransac_batch: every job needs a context of its own");
+    if (rc0 != CLC_OK) return rc0;
+    std::vector<clc_two_view_job*> ptr((size_t)n_jobs);
+    for (int i = 0; i < n_jobs; ++i) ptr[(size_t)i] = &jobs[i];
+    return acr_two_view_batch(ctxs, ptr.data(), n_jobs, kind);
 }
 
 } // extern "C"

@@ -40,8 +40,9 @@ extern "C" {
  * clc_pnp_localize_ac_batch / clc_pose_job, one-rank communicators in clc_mc_create).  3: round 5's additions (clc_desc_cache_mode,
  * clc_describe_match_pair_dev, clc_essential_acransac_batch, clc_inter_pose_batch, clc_k2nn_device_info) and round 6's changes
  * (clc_describe_match_pair_dev lost its `chunks` argument, CLC_K2NN_MATRIX_PLAIN is gone, the descriptor hand-over is by ownership:
- * clc_desc_cache_publish returns a handle).  Bindings check clc_abi_version() BEFORE resolving symbols an older library does not export. */
-#define CLC_ABI_VERSION 3
+ * clc_desc_cache_publish returns a handle).  4: the 'F' / 'H' models of the two-view filter (clc_two_view_acransac, _batch, clc_two_view_minimal).
+ * Bindings check clc_abi_version() BEFORE resolving symbols an older library does not export. */
+#define CLC_ABI_VERSION 4
 #define CLC_DESC_BYTES 64
 #define CLC_MAX_LEVELS 8
 #define CLC_MAX_BATCH 8    /* cameras per clc_describe_batch_dev / clc_detect_batch_dev call */
@@ -552,6 +553,30 @@ typedef struct clc_two_view_job {
     double        error_max, min_nfa;
 } clc_two_view_job;
 int clc_essential_acransac_batch(clc_ctx* const* ctxs, clc_two_view_job* jobs, int n_jobs);
+
+/* The same a-contrario filter under RobustMatcher's other two models (ABI 4; RobustMatcher.hpp:399-405 dispatches on colocParams::model):
+ *   CLC_MODEL_FUNDAMENTAL 'F'  filterFundamental :128-151  ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError, UnnormalizerT>(.., true)
+ *   CLC_MODEL_HOMOGRAPHY  'H'  filterHomography  :188-239  ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI>(.., false)
+ *   CLC_MODEL_ESSENTIAL   'E'  = clc_essential_acransac (h_M = E, h_F = F)
+ * h_x1 / h_x2: N x 2 pixels; both images img_w x img_h (the reference hands params.imageSize for both): the points are conditioned by the
+ * image size, samples of 7 (4) correspondences give <= 3 (1) models, residual = squared distance to the epipolar line in image 2
+ * ('F', point-to-line alpha0, residual^(1/2)) / squared transfer error ('H', point-to-point alpha0), both in conditioned coordinates.
+ * h_M (9, nullable): the model brought back to PIXELS (x2^T F x1 = 0; x2 ~ H x1) -- what RelativePose_Info::essential_matrix receives;
+ * h_F (9, nullable): F for 'E' and 'F', zeros for 'H'.  *error_max: the a-contrario threshold in pixels (sqrt(e) / N2(0,0)); K1 / K2
+ * are read for 'E' only.  The rounds are the resection's (one launch per round: replay + seven-/four-point solve + residuals, sort, NFA). */
+enum { CLC_MODEL_ESSENTIAL = 'E', CLC_MODEL_FUNDAMENTAL = 'F', CLC_MODEL_HOMOGRAPHY = 'H' };
+int clc_two_view_acransac(clc_ctx* ctx, int model, const double* h_x1, const double* h_x2, int N, const double* h_K1,
+                          const double* h_K2, int img_w, int img_h, int max_iteration, uint64_t seed, double precision,
+                          double* h_M, double* h_F, uint8_t* h_inlier_mask, int32_t* h_inliers, int* n_inliers,
+                          double* error_max, double* min_nfa, int* iterations);
+/* Several filters of ONE model at once, as clc_essential_acransac_batch (which is this with 'E'): job.E receives the model matrix (E, F
+ * or H), job.F the fundamental matrix ('E', 'F') or zeros ('H'); job.K1 / K2 are read for 'E' only. */
+int clc_two_view_acransac_batch(clc_ctx* const* ctxs, int model, clc_two_view_job* jobs, int n_jobs);
+/* The minimal solver of 'F' / 'H' on caller-chosen samples (the hypothesis generator the tests hand to the sequential oracle, as
+ * clc_pnp_p3p / clc_essential_fivepoint are for the other kinds): h_samples S x 7 (4) indices into the N correspondences; h_models
+ * S x 3 (1) x 9 matrices IN CONDITIONED COORDINATES, NaN-filled where a sample has fewer real roots. */
+int clc_two_view_minimal(clc_ctx* ctx, int model, const double* h_x1, const double* h_x2, int N, int img_w, int img_h,
+                         const int32_t* h_samples, int S, double* h_models);
 
 /* The inter-camera step of ColoC::interPoseEstimator(source, dest) between the pair's putative matches and the covariance intersection
  * (coloc.hpp:296-340), for several camera pairs at once: a-contrario five-point filter (filterMatchesPair, :296) -> relative pose from

@@ -146,12 +146,15 @@ void orc_epipolar_residuals(const double* F, int H, const double* x1, const doub
 
 /* ---- a-contrario RANSAC (oracle/clc_oracle_acr.c; include/coloc/Localizer.hpp:82-93, RobustMatcher.hpp:153-171) ---- */
 
-/* minimal solver callback: `sample` holds the m data indices (3 for kind 0, 5 for kind 1); writes up to 4 (10) models of
- * 12 (18) doubles -- [R|t] row-major, resp. {F (9), E (9)} -- in solver order and returns how many */
+/* minimal solver callback: `sample` holds the m data indices (3 for kind 0, 5 for kind 1, 7 for kind 2, 4 for kind 3); writes up to
+ * 4 (10, 3, 1) models of 12 (18, 9, 9) doubles -- [R|t] row-major, {F (9), E (9)}, resp. F / H IN NORMALISED COORDINATES
+ * (orc_tv_normalize) -- in solver order and returns how many */
 typedef int (*orc_acr_fit_fn)(void* user, const uint32_t* sample, double* models_out);
 
 /* kind 0: resection, a = X (N x 3), b = x (N x 2 pixels), K1 = intrinsics (9, row-major);
- * kind 1: essential, a = x1, b = x2 (N x 2 pixels), img_w x img_h = size of image 2 (logalpha0).
+ * kind 1: essential, a = x1, b = x2 (N x 2 pixels), img_w x img_h = size of image 2 (logalpha0);
+ * kind 2: fundamental (RobustMatcher.hpp:128-151), kind 3: homography (:188-239): a = x1, b = x2 (pixels), both images img_w x img_h;
+ *         the loop runs on coordinates conditioned by the image size and model_out is the matrix brought back to pixels.
  * precision = +inf: pure a-contrario mode (what the reference passes).  Outputs: the model, the inliers in ascending
  * residual order (capacity N), the precision found (pixels for kind 0), the minimum log10 NFA, the iteration that
  * produced the model and the number of iterations run.  Returns 1 if a meaningful model (NFA < 0) was found. */
@@ -165,6 +168,18 @@ void orc_acr_tables(int n, int m, float* logc_n, float* logc_k);
 double orc_acr_best_nfa(const double* err, int n, int m, int max_models, double logalpha0, double mult, int* k_out);
 /* the sample of iteration `iter`: m distinct positions in [0, n_index) -- the oracle's OWN statement of the documented sampler */
 void orc_acr_sample(uint64_t seed, uint32_t iter, uint32_t n_index, int m, uint32_t* pos);
+
+
+/* ---- the seven-point / four-point models (oracle/clc_oracle_twoview.c; RobustMatcher.hpp:128-151, :188-239) ---- */
+/* q1, q2: 7 (4) normalised correspondences {u, v}; F_out: up to 3 matrices of 9 (x2^T F x1 = 0), H_out: 9 (x2 ~ H x1); returns the count */
+int orc_seven_point(const double* q1, const double* q2, double* F_out);
+int orc_four_point(const double* q1, const double* q2, double* H_out);
+/* ACKernelAdaptor's conditioning by the image size: {d, tx, ty} of T = [d 0 tx; 0 d ty; 0 0 1]; x_n = T x; F = T^T Fn T, H = T^-1 Hn T */
+void orc_tv_normalizer(int w, int h, double* d_tx_ty);
+void orc_tv_normalize(int w, int h, const double* x, int n, double* xn);
+void orc_tv_unnormalize(int homography, int w, int h, const double* Mn, double* M);
+/* kind 2: squared distance of x2 to the epipolar line F x1; kind 3: squared transfer error |x2 - H x1|^2 (normalised coordinates) */
+void orc_tv_residuals(int kind, const double* M, const double* q1, const double* q2, int n, double* e);
 
 #ifdef __cplusplus
 }

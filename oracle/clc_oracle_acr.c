@@ -5,6 +5,8 @@
  *                reference include/coloc/Localizer.hpp:82-93  ->  robust::ACRANSAC(ACKernelAdaptorResection_Intrinsics)
  *   - two-view:  robust::ACRANSAC(ACKernelAdaptorEssential<FivePointSolver, SymmetricEpipolarDistanceError>, inliers,
  *                256, &E, +inf)   reference include/coloc/RobustMatcher.hpp:153-171
+ *   - and the same loop over ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError> ('F', :128-151) and
+ *                ACKernelAdaptor<FourPointSolver, AsymmetricError> ('H', :188-239): kinds 2 / 3, see clc_oracle_twoview.c
  *
  * PARITY UNPINNED: lib/openMVG is an empty, unpinned submodule in the reference tree (.gitmodules:1-3), nothing of it
  * can be built or run here and the reference holds no fixture for this step.  The control flow and the NFA arithmetic
@@ -134,8 +136,10 @@ static void acr_errors(int kind, const double* model, const double* a, const dou
             const double dv = (b[2 * i + 1] - v / w) * s;
             e[i] = du * du + dv * dv;
         }
-    } else {
+    } else if (kind == 1) {
         orc_epipolar_residuals(model, 1, a, b, n, e);     /* SymmetricEpipolarDistanceError on pixels, F = model[0..8] */
+    } else {
+        orc_tv_residuals(kind, model, a, b, n, e);        /* 'F' / 'H' on the normalised coordinates (clc_oracle_twoview.c) */
     }
 }
 
@@ -144,7 +148,10 @@ int orc_acransac(int kind, const double* a, const double* b, int n, const double
                  double* model_out, uint32_t* inliers_out, int* n_inliers_out, double* error_max_out, double* min_nfa_out,
                  int32_t* best_iter_out, int32_t* iterations_run_out)
 {
-    const int m = kind == 0 ? 3 : 5, M = kind == 0 ? 4 : 10, md = kind == 0 ? 12 : 18;
+    /* kind 0 resection (P3P), 1 essential (five points), 2 fundamental (seven points), 3 homography (four points) */
+    static const int k_m[4] = { 3, 5, 7, 4 }, k_M[4] = { 4, 10, 3, 1 }, k_md[4] = { 12, 18, 9, 9 };
+    if (kind < 0 || kind > 3) return 0;
+    const int m = k_m[kind], M = k_M[kind], md = k_md[kind];
     if (n_inliers_out) *n_inliers_out = 0;
     if (error_max_out) *error_max_out = 0.0;
     if (min_nfa_out) *min_nfa_out = INFINITY;
@@ -153,8 +160,25 @@ int orc_acransac(int kind, const double* a, const double* b, int n, const double
     if (n <= m) return 0;
     /* resection: log10(pi) (error on the normalised camera plane); essential: point-to-line, 2 D / A * 0.5 of image 2 */
     double logalpha0, mult, norm2;
+    double* norm_pts = NULL;
+    double nrm0 = 1.0;                                   /* N2(0,0) of the ACKernelAdaptor kinds */
     if (kind == 0) { logalpha0 = log10(M_PI); mult = 1.0; norm2 = (1.0 / K1[0]) * (1.0 / K1[0]); }
-    else {
+    else if (kind >= 2) {
+        /* ACKernelAdaptor: both point sets conditioned by the image size; point-to-line ('F') log10(2 D / A / N2(0,0)) with the
+         * square root of the error, point-to-point ('H') log10(pi / A / N2(0,0)^2); the models live in normalised coordinates */
+        double t[3];
+        orc_tv_normalizer(img_w, img_h, t);
+        nrm0 = t[0];
+        const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
+        if (kind == 2) { logalpha0 = log10(2.0 * D / A / nrm0); mult = 0.5; }
+        else { logalpha0 = log10(M_PI / A / (nrm0 * nrm0)); mult = 1.0; }
+        norm2 = nrm0 * nrm0;
+        norm_pts = (double*)malloc(sizeof(double) * 4 * (size_t)n);
+        orc_tv_normalize(img_w, img_h, a, n, norm_pts);
+        orc_tv_normalize(img_w, img_h, b, n, norm_pts + 2 * (size_t)n);
+        a = norm_pts;
+        b = norm_pts + 2 * (size_t)n;
+    } else {
         const double D = sqrt((double)img_w * (double)img_w + (double)img_h * (double)img_h), A = (double)img_w * (double)img_h;
         const double al = 2.0 * D / A * .5;
         logalpha0 = log10(al);
@@ -227,11 +251,16 @@ int orc_acransac(int kind, const double* a, const double* b, int n, const double
     if (n_inl > 0) {
         memcpy(inliers_out, inl, sizeof(uint32_t) * (size_t)n_inl);
         /* unormalizeError: resection sqrt(e) / N1(0,0) (pixels); essential: identity */
-        if (error_max_out) *error_max_out = kind == 0 ? sqrt(error_max) / (1.0 / K1[0]) : error_max;
+        if (error_max_out) *error_max_out = kind == 0 ? sqrt(error_max) / (1.0 / K1[0]) : (kind == 1 ? error_max : sqrt(error_max) / nrm0);
+        if (kind >= 2) {                                 /* Unnormalize(model): back to pixels */
+            double Mp[9];
+            orc_tv_unnormalize(kind == 3, img_w, img_h, model_out, Mp);
+            memcpy(model_out, Mp, sizeof Mp);
+        }
     }
     if (n_inliers_out) *n_inliers_out = n_inl;
     if (min_nfa_out) *min_nfa_out = min_nfa;
-    free(models); free(inl); free(index); free(se); free(e); free(logc_k); free(logc_n);
+    free(models); free(inl); free(index); free(se); free(e); free(logc_k); free(logc_n); free(norm_pts);
     return n_inl > 0;
 }
 

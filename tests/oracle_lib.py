@@ -214,12 +214,13 @@ class Oracle:
         return float(v), int(k.value)
 
     def acransac(self, kind, a, b, K1, fit, max_iteration=256, seed=1, precision=float("inf"), img_wh=(0, 0)):
-        """Sequential AC-RANSAC.  kind 0: a = X (N,3), b = x (N,2); kind 1: a = x1, b = x2.  `fit(sample) -> array
-        (n_models, 12 | 18)` is the minimal solver (valid models only, solver order).  Returns a dict."""
+        """Sequential AC-RANSAC.  kind 0: a = X (N,3), b = x (N,2); kind 1 (essential), 2 (fundamental), 3 (homography): a = x1,
+        b = x2 in pixels.  `fit(sample) -> array (n_models, 12 | 18 | 9 | 9)` is the minimal solver (valid models only, solver order;
+        kinds 2 / 3: models in the coordinates tv_normalize gives).  Returns a dict."""
         a = np.ascontiguousarray(a, dtype=np.float64); b = np.ascontiguousarray(b, dtype=np.float64)
         K1 = np.ascontiguousarray(K1, dtype=np.float64).reshape(9)
         n = a.shape[0]
-        md, m = (12, 3) if kind == 0 else (18, 5)
+        md, m = {0: (12, 3), 1: (18, 5), 2: (9, 7), 3: (9, 4)}[kind]
         FIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double))
         calls = []
 
@@ -243,6 +244,41 @@ class Oracle:
                                       C.byref(nfa), C.byref(best_it), C.byref(its))
         return dict(found=bool(found), model=model, inliers=inl[:n_inl.value].copy(), error_max=emax.value, min_nfa=nfa.value,
                     best_iter=best_it.value, iterations=its.value, samples=calls)
+
+
+    # ---- seven-point / four-point models (oracle/clc_oracle_twoview.c) ----
+    def tv_normalize(self, wh, x):
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, 2)
+        out = np.zeros_like(x)
+        self.lib.orc_tv_normalize(C.c_int(int(wh[0])), C.c_int(int(wh[1])), _ptr(x), C.c_int(x.shape[0]), _ptr(out))
+        return out
+
+    def tv_unnormalize(self, homography, wh, Mn):
+        Mn = np.ascontiguousarray(Mn, dtype=np.float64).reshape(9)
+        out = np.zeros(9)
+        self.lib.orc_tv_unnormalize(C.c_int(1 if homography else 0), C.c_int(int(wh[0])), C.c_int(int(wh[1])), _ptr(Mn), _ptr(out))
+        return out.reshape(3, 3)
+
+    def seven_point(self, q1, q2):
+        q1 = np.ascontiguousarray(q1, dtype=np.float64).reshape(7, 2); q2 = np.ascontiguousarray(q2, dtype=np.float64).reshape(7, 2)
+        F = np.zeros(27)
+        self.lib.orc_seven_point.restype = C.c_int
+        n = self.lib.orc_seven_point(_ptr(q1), _ptr(q2), _ptr(F))
+        return [F[9 * k:9 * k + 9].copy() for k in range(n)]
+
+    def four_point(self, q1, q2):
+        q1 = np.ascontiguousarray(q1, dtype=np.float64).reshape(4, 2); q2 = np.ascontiguousarray(q2, dtype=np.float64).reshape(4, 2)
+        H = np.zeros(9)
+        self.lib.orc_four_point.restype = C.c_int
+        self.lib.orc_four_point(_ptr(q1), _ptr(q2), _ptr(H))
+        return H
+
+    def tv_residuals(self, kind, M, q1, q2):
+        q1 = np.ascontiguousarray(q1, dtype=np.float64).reshape(-1, 2); q2 = np.ascontiguousarray(q2, dtype=np.float64).reshape(-1, 2)
+        M = np.ascontiguousarray(M, dtype=np.float64).reshape(9)
+        e = np.zeros(q1.shape[0])
+        self.lib.orc_tv_residuals(C.c_int(kind), _ptr(M), _ptr(q1), _ptr(q2), C.c_int(q1.shape[0]), _ptr(e))
+        return e
 
 
 class RefFeeder:

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export " + n
     assert sorted(abi.EXPORTS) == names
-    assert lib.clc_abi_version() == abi.ABI_VERSION == 3
+    assert lib.clc_abi_version() == abi.ABI_VERSION == 4
     assert lib.clc_status_string(2) == b"capacity exceeded"
 
 

@@ -30,7 +30,7 @@ def test_configure_build_install_and_consume(tmp_path):
     lib = C.CDLL(str(so))
     for name in _declared():
         assert hasattr(lib, name), "missing export " + name
-    assert lib.clc_abi_version() == 3
+    assert lib.clc_abi_version() == 4
     # the consumer: find_package(coloc_hip) + target_link_libraries(... coloc_hip::coloc_hip)
     cons = tmp_path / "consumer"
     run(["cmake", "-S", os.path.join(ROOT, "tests", "cmake_consumer"), "-B", str(cons), "-DCMAKE_PREFIX_PATH=" + str(prefix),
