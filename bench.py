@@ -1015,6 +1015,23 @@ def main():
                                        "a round = two launches since round 5 (replay + samples + five-point solve ~44 us; nfa ~11 us)",
                                "p50_ms": float(np.median(te[5:])), "inliers": int(len(r["inliers"])), "iterations": int(r["iterations"]),
                                "fixed_threshold_p50_ms": float(np.median(tf[5:]))}
+            # the other two models RobustMatcher can filter with (RobustMatcher.hpp:128-151 'F', :188-239 'H'; round 6): the same
+            # correspondences under the seven-point model, and the same cameras looking at a plane under the four-point one.  Their
+            # rounds are ONE launch each (the solve is a few microseconds on one thread of every slot workgroup), like the resection's.
+            nrm = np.array([0.1, -0.05, 1.0]); nrm /= np.linalg.norm(nrm)
+            rays = np.c_[p1, np.ones(Nc)] @ np.linalg.inv(Kc).T
+            Xp = rays * (9.0 / (rays @ nrm))[:, None]
+            q2 = (Xp @ Rc.T + np.array([0.5, 0.1, 0.2])) @ Kc.T; q2 = q2[:, :2] / q2[:, 2:3] + rng2.normal(0, 0.5, (Nc, 2))
+            q2[oi] = p2[oi]
+            for mdl, b2 in (("F", p2), ("H", q2)):
+                tm = []
+                for it in range(35):
+                    t1 = time.perf_counter()
+                    rm = ctx.two_view_acransac(mdl, p1, b2, (1280, 720), max_iteration=256, seed=it + 1)
+                    tm.append((time.perf_counter() - t1) * 1e3)
+                out["two_view"]["model_" + mdl] = {"what": "clc_two_view_acransac '%s' (%s), same sizes" % (mdl, "seven-point, distance to the epipolar line" if mdl == "F" else "four-point, transfer error; planar scene"),
+                                                   "p50_ms": float(np.median(tm[5:])), "inliers": int(len(rm["inliers"])), "iterations": int(rm["iterations"]),
+                                                   "threshold_px": float(rm["error_max"])}
             # the same filter for 4 / 8 camera pairs in ONE clc_essential_acransac_batch call (what a frame of the streaming loop asks for):
             # the pairs' rounds share their launches (lockstep, blockIdx.y = pair; CLC_ACR_LOCKSTEP=0: chains of their own, interleaved --
             # 8 pairs 1.08-1.21 ms against 0.80), results job by job those of the single calls

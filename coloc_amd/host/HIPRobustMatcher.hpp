@@ -1,5 +1,5 @@
-// HIPRobustMatcher.hpp -- the essential-matrix path of coloc::RobustMatcher (reference
-// include/coloc/RobustMatcher.hpp:153-186, 372-424) over the C ABI of libcoloc_hip.so.
+// HIPRobustMatcher.hpp -- coloc::RobustMatcher (reference include/coloc/RobustMatcher.hpp) over the C ABI of libcoloc_hip.so: the
+// a-contrario filter under all three of its models, the poses that come out of them, and the members ColoC calls.
 //
 //   bool filterEssential(intrinsics1, intrinsics2, x1, x2, relativePose_info, params, findPose)      :153-186
 //        ACRANSAC(ACKernelAdaptorEssential<FivePointSolver, SymmetricEpipolarDistanceError>, inliers, 256, &E,
@@ -19,7 +19,10 @@
 //        only used to log f1^T F f2 per match to "guidedmatches2.txt" (:334-349).  Host arithmetic, no GPU work.
 // x1 / x2 are 2 x N UNDISTORTED pixel coordinates (computeRelativePose undistorts with get_ud_pixel, :391-397).
 // Status convention as the reference: EXIT_SUCCESS / EXIT_FAILURE through bool, FALSE MEANS SUCCESS.
-// Only model 'E' (the one coloc_node.cpp:87 selects) is provided; 'F' / 'H' stay with OpenMVG on the host.
+//   bool filterFundamental(...)  :128-151   ('F': seven points, distance to the epipolar line)     -> clc_two_view_acransac
+//   bool filterHomography(...)   :188-239   ('H': four points, transfer error; decomposeHomography :106-126 -- cv::decomposeHomographyMat
+//        restated on the host -- and performChiralityTest :39-104 for the pose)                     -> clc_two_view_acransac
+// coloc_node.cpp:87 selects 'E'; 'F' / 'H' are reachable through colocParams::model like in the reference (:399-405).
 #pragma once
 
 #include <array>
@@ -27,6 +30,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <map>
 #include <vector>
 
@@ -153,13 +157,16 @@ inline bool triangulate_dlt(const openMVG::Vec3& f1, const openMVG::Vec3& f2, co
     return true;
 }
 
-inline bool RelativePoseFromEssential(const openMVG::Mat3X& x1, const openMVG::Mat3X& x2, const openMVG::Mat3& E,
-                                      const std::vector<uint32_t>& bearing_vector_index_to_use, openMVG::geometry::Pose3* relative_pose,
-                                      std::vector<uint32_t>* vec_selected_points = nullptr, std::vector<openMVG::Vec3>* vec_points = nullptr,
-                                      const double positive_depth_solution_ratio = 0.7)
+// The chirality vote over candidate relative poses: every listed correspondence is triangulated (DLT on the bearing vectors) under each
+// candidate, the candidate with most points in front of both cameras wins (the first of equals), and the result is trusted when the
+// runner-up has less than `positive_depth_solution_ratio` of its count.  OpenMVG's RelativePoseFromEssential ends in it and
+// RobustMatcher::performChiralityTest (RobustMatcher.hpp:39-104) is the same code over the candidates of a homography.
+inline bool chirality_vote(const openMVG::Mat3X& x1, const openMVG::Mat3X& x2, const std::vector<uint32_t>& bearing_vector_index_to_use,
+                           const std::vector<openMVG::geometry::Pose3>& relative_poses, openMVG::geometry::Pose3* relative_pose,
+                           std::vector<uint32_t>* vec_selected_points, std::vector<openMVG::Vec3>* vec_points,
+                           const double positive_depth_solution_ratio)
 {
-    std::vector<openMVG::geometry::Pose3> relative_poses;
-    motion_from_essential(E, &relative_poses);
+    if (relative_poses.empty()) return false;
     std::vector<uint32_t> cheirality_accumulator(relative_poses.size(), 0);
     std::vector<std::vector<uint32_t>> vec_newInliers(relative_poses.size());
     std::vector<std::vector<openMVG::Vec3>> vec_3D(relative_poses.size());
@@ -184,13 +191,140 @@ inline bool RelativePoseFromEssential(const openMVG::Mat3X& x1, const openMVG::M
     size_t index = 0;
     for (size_t i = 1; i < cheirality_accumulator.size(); ++i) if (cheirality_accumulator[i] > cheirality_accumulator[index]) index = i;
     if (cheirality_accumulator[index] == 0) return false;
-    *relative_pose = relative_poses[index];
+    if (relative_pose) *relative_pose = relative_poses[index];
     if (vec_selected_points) *vec_selected_points = vec_newInliers[index];
     if (vec_points) *vec_points = vec_3D[index];
     std::vector<uint32_t> sorted(cheirality_accumulator);
     for (size_t a = 0; a < sorted.size(); ++a) for (size_t b = a + 1; b < sorted.size(); ++b) if (sorted[b] < sorted[a]) { const uint32_t t = sorted[a]; sorted[a] = sorted[b]; sorted[b] = t; }
+    if (sorted.size() < 2) return true;                  // (one candidate: nothing to compare with; the reference indexes rbegin()[1] here)
     const double ratio = sorted[sorted.size() - 2] / static_cast<double>(sorted[sorted.size() - 1]);
     return ratio < positive_depth_solution_ratio;
+}
+
+inline bool RelativePoseFromEssential(const openMVG::Mat3X& x1, const openMVG::Mat3X& x2, const openMVG::Mat3& E,
+                                      const std::vector<uint32_t>& bearing_vector_index_to_use, openMVG::geometry::Pose3* relative_pose,
+                                      std::vector<uint32_t>* vec_selected_points = nullptr, std::vector<openMVG::Vec3>* vec_points = nullptr,
+                                      const double positive_depth_solution_ratio = 0.7)
+{
+    std::vector<openMVG::geometry::Pose3> relative_poses;
+    motion_from_essential(E, &relative_poses);
+    return chirality_vote(x1, x2, bearing_vector_index_to_use, relative_poses, relative_pose, vec_selected_points, vec_points,
+                          positive_depth_solution_ratio);
+}
+
+// cv::decomposeHomographyMat(H, K, rotations, translations, normals) as RobustMatcher::decomposeHomography calls it (RobustMatcher.hpp:
+// 106-126).  OpenCV is not part of the reference tree; this restates the analytical method its implementation documents (E. Malis,
+// M. Vargas, "Deeper understanding of the homography decomposition for vision-based control", INRIA RR-6303, 2007):
+//   Hn = K^-1 H K scaled by 1 / (its middle singular value);  S = Hn^T Hn - I;  a pure rotation (|S|_inf < 1e-3) gives the one motion
+//   {Hn, 0, 0};  otherwise the two plane normals n_a, n_b come from the minors of S around its largest diagonal entry, the translations
+//   (in the first frame) from the norms r^2 = 2 + tr S + v, |t|^2 = 2 + tr S - v, v = 2 sqrt(1 + tr S - M00 - M11 - M22), and
+//   R = Hn (I - (2 / v) t* n^T), negated when its determinant is negative;  four motions {Ra, ta, na}, {Ra, -ta, -na}, {Rb, tb, nb},
+//   {Rb, -tb, -nb} with t = R t*.
+struct HomographyMotion { openMVG::Mat3 R; openMVG::Vec3 t, n; };
+inline double opposite_of_minor(const openMVG::Mat3& M, const int row, const int col)
+{
+    const int x1 = col == 0 ? 1 : 0, x2 = col == 2 ? 1 : 2, y1 = row == 0 ? 1 : 0, y2 = row == 2 ? 1 : 2;
+    return M(y1, x2) * M(y2, x1) - M(y1, x1) * M(y2, x2);
+}
+inline double det3(const openMVG::Mat3& A)
+{
+    return A(0, 0) * (A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1)) - A(0, 1) * (A(1, 0) * A(2, 2) - A(1, 2) * A(2, 0)) +
+           A(0, 2) * (A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0));
+}
+inline int decompose_homography_mat(const openMVG::Mat3& H, const openMVG::Mat3& K, std::vector<HomographyMotion>* motions)
+{
+    motions->clear();
+    // K^-1 of an upper-triangular calibration matrix
+    const double fx = K(0, 0), sk = K(0, 1), cx = K(0, 2), fy = K(1, 1), cy = K(1, 2);
+    openMVG::Mat3 Ki;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ki(i, j) = 0.0;
+    Ki(0, 0) = 1.0 / fx; Ki(0, 1) = -sk / (fx * fy); Ki(0, 2) = (sk * cy - cx * fy) / (fx * fy);
+    Ki(1, 1) = 1.0 / fy; Ki(1, 2) = -cy / fy; Ki(2, 2) = 1.0;
+    openMVG::Mat3 Hn = mul(mul(Ki, H), K);
+    // removeScale: divide by the middle singular value (square roots of the eigenvalues of Hn^T Hn)
+    {
+        std::array<double, 9> HtH{};
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) HtH[3 * i + j] = Hn(0, i) * Hn(0, j) + Hn(1, i) * Hn(1, j) + Hn(2, i) * Hn(2, j);
+        std::array<double, 3> w;
+        std::array<double, 9> V;
+        jacobi_eigen<3>(HtH, w, V);
+        double a = w[0], b = w[1], c = w[2], t;
+        if (a < b) { t = a; a = b; b = t; }
+        if (b < c) { t = b; b = c; c = t; if (a < b) { t = a; a = b; b = t; } }
+        const double mid = std::sqrt(b > 0.0 ? b : 0.0);
+        if (!(mid > 0.0)) return 0;
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Hn(i, j) /= mid;
+    }
+    openMVG::Mat3 S = mul(transpose(Hn), Hn);
+    S(0, 0) -= 1.0; S(1, 1) -= 1.0; S(2, 2) -= 1.0;
+    double ninf = 0.0;                                   // cv::norm(S, NORM_INF): the largest absolute entry
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) ninf = std::max(ninf, std::fabs(S(i, j)));
+    if (ninf < 0.001) {
+        HomographyMotion m;
+        m.R = Hn; m.t = openMVG::Vec3(0, 0, 0); m.n = openMVG::Vec3(0, 0, 0);
+        motions->push_back(m);
+        return 1;
+    }
+    auto signd = [](const double x) { return x >= 0.0 ? 1 : -1; };
+    const double M00 = opposite_of_minor(S, 0, 0), M11 = opposite_of_minor(S, 1, 1), M22 = opposite_of_minor(S, 2, 2);
+    const double rtM00 = std::sqrt(M00), rtM11 = std::sqrt(M11), rtM22 = std::sqrt(M22);
+    const double M01 = opposite_of_minor(S, 0, 1), M12 = opposite_of_minor(S, 1, 2), M02 = opposite_of_minor(S, 0, 2);
+    const int e12 = signd(M12), e02 = signd(M02), e01 = signd(M01);
+    const double nS00 = std::fabs(S(0, 0)), nS11 = std::fabs(S(1, 1)), nS22 = std::fabs(S(2, 2));
+    int indx = 0;
+    if (nS00 < nS11) { indx = 1; if (nS11 < nS22) indx = 2; }
+    else if (nS00 < nS22) indx = 2;
+    openMVG::Vec3 npa, npb;
+    switch (indx) {
+    case 0:
+        npa[0] = S(0, 0);               npb[0] = S(0, 0);
+        npa[1] = S(0, 1) + rtM22;       npb[1] = S(0, 1) - rtM22;
+        npa[2] = S(0, 2) + e12 * rtM11; npb[2] = S(0, 2) - e12 * rtM11;
+        break;
+    case 1:
+        npa[0] = S(0, 1) + rtM22;       npb[0] = S(0, 1) - rtM22;
+        npa[1] = S(1, 1);               npb[1] = S(1, 1);
+        npa[2] = S(1, 2) - e02 * rtM00; npb[2] = S(1, 2) + e02 * rtM00;
+        break;
+    default:
+        npa[0] = S(0, 2) + e01 * rtM11; npb[0] = S(0, 2) - e01 * rtM11;
+        npa[1] = S(1, 2) + rtM00;       npb[1] = S(1, 2) - rtM00;
+        npa[2] = S(2, 2);               npb[2] = S(2, 2);
+        break;
+    }
+    const double traceS = S(0, 0) + S(1, 1) + S(2, 2);
+    const double v = 2.0 * std::sqrt(1.0 + traceS - M00 - M11 - M22);
+    const double ESii = signd(S(indx, indx));
+    const double r_2 = 2.0 + traceS + v, nt_2 = 2.0 + traceS - v;
+    const double r = std::sqrt(r_2), n_t = std::sqrt(nt_2);
+    auto norm3 = [](const openMVG::Vec3& a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
+    const double na_n = norm3(npa), nb_n = norm3(npb);
+    openMVG::Vec3 na, nb, ta_star, tb_star;
+    for (int i = 0; i < 3; ++i) { na[i] = npa[i] / na_n; nb[i] = npb[i] / nb_n; }
+    const double half_nt = 0.5 * n_t, esii_t_r = ESii * r;
+    for (int i = 0; i < 3; ++i) {
+        ta_star[i] = half_nt * (esii_t_r * nb[i] - n_t * na[i]);
+        tb_star[i] = half_nt * (esii_t_r * na[i] - n_t * nb[i]);
+    }
+    auto rotation_of = [&](const openMVG::Vec3& tstar, const openMVG::Vec3& n) {
+        openMVG::Mat3 A;                                 // I - (2 / v) t* n^T
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A(i, j) = (i == j ? 1.0 : 0.0) - (2.0 / v) * tstar[i] * n[j];
+        openMVG::Mat3 R = mul(Hn, A);
+        if (det3(R) < 0.0) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = -R(i, j);
+        return R;
+    };
+    auto apply = [](const openMVG::Mat3& R, const openMVG::Vec3& a) {
+        return openMVG::Vec3(R(0, 0) * a[0] + R(0, 1) * a[1] + R(0, 2) * a[2], R(1, 0) * a[0] + R(1, 1) * a[1] + R(1, 2) * a[2],
+                             R(2, 0) * a[0] + R(2, 1) * a[1] + R(2, 2) * a[2]);
+    };
+    auto neg = [](const openMVG::Vec3& a) { return openMVG::Vec3(-a[0], -a[1], -a[2]); };
+    const openMVG::Mat3 Ra = rotation_of(ta_star, na), Rb = rotation_of(tb_star, nb);
+    const openMVG::Vec3 ta = apply(Ra, ta_star), tb = apply(Rb, tb_star);
+    motions->push_back(HomographyMotion{ Ra, ta, na });
+    motions->push_back(HomographyMotion{ Ra, neg(ta), neg(na) });
+    motions->push_back(HomographyMotion{ Rb, tb, nb });
+    motions->push_back(HomographyMotion{ Rb, neg(tb), neg(nb) });
+    return 4;
 }
 
 } // namespace hipgeom
@@ -253,28 +387,79 @@ public:
         return EXIT_SUCCESS;
     }
 
-    // RobustMatcher::filterFundamental (:128-151) and ::filterHomography (:188-230).  NOT on the GPU path, on purpose and by name: the
-    // hot path SURVEY.md section 8 (f-2) scopes is the essential-matrix model, the one `coloc_node.cpp:87` selects ('E'); the other two
-    // need OpenMVG's seven-point / four-point solvers with its point normalisation (ACKernelAdaptor) and, for 'H', OpenCV's
-    // decomposeHomographyMat (RobustMatcher.hpp:106-126) -- none of it in the reference tree.  They keep the reference's signatures so
-    // that code that names them compiles, return EXIT_FAILURE like a failed estimate, and say why: lastStatus() ==
-    // kModelNotOnGpuPath (a caller can fall back to the reference's CPU RobustMatcher for these two models).
-    enum Status { kOk = 0, kEstimateFailed = 1, kModelNotOnGpuPath = 2 };
+    enum Status { kOk = 0, kEstimateFailed = 1, kModelNotOnGpuPath = 2 /* a model letter RobustMatcher.hpp:399-405 does not know */ };
     Status lastStatus() const { return last_status_; }
-    bool filterFundamental(const openMVG::cameras::IntrinsicBase*, const openMVG::cameras::IntrinsicBase*, const openMVG::Mat&, const openMVG::Mat&,
-                           openMVG::sfm::RelativePose_Info&, colocParams&, bool)
+
+    // RobustMatcher::filterFundamental (:128-151): ACRANSAC(ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError, UnnormalizerT>(x1, w, h,
+    // x2, w, h, true), inliers, 256, &F, initial_residual_tolerance) -> clc_two_view_acransac(.., 'F', ..); the matrix goes where the
+    // reference puts it (relativePose_info.essential_matrix), found_residual_precision is the constant 5.0 of :145, failure iff fewer
+    // than 2.5 x 7 inliers; findPose is not used by this model (no pose comes out of F alone in the reference either).
+    bool filterFundamental(const openMVG::cameras::IntrinsicBase* intrinsics1, const openMVG::cameras::IntrinsicBase* intrinsics2,
+                           const openMVG::Mat& x1, const openMVG::Mat& x2, openMVG::sfm::RelativePose_Info& relativePose_info, colocParams& prm,
+                           bool /*findPose*/)
     {
-        return not_on_gpu_path('F', "RobustMatcher.hpp:128-151 (SevenPointSolver + EpipolarDistanceError)");
+        if (!intrinsics1 || !intrinsics2 || !ctx_) return EXIT_FAILURE;
+        double emax = 0.0;
+        if (!two_view_filter(CLC_MODEL_FUNDAMENTAL, x1, x2, prm, relativePose_info.initial_residual_tolerance, relativePose_info, &emax))
+            return EXIT_FAILURE;
+        relativePose_info.found_residual_precision = 5.0;
+        if (relativePose_info.vec_inliers.size() < 2.5 * 7) return EXIT_FAILURE;
+        return EXIT_SUCCESS;
     }
-    bool filterHomography(const openMVG::cameras::IntrinsicBase*, const openMVG::cameras::IntrinsicBase*, const openMVG::Mat&, const openMVG::Mat&,
-                          openMVG::sfm::RelativePose_Info&, colocParams&, bool)
+
+    // RobustMatcher::decomposeHomography (:106-126): the motions of H under params->K[0], every translation normalised and handed to
+    // Pose3 in the place of the CENTRE, as the reference writes it (:123).  Returns EXIT_SUCCESS.
+    bool decomposeHomography(openMVG::Mat3& H, std::vector<openMVG::geometry::Pose3>& motions)
     {
-        return not_on_gpu_path('H', "RobustMatcher.hpp:188-230 (FourPointSolver + AsymmetricError, cv::decomposeHomographyMat)");
+        std::vector<hipgeom::HomographyMotion> ms;
+        hipgeom::decompose_homography_mat(H, params->K[0], &ms);
+        for (const hipgeom::HomographyMotion& m : ms) {
+            const double nt = std::sqrt(m.t[0] * m.t[0] + m.t[1] * m.t[1] + m.t[2] * m.t[2]);
+            const openMVG::Vec3 tn = nt > 0.0 ? openMVG::Vec3(m.t[0] / nt, m.t[1] / nt, m.t[2] / nt) : m.t;   // (Eigen: normalized() of 0 is 0)
+            motions.emplace_back(m.R, tn);
+        }
+        return EXIT_SUCCESS;
+    }
+
+    // RobustMatcher::performChiralityTest (:39-104): the vote of RelativePoseFromEssential over caller-supplied candidates
+    bool performChiralityTest(const openMVG::Mat3X& x1, const openMVG::Mat3X& x2, const openMVG::Mat3& /*E*/,
+                              const std::vector<uint32_t>& bearing_vector_index_to_use, std::vector<openMVG::geometry::Pose3> relative_poses,
+                              openMVG::geometry::Pose3* final_pose, std::vector<uint32_t>* vec_selected_points = nullptr,
+                              std::vector<openMVG::Vec3>* vec_points = nullptr, const double positive_depth_solution_ratio = 0.7)
+    {
+        return hipgeom::chirality_vote(x1, x2, bearing_vector_index_to_use, relative_poses, final_pose, vec_selected_points, vec_points,
+                                       positive_depth_solution_ratio);
+    }
+
+    // RobustMatcher::filterHomography (:188-239): ACRANSAC(ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI>(x1, w, h, x2,
+    // w, h, false), inliers, 256, &H, +inf) -> clc_two_view_acransac(.., 'H', ..); failure iff fewer than 2.5 x 4 inliers; otherwise
+    // found_residual_precision = the a-contrario threshold and, with findPose, the motions of H voted on by the chirality test -- whose
+    // verdict the reference does not look at (:218): relativePose is whatever it left in final_pose.
+    bool filterHomography(const openMVG::cameras::IntrinsicBase* intrinsics1, const openMVG::cameras::IntrinsicBase* intrinsics2,
+                          const openMVG::Mat& x1, const openMVG::Mat& x2, openMVG::sfm::RelativePose_Info& relativePose_info, colocParams& prm,
+                          bool findPose)
+    {
+        if (!intrinsics1 || !intrinsics2 || !ctx_) return EXIT_FAILURE;
+        const openMVG::Mat3X normpt2D_1 = (*intrinsics1)(x1), normpt2D_2 = (*intrinsics2)(x2);
+        double emax = 0.0;
+        if (!two_view_filter(CLC_MODEL_HOMOGRAPHY, x1, x2, prm, std::numeric_limits<double>::infinity(), relativePose_info, &emax))
+            return EXIT_FAILURE;
+        if (relativePose_info.vec_inliers.size() < 4 * 2.5) return EXIT_FAILURE;
+        relativePose_info.found_residual_precision = emax;
+        if (findPose) {
+            std::vector<openMVG::geometry::Pose3> motions;
+            decomposeHomography(relativePose_info.essential_matrix, motions);
+            openMVG::geometry::Pose3 final_pose;
+            (void)performChiralityTest(normpt2D_1, normpt2D_2, relativePose_info.essential_matrix, relativePose_info.vec_inliers, motions,
+                                       &final_pose);
+            relativePose_info.relativePose = final_pose;
+        }
+        return EXIT_SUCCESS;
     }
 
     // RobustMatcher::computeRelativePose (:372-424): positions of the pair's putative matches, undistorted through each camera's
-    // radial-K3 model, into the filter selected by params->model (:399-405).  Only the essential-matrix model ('E', the one the
-    // reference's own launch code uses) runs on the GPU; 'F' / 'H' report kModelNotOnGpuPath (above).
+    // radial-K3 model, into the filter selected by params->model (:399-405): 'E' (the one the reference's own launch code uses), 'F'
+    // or 'H', all three on the GPU; another letter is "Unknown filtering type" (:406-408) -> kModelNotOnGpuPath.
     bool computeRelativePose(openMVG::sfm::RelativePose_Info& relativePose, openMVG::Pair current_pair, FeatureMap& regions,
                              openMVG::matching::PairWiseMatches& putativeMatches)
     {
@@ -302,8 +487,11 @@ public:
             status = filterEssential(&camL, &camR, xL, xR, relativePose, *params, true);
             if (status == EXIT_FAILURE) last_status_ = kEstimateFailed;
         }
-        else if (params->model == 'F') status = filterFundamental(&camL, &camR, xL, xR, relativePose, *params, true);
-        else if (params->model == 'H') status = filterHomography(&camL, &camR, xL, xR, relativePose, *params, true);
+        else if (params->model == 'F' || params->model == 'H') {
+            status = params->model == 'F' ? filterFundamental(&camL, &camR, xL, xR, relativePose, *params, true)
+                                          : filterHomography(&camL, &camR, xL, xR, relativePose, *params, true);
+            if (status == EXIT_FAILURE) last_status_ = kEstimateFailed;
+        }
         else status = not_on_gpu_path(params->model, "RobustMatcher.hpp:399-405 knows 'E', 'F', 'H'");
         if (status == EXIT_FAILURE && last_status_ != kModelNotOnGpuPath) std::cerr << "Unable to estimate relative pose." << std::endl;
         return status;
@@ -381,11 +569,34 @@ public:
     }
 
 private:
+    // the a-contrario filter of model 'F' / 'H' on the GPU: inliers and the model matrix (pixels) into relativePose_info; false: the call failed
+    bool two_view_filter(const int model, const openMVG::Mat& x1, const openMVG::Mat& x2, colocParams& prm, const double precision,
+                         openMVG::sfm::RelativePose_Info& relativePose_info, double* emax)
+    {
+        const int n = static_cast<int>(x1.cols());
+        std::vector<double> p1(2 * static_cast<size_t>(n)), p2(2 * static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) {
+            p1[2 * i] = x1(0, i); p1[2 * i + 1] = x1(1, i);
+            p2[2 * i] = x2(0, i); p2[2 * i + 1] = x2(1, i);
+        }
+        double M[9] = {}, nfa = 0.0;
+        std::vector<int32_t> inl(static_cast<size_t>(n > 0 ? n : 1));
+        int n_inl = 0, its = 0;
+        const int rc = clc_two_view_acransac(ctx_, model, p1.data(), p2.data(), n, nullptr, nullptr, static_cast<int>(prm.imageSize.first),
+                                             static_cast<int>(prm.imageSize.second), iterationCount, seed++, precision, M, nullptr, nullptr,
+                                             inl.data(), &n_inl, emax, &nfa, &its);
+        if (rc != CLC_OK) {
+            std::cerr << "HIPRobustMatcher: clc_two_view_acransac: " << clc_last_error_string(ctx_) << std::endl;
+            return false;
+        }
+        relativePose_info.vec_inliers.assign(inl.begin(), inl.begin() + n_inl);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) relativePose_info.essential_matrix(i, j) = M[3 * i + j];
+        return true;
+    }
     bool not_on_gpu_path(const char model, const char* where)
     {
         last_status_ = kModelNotOnGpuPath;
-        std::cerr << "HIPRobustMatcher: filtering model '" << model << "' is not on the GPU path (" << where
-                  << "); only the essential-matrix model 'E' is -- use the reference's CPU RobustMatcher for this model." << std::endl;
+        std::cerr << "HIPRobustMatcher: unknown filtering type '" << model << "' (" << where << ")." << std::endl;
         return EXIT_FAILURE;
     }
     Status last_status_ = kOk;

@@ -90,6 +90,5 @@ def test_localizer_and_two_view_drivers(tmp_path, gpu_ctx):
     assert abs(n_geo - n2) <= 0.02 * n2 and n_pose == 1 and n_cons == n_geo
     C3 = tail[3:6]
     assert (C3 @ Crel) / (np.linalg.norm(C3) * np.linalg.norm(Crel)) > 0.995
-    # models 'F' and 'H' (RobustMatcher.hpp:128-151, 188-230) are declared with the reference's signatures and answer
-    # kModelNotOnGpuPath -- a status of their own, not the failure of an estimate; 'E' leaves kOk
+    # an unknown model letter answers kModelNotOnGpuPath -- a status of its own, not the failure of an estimate; 'E' and 'F' leave kOk
     assert tail[6] == 1.0
