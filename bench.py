@@ -175,6 +175,7 @@ def run_exchange_legs(args, ctx, dist, torch, dev, world, rank, step, fence, d_m
                 out[leg] = {"error": err or "another rank could not map the peers' arenas"}
             else:
                 got = torch.full_like(d_match, -9)
+                torch.cuda.synchronize(dev)      # (torch fills on ITS stream; the library launches on another, non-blocking one: order them)
                 sweep_stream = torch.cuda.Stream(device=dev) if overlap else None
                 sweep_ptr = sweep_stream.cuda_stream if overlap else sptr
                 # what RCCL says about the communicator each rank holds (ncclCommCount, ncclCommUserRank): (0, -1) on rehearsal handles
@@ -398,6 +399,7 @@ def main():
             s_x = torch.cuda.Stream(device=dev)
             a_x = torch.zeros_like(arena)
             m_x = torch.empty_like(d_match)
+            torch.cuda.synchronize(dev)
             extra_lanes.append((c_x, s_x, a_x, m_x))
             lanes.append((c_x, s_x.cuda_stream, a_x, m_x, [a_x[c].data_ptr() for c in cams]))
     tick = [0]
@@ -803,6 +805,7 @@ def main():
                 st2 = torch.cuda.Stream(device=dev)
                 arena2 = torch.zeros_like(arena)
                 match2 = torch.empty_like(d_match)
+                torch.cuda.synchronize(dev)
                 lanes = [(ctx, sptr, arena, d_match, [arena[c].data_ptr() for c in cams]),
                          (ctx2, st2.cuda_stream, arena2, match2, [arena2[c].data_ptr() for c in cams])]
                 want = d_match[:n_out].clone()
@@ -864,6 +867,7 @@ def main():
             bk = [torch.zeros((capk, 20), dtype=torch.uint8, device=dev) for _ in range(8)]
             bc = [torch.zeros((2,), dtype=torch.int32, device=dev) for _ in range(8)]
             bd = [torch.zeros((capk, 64), dtype=torch.uint8, device=dev) for _ in range(8)]
+            torch.cuda.synchronize(dev)
             for nb in (4, 8):
                 ip = [imgs[i % len(imgs)].data_ptr() for i in range(nb)]
                 args_ = (ip, W, H, W, [t.data_ptr() for t in bk[:nb]], [t.data_ptr() for t in bc[:nb]], [t.data_ptr() for t in bd[:nb]], sptr)
@@ -1100,6 +1104,7 @@ def main():
                 kp2 = [torch.from_numpy(synth.random_keypoints(NKP, W2, H2, seed=2200 + c).view(np.uint8).reshape(-1, 20).copy()).to(dev)
                        for c in range(4)]
                 ar2 = torch.zeros((4, NKP, 64), dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize(dev)
                 cnts = [NKP] * 4
                 jb = multicam.jobs_to_abi(multicam.shard_pairs(cnts, 1, 0, grain=ctx2.k2nn_queries_per_block), cnts, NKP, THR)
                 ip, kp_ = [t.data_ptr() for t in imgs2], [t.data_ptr() for t in kp2]
@@ -1119,6 +1124,7 @@ def main():
                 # pyramid, two detector and one CLATCH launch), the pairs are matched with the counts read on the device
                 kb = [torch.zeros((NKP, 20), dtype=torch.uint8, device=dev) for _ in range(4)]
                 cb = [torch.zeros((2,), dtype=torch.int32, device=dev) for _ in range(4)]
+                torch.cuda.synchronize(dev)
                 kbp, cbp = [t.data_ptr() for t in kb], [t.data_ptr() for t in cb]
                 prs = multicam.exhaustive_pairs(4)
                 jb2 = [(a_ * NKP, NKP, b_ * NKP, NKP, k_ * NKP, THR) for k_, (a_, b_) in enumerate(prs)]
@@ -1211,6 +1217,7 @@ def main():
                 det.pyramid_build_dev(d_img.data_ptr(), W, H, W, None)
                 kp_dev, _ = det.detect(capacity=12000)
                 tmp = torch.zeros((max(len(kp_dev), 1), 64), dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize(dev)
                 det.describe_detected_dev(tmp.data_ptr(), None)
                 det.sync()
                 desc_dev = tmp.cpu().numpy()[:len(kp_dev)]

@@ -37,6 +37,8 @@
 #include "coloc_hip.h"
 #include "coloc_hip_geometry.hpp"
 
+static_assert(CLC_ABI_VERSION >= 4, "this policy header uses entry points of ABI version 4 (clc_two_view_acransac)");
+
 namespace coloc {
 namespace hipgeom {
 

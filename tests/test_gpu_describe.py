@@ -174,6 +174,7 @@ def test_batched_cameras_equal_per_image_calls(oracle):
             d_imgs.append(t)
         d_kps = [torch.from_numpy(k.view(np.uint8).reshape(-1, 20).copy()).cuda() if len(k) else torch.zeros((1, 20), dtype=torch.uint8, device="cuda:0") for k in kps]
         d_desc = [torch.full((max(c, 1), 64), 0xAB, dtype=torch.uint8, device="cuda:0") for c in counts]
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         torch.cuda.synchronize()
         ctx.describe_batch_dev([t.data_ptr() for t in d_imgs], W, H, pitch, [t.data_ptr() for t in d_kps], counts,
                                [t.data_ptr() for t in d_desc])

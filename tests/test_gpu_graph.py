@@ -25,6 +25,7 @@ def test_describe_match_step_captured_and_replayed(oracle):
     arena = torch.zeros((2, N, 64), dtype=torch.uint8, device=dev)
     d_pair = torch.full((N,), -9, dtype=torch.int32, device=dev)
     d_map = torch.full((N,), -9, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
     jobs = multicam.jobs_to_abi(multicam.shard_pairs([N, N], 1, 0, grain=ctx.k2nn_queries_per_block), [N, N], N, 40)
 
     def fill(rep):
@@ -87,6 +88,7 @@ def test_detect_describe_counted_match_captured_and_replayed(oracle):
     cnt = [torch.zeros((2,), dtype=torch.int32, device=dev) for _ in range(2)]
     arena = torch.zeros((2, CAP, 64), dtype=torch.uint8, device=dev)
     d_pair = torch.full((CAP,), -9, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
 
     def step():
         ctx.detect_batch_dev([t.data_ptr() for t in imgs], W, H, W, [t.data_ptr() for t in kps], [t.data_ptr() for t in cnt],

@@ -184,6 +184,7 @@ def test_map_tracking_on_device_equals_host_path(gpu_ctx, oracle):
     assert np.array_equal(gpu_ctx.match_map(Q, 60), want)
     d_q = torch.from_numpy(Q).cuda()
     d_m = torch.full((Q.shape[0],), -7, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
     torch.cuda.synchronize()
     gpu_ctx.match_map_dev(d_q.data_ptr(), Q.shape[0], 60, d_m.data_ptr())
     gpu_ctx.sync()
@@ -224,6 +225,7 @@ def test_two_contexts_two_streams_concurrently(oracle, k2nn_formulation):
     dq = [torch.from_numpy(q).cuda() for q, _ in data]
     dt = [torch.from_numpy(t).cuda() for _, t in data]
     dm = [torch.full((q.shape[0],), -7, dtype=torch.int32, device="cuda:0") for q, _ in data]
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
     torch.cuda.synchronize()
     for rep in range(5):
         for i, c in enumerate(ctxs):
@@ -248,6 +250,7 @@ def test_clock_check_grid_padding(gpu_ctx, oracle, k2nn_formulation, nq, nt):
     dq, dt = torch.from_numpy(Q).cuda(), torch.from_numpy(T).cuda()
     out = torch.full((nq,), -9, dtype=torch.int32, device="cuda")
     guard = torch.full((1 << 16,), 0x5A, dtype=torch.uint8, device="cuda")      # a neighbour a stray stamp would likely hit
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
     med, lo, hi, wgs = gpu_ctx.k2nn_clock_check(dq.data_ptr(), nq, dt.data_ptr(), nt, out.data_ptr())
     torch.cuda.synchronize()
     assert 0.5 < lo <= med <= hi < 3.0 and wgs > 0
@@ -282,6 +285,7 @@ def test_counted_jobs_read_their_sizes_on_the_device(gpu_ctx, oracle):
         ct = (C.c_void_p * 2)(cnt.data_ptr() + 4, cnt.data_ptr() + 4)
         row0 = (C.c_uint32 * 2)(0, split)
         out = torch.full((cap,), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         rc = gpu_ctx.lib.clc_match_jobs_counted_dev(gpu_ctx.h, d_arena.data_ptr(), jobs, 2, cq, ct, row0, out.data_ptr(), None)
         assert rc == 0, gpu_ctx.lib.clc_last_error_string(gpu_ctx.h)
         gpu_ctx.sync()

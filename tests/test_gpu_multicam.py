@@ -38,6 +38,7 @@ def test_every_ranks_jobs_reassemble_to_the_all_pairs_loop(oracle, world, counts
         jobs = multicam.shard_pairs(counts, world, r)
         world_jobs.append(jobs)
         out = torch.full((max(1, sum(j.nq for j in jobs)),), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         with torch.cuda.stream(st):
             ctx.match_jobs_dev(arena.data_ptr(), multicam.jobs_to_abi(jobs, counts, cap, 40), out.data_ptr(), st.cuda_stream)
         st.synchronize()
@@ -77,6 +78,7 @@ def test_c_entry_points_every_rank_of_a_virtual_world(oracle, world, counts):
         got_counts = mc.gather_dev(dev[r].data_ptr(), counts[r], mode=r % 2)
         assert got_counts == counts
         out = torch.full((max(1, cap * world),), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         shares = mc.match_dev(40, out.data_ptr(), cap * world)
         ctx.sync()
         assert shares == [(j.pair[0], j.pair[1], j.q_begin, j.nq, j.out_offset)
@@ -126,6 +128,7 @@ def test_enqueue_only_steps_with_different_descriptors_every_step(oracle, world,
     for r in range(world):
         mc = MultiCam(ctx, world=world, rank=r, maxkp=cap)
         outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in steps]
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         shares_by_step = []
 
         def put_others(step):
@@ -179,6 +182,7 @@ def test_sync_steps_alternate_buffers(oracle):
         assert mc.gather_dev(dev[1].data_ptr(), counts[1], mode=1) == counts
         seen.append(mc.arena())
         out = torch.full((cap * world,), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         shares = mc.match_dev(40, out.data_ptr(), cap * world)
         ctx.sync()
         want = oracle.k2nn(descs[0], descs[1], 40)
@@ -221,6 +225,7 @@ def test_one_rank_communicator_drives_the_rccl_abi(oracle, mode):
         assert mc.counts(stream=st.cuda_stream) == [n]
         arena = mc.arena()
         out = torch.full((cap,), -9, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         ctx.match_2nn_dev(arena, n, d_other.data_ptr(), len(other), 40, out.data_ptr(), stream=st.cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy()[:n], oracle.k2nn(desc, other, 40))
@@ -252,6 +257,7 @@ def test_host_counts_of_four_steps_enqueued_behind_a_backed_up_stream(oracle):
     torch.cuda.synchronize()
     counts = [2000, 300, 1234, 64]
     outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in counts]
+    torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
     with torch.cuda.stream(st):
         torch.cuda._sleep(int(2.0e8))                  # ~0.1 s of device time in front of everything that follows
     shares = []
@@ -312,6 +318,7 @@ def test_config3_at_size_eight_cameras_of_ten_thousand_keypoints(oracle, overlap
             mc.set_overlap(True)
         assert mc.comm_info() == (0, -1)                              # a rehearsal handle has no communicator
         outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in range(nsteps)]
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         shares = []
         for s, (descs, dev) in enumerate(steps):
             for o in range(world):
@@ -362,6 +369,7 @@ def test_overlapped_steps_equal_one_stream_steps_with_ragged_counts(oracle):
             if overlap:
                 mc.set_overlap(True)
             outs = [torch.full((cap * world,), -9, dtype=torch.int32, device="cuda") for _ in steps]
+            torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
             shares = []
             for s, (counts, descs, dev, d_cnt) in enumerate(steps):
                 for o in range(world):

@@ -37,6 +37,7 @@ def test_pair_step_equals_oracle(oracle, formulation, nq, nt):
         assert nq < 3000 or nt < 3000 or (want_m >= 0).sum() > nq // 4              # the cameras see the same scene: the accept branch is exercised
         desc = [torch.full((max(n, 1), 64), 0xA5, dtype=torch.uint8, device="cuda") for n in (nq, nt)]
         match = torch.full((max(nq, 1),), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         torch.cuda.synchronize()
         for rep in range(3):                                                        # rows and arrival words re-arm
             ctx.describe_match_pair_dev([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [nq, nt],
@@ -65,6 +66,7 @@ def test_pair_step_back_to_back_with_changing_inputs(oracle):
             nq, nt = shapes[it % len(shapes)]
             desc = [torch.zeros((10000, 64), dtype=torch.uint8, device="cuda") for _ in range(2)]
             match = torch.full((10000,), -7, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
             ctx.describe_match_pair_dev([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [nq, nt],
                                         [t.data_ptr() for t in desc], 40, match.data_ptr())
             outs.append((nq, nt, desc, match))
@@ -90,6 +92,7 @@ def test_pair_step_is_capturable(oracle):
         imgs, kps, d_imgs, d_kps = _inputs(torch, n, n, seed=9)
         desc = [torch.zeros((n, 64), dtype=torch.uint8, device="cuda") for _ in range(2)]
         match = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()      # the fill runs on torch's stream, the library on its own (non-blocking) one: order them
         st = torch.cuda.Stream()
         args = ([t.data_ptr() for t in d_imgs], W, H, W, [t.data_ptr() for t in d_kps], [n, n], [t.data_ptr() for t in desc], 40, match.data_ptr())
         with torch.cuda.stream(st):
