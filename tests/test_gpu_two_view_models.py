@@ -70,6 +70,17 @@ def test_equals_sequential_oracle(gpu_ctx, oracle, model, n, seed):
 
 
 @pytest.mark.parametrize("model", ["F", "H"])
+def test_more_than_8192_correspondences(gpu_ctx, oracle, model):
+    """16 elements per thread in the sort (the widest form of the round kernel), and the capacity is reported past 16 384"""
+    sc = tvh.scene(9000, 46, planar=model == "H")
+    got, want = _check_exact(gpu_ctx, oracle, model, sc, max_it=40, seed=46)
+    assert want["found"] and len(got["inliers"]) > 5000
+    big = tvh.scene(16385, 47, planar=model == "H")
+    with pytest.raises(abi.CLCError):
+        gpu_ctx.two_view_acransac(model, big["x1"], big["x2"], big["wh"], max_iteration=8)
+
+
+@pytest.mark.parametrize("model", ["F", "H"])
 def test_other_outlier_rates_iteration_counts_and_seeds(gpu_ctx, oracle, model):
     for n, outl, max_it, seed in [(200, 0.0, 64, 1), (400, 0.5, 256, 2), (800, 0.6, 512, 3), (150, 0.2, 16, 4), (64, 0.3, 40, 5)]:
         sc = tvh.scene(n, 50 + seed, planar=model == "H", outlier_frac=outl)
