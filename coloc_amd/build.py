@@ -19,7 +19,7 @@ HEADERS = ["clc_internal.h", "clc_ctx.h", "desc_cache.h", "inter_geometry.h", "c
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in plain VGPRs (gfx950's register file is unified), so the K2NN top-2 reads
 # them directly instead of through v_accvgpr_read copies.
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-mllvm", "-amdgpu-mfma-vgpr-form",
-          "-I", os.path.join(os.path.dirname(PKG), "include")]          # (capi.hip includes host/HIPRobustMatcher.hpp, which names coloc_hip.h plainly)
+          "-I", os.path.join(os.path.dirname(PKG), "include")]          # (inter_geometry.cpp includes host/HIPRobustMatcher.hpp, which names coloc_hip.h plainly)
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
 
 

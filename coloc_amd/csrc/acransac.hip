@@ -2,6 +2,8 @@
 // and two-view steps,
 //     SfM_Localizer::Localize(P3P_KE_CVPR17, ..., {error_max = +inf, max_iteration = 256})   include/coloc/Localizer.hpp:82-93
 //     ACRANSAC(ACKernelAdaptorEssential<FivePointSolver, SymmetricEpipolarDistanceError>, ...)  include/coloc/RobustMatcher.hpp:153-171
+//     ACRANSAC(ACKernelAdaptor<SevenPointSolver, EpipolarDistanceError, UnnormalizerT>, ...)    :128-151  ('F', round 6)
+//     ACRANSAC(ACKernelAdaptor<FourPointSolver, AsymmetricError, UnnormalizerI>, ...)           :188-239  ('H', round 6)
 // restated from the published algorithm (Moisan, Moulon, Monasse, IPOL 2012; see oracle/clc_oracle_acr.c for the
 // sequential form and what is unpinned).  Per model: residuals over ALL data, sorted with their indices, NFA(k) over
 // the k smallest, the model's value = min_k NFA(k); the run keeps the model with the lowest value, and once a
@@ -18,9 +20,10 @@
 //             the phase-switch rule), stops at the first iteration that changes the index set -- the iterations after it were
 //             sampled speculatively from the old set and are discarded; one workgroup then applies the side effects (device
 //             state, best inlier list, index set, the word the host polls, the result record when the run ends).
-// The resection path runs solve + nfa + the select of the PREVIOUS round as ONE launch per round (acr_round_kernel below), the
+// The resection path -- and the seven-point / four-point paths, whose solves are as short as a P3P -- runs solve + nfa + the select of
+// the PREVIOUS round as ONE launch per round (acr_round_kernel<E, KIND> below), the
 // five-point path as two (acr_solve5_kernel: select of the previous round + samples + solve; nfa); several solves of one kind can share
-// those launches (blockIdx.y = solve: the *_chains_kernel forms, driven in lockstep by capi.hip).  The host only polls one packed word per round in pinned memory to learn whether
+// those launches (blockIdx.y = solve: the *_chains_kernel forms, driven in lockstep by pose_batch.hip).  The host only polls one packed word per round in pinned memory to learn whether
 // another round is needed: one round to find the first meaningful model, then one per improvement in the reserve.  Results are identical to the
 // sequential oracle: same samples, bit-identical residuals (same operation order, no FMA contraction), a total order on
 // (residual, index), and the same portable log10 in the NFA terms.
@@ -1106,7 +1109,7 @@ hipError_t launch_acr_round_5pt(const AcrProblem& pb, int par, AcrState* d_state
     return e;
 }
 
-// ---- the same rounds for several solves in one launch (lockstep; capi.hip drives them) ----------------------------------------------
+// ---- the same rounds for several solves in one launch (lockstep; pose_batch.hip drives them) ----------------------------------------------
 template <typename K>
 static hipError_t acr_dyn_lds(K kernel, bool (&attr_set)[64])
 {

@@ -351,7 +351,7 @@ __device__ __forceinline__ uint32_t mx_decode_rel(const uint32_t bits, const uin
 // t covers the top-2 of chain 0 of tile t, chain 0 of tile t + 1 covers the top-2 of chain 1 of tile t -- so the kernel keeps its
 // three waves per SIMD; the price is that every A operand is read from LDS twice.  (Round 2's loop -- k-step outer, both chains per
 // A read, then all 64 v_med3 -- was kept as an A/B formulation through round 5: profiles/r06_removed_variants.patch.)
-// PROBE: the same code under another symbol, for the launches of the per-device share probe at context creation (capi.hip k2nn_probe_bias):
+// PROBE: the same code under another symbol, for the launches of the per-device share probe at context creation (capi_match.hip k2nn_probe_bias):
 // a kernel trace of an application then shows ITS sweeps under k2nn_sweep_mx_kernel<false, false, false> and the probe's -- run from cold
 // clocks, under four different share pairs -- under <..., true>, instead of one average over both.
 template <bool STAMP, bool GLOBAL = false, bool PROBE = false>
