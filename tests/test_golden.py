@@ -43,3 +43,25 @@ def test_feeder_against_reference_outputs(oracle):
         assert np.array_equal(np.stack([k["x"], k["y"], k["score"].astype(np.int32)], 1), g["xys_" + name])
         ang = np.array([oracle.feature_angle(img, int(p["x"]), int(p["y"])) for p in k], dtype=np.float32)
         assert np.array_equal(ang.view(np.uint32), g["angle_" + name].view(np.uint32))
+
+
+def test_twoview_models_golden(oracle):
+    """the a-contrario filter under the seven-point / four-point models, the oracle's own solvers (tests/golden/make_golden_twoview.py):
+    conditioning bit for bit, the first sample's models and the run's numbers to 1e-9 (libm's acos / cos / pow sit in the cubic),
+    the discrete results exactly"""
+    g = np.load(os.path.join(G, "twoview_models.npz"))
+    for model, kind in (("F", 2), ("H", 3)):
+        x1, x2, wh, seed = g[model + "_x1"], g[model + "_x2"], tuple(int(v) for v in g[model + "_wh"]), int(g[model + "_seed"])
+        q1, q2 = oracle.tv_normalize(wh, x1), oracle.tv_normalize(wh, x2)
+        assert np.array_equal(q1, g[model + "_q1"]) and np.array_equal(q2, g[model + "_q2"])
+        smp = g[model + "_first_sample"]
+        mods = oracle.seven_point(q1[smp], q2[smp]) if model == "F" else [oracle.four_point(q1[smp], q2[smp])]
+        assert np.allclose(np.array(mods), g[model + "_first_models"], rtol=1e-9, atol=1e-12)
+        fit = (lambda s: oracle.seven_point(q1[s], q2[s])) if model == "F" else (lambda s: [oracle.four_point(q1[s], q2[s])])
+        r = oracle.acransac(kind, x1, x2, np.eye(3), fit, max_iteration=128, seed=seed, img_wh=wh)
+        assert r["found"] and r["iterations"] == int(g[model + "_iterations"]) and r["best_iter"] == int(g[model + "_best_iter"])
+        assert np.array_equal(r["inliers"], g[model + "_inliers"])
+        assert np.allclose(r["model"], g[model + "_model"], rtol=1e-9, atol=1e-12)
+        assert abs(r["error_max"] - float(g[model + "_error_max"])) <= 1e-9 * float(g[model + "_error_max"])
+        assert abs(r["min_nfa"] - float(g[model + "_min_nfa"])) <= 1e-9 * abs(float(g[model + "_min_nfa"]))
+        assert np.array_equal(np.array(r["samples"][0]), smp)

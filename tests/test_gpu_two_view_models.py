@@ -210,3 +210,22 @@ def test_batches_equal_the_single_solves(gpu_ctx, model, n_jobs):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("model", ["F", "H"])
+def test_against_the_golden_fixture(gpu_ctx, model):
+    """tests/golden/twoview_models.npz (the oracle's filter with its own solvers, frozen): the device's models of the fixture's first
+    sample are the fixture's to rounding, and the device's filter keeps the fixture's inliers (another null-space basis: the runs may
+    end on different iterations, the solution of the scene is the same)"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "twoview_models.npz"))
+    x1, x2, wh, seed = g[model + "_x1"], g[model + "_x2"], tuple(int(v) for v in g[model + "_wh"]), int(g[model + "_seed"])
+    dev = [m for m in gpu_ctx.two_view_minimal(model, x1, x2, wh, g[model + "_first_sample"][None, :].astype(np.int32))[0] if not np.isnan(m).any()]
+    gold = list(g[model + "_first_models"])
+    assert len(dev) == len(gold)
+    for a in dev:
+        assert min(float(np.abs(tvh.unit(a) - tvh.unit(b)).max()) for b in gold) < 1e-6
+    got = gpu_ctx.two_view_acransac(model, x1, x2, wh, max_iteration=128, seed=seed)
+    a, b = set(got["inliers"].tolist()), set(g[model + "_inliers"].tolist())
+    assert got["M"] is not None and len(a & b) >= 0.95 * len(a | b)
+    assert 0.5 * float(g[model + "_error_max"]) <= got["error_max"] <= 2.0 * float(g[model + "_error_max"])
