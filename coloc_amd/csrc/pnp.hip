@@ -325,7 +325,6 @@ __device__ __forceinline__ bool invert6_column(const double* A, int c, double* i
 
 static constexpr int kRefineSums = 29;   // 21 (upper JtWJ) + 6 (JtWr) + 1 (cost) + 1 (points used)
 static constexpr int kRefineThreads = 512;
-static constexpr int kRefineWaves = kRefineThreads / 64;
 
 __global__ __launch_bounds__(kRefineThreads) void pnp_refine_kernel(const double* __restrict__ Rt_in, const double* __restrict__ X,
                                                                     const double* __restrict__ x, const uint8_t* __restrict__ mask,
