@@ -1,5 +1,5 @@
 """Soak: the virtual-world reassembly test of tests/test_gpu_multicam.py (8 ranks x 1200 keypoints) N times in one process.
-usage: python tools/soak/multicam_virtual_world_loop.py [N]"""
+usage: python tests/soak/multicam_virtual_world_loop.py [N]"""
 import os
 import sys
 

@@ -2,7 +2,7 @@
 the 16-column walk groups (every width class mod 16, widths 6 mod 16 over-represented), random level counts, thresholds and image kinds.
 usage: soak_detect.py [cases] [seed]   -- prints the first mismatch and exits 1."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np
 import synth, oracle_lib

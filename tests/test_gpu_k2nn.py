@@ -204,7 +204,7 @@ def test_complement_rows_distance_512(gpu_ctx, oracle):
 
 
 def test_repeated_full_size_sweeps_rearm(gpu_ctx, oracle):
-    """Bounded soak (tools/soak/soak_k2nn.py in small): 12 back-to-back 10k x 10k sweeps on one context, each with fresh
+    """Bounded soak (tests/soak/soak_k2nn.py in small): 12 back-to-back 10k x 10k sweeps on one context, each with fresh
     data, each equal to the oracle -- the self re-arming rows / arrival counters and the in-launch finalize ordering."""
     for rep in range(12):
         Q, T = synth.planted_descriptors(10000, 10000, seed=9000 + rep)
